@@ -1,0 +1,160 @@
+/*
+ * mrgnas.h -- C ABI of libmrgnas_hip.so: the MI355X (gfx950) implementation of
+ * MR-GNAS's relational message-passing hot path.
+ *
+ * The reference (Amanda-Zheng/MR-GNAS) is pure Python on PyTorch + DGL and has
+ * no FFI of its own; each entry point below replaces the ATen/DGL kernel
+ * sequence that one reference operator launches.  The citation on each
+ * function is the reference interface it stands in for (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *  - float tensors are float32, row-major, contiguous (leading dimension == D);
+ *  - graph index arrays are int32;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *    call only enqueues work on that stream -- no allocation, no
+ *    synchronisation, safe to capture into a hipGraph;
+ *  - scratch memory is caller-owned: ask mrg_*_workspace_bytes(), pass `ws`;
+ *  - return value: 0 = success, < 0 = argument error (MRG_E_*), > 0 = the
+ *    hipError_t of the failed launch.  mrg_error_string() explains either.
+ *  - row layout of every [M, D] edge tensor, M = E + N: rows [0, b0) original
+ *    direction ("in") edges, [b0, b1) inverse ("out") edges, [b1, M) one
+ *    self-loop row per node (reference models/model_lp.py:126-129,
+ *    models/model_search_lp.py:135-139).  The reference always has b0 = E/2,
+ *    b1 = E; relation-block shards pass their local boundaries.
+ */
+#ifndef MRGNAS_H
+#define MRGNAS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRG_ABI_VERSION 1
+
+#define MRG_OK            0
+#define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
+#define MRG_E_SHAPE      -2   /* negative size, or a size the kernels do not cover (D > 1024, or D > 256 with D % 4 != 0) */
+#define MRG_E_ENUM       -3   /* unknown op / mode / act code */
+#define MRG_E_WORKSPACE  -4   /* workspace pointer missing */
+
+/* compose codes (a1) */
+#define MRG_COMPOSE_MULT 0
+#define MRG_COMPOSE_SUB  1
+#define MRG_COMPOSE_ADD  2
+/* reducer codes (a4-a6) */
+#define MRG_REDUCE_SUM   0
+#define MRG_REDUCE_MEAN  1
+#define MRG_REDUCE_MAX   2
+/* activation codes for mrg_linear_fwd */
+#define MRG_ACT_NONE     0
+#define MRG_ACT_RELU     1
+
+int mrg_abi_version(void);
+const char *mrg_error_string(int code);
+/* Name of the code object's target, e.g. "gfx950". */
+const char *mrg_target_arch(void);
+
+/* ---- a1: compose ops ---------------------------------------------------
+ * pre_mult_op / pre_sub_op / pre_add_op .forward(g, src_emb, hr)
+ * reference models/operations_lp.py:71-98.   out = s (*|-|+) hr, [rows, D]. */
+int mrg_compose_fwd(int op, const float *s, const float *hr, float *out,
+                    int64_t rows, int D, void *stream);
+/* autograd of the above: gs/ghr may be NULL when not needed. */
+int mrg_compose_bwd(int op, const float *gout, const float *s, const float *hr,
+                    float *gs, float *ghr, int64_t rows, int D, void *stream);
+
+/* ---- G + a1: gather feeding the compose ----------------------------------
+ * all_ent_emb[src_id_final] (op) rel_embed[edge_type_final]
+ * reference models/model_lp.py:126-131, models/model_search_lp.py:135-145.
+ * out[i,:] = ent[ent_idx[i],:] (op) rel[rel_idx[i],:];  op = -1 copies ent rows
+ * only (plain gather, rel ignored). Bit-exact. */
+int mrg_gather_compose_fwd(int op, const float *ent, const float *rel,
+                           const int32_t *ent_idx, const int32_t *rel_idx,
+                           float *out, int64_t rows, int D, void *stream);
+
+/* floats per (u, v, c) slot of a gate: u at [0, D), v at [D, 2D), c at index
+ * in_dim (2D with s_in, D without); padded so every slot stays 16-byte aligned. */
+#define MRG_GATE_LD(D) (2 * (D) + 4)
+
+/* ---- a2 / a3: collapsed scalar gates --------------------------------------
+ * f_sparse_op_comp.forward  reference models/operations_lp.py:317-343
+ * f_sparse_op_last.forward  reference models/operations_lp.py:412-416
+ *
+ * a_x(W_x [s ; s_in] + b_x) has no non-linearity inside, so it equals
+ * u_x . s + v_x . s_in + c_x with  [u_x ; v_x] = W_x^T a_x,  c_x = a_x . b_x.
+ *
+ * mrg_gate_collapse:   uvc[0 .. in_dim) = W^T a,  uvc[in_dim] = a . b
+ *   W [D, in_dim] (nn.Linear weight), b [D] or NULL, a [D] (nn.Linear(D,1).weight). */
+int mrg_gate_collapse(const float *W, const float *b, const float *a, float *uvc,
+                      int D, int in_dim, void *stream);
+/* out[i,:] = sigmoid(u_x.s_i + v_x.s_in_i + c_x) * s_i * scale * (i < b1 ? norm[i] : 1)
+ *   x = segment of row i (0: i < b0, 1: b0 <= i < b1, 2: i >= b1)
+ *   uvc  [3][MRG_GATE_LD(D)]  (u, v, c per segment); s_in NULL => v ignored (f_sparse_last)
+ *   norm [b1] or NULL (=> 1).  f_sparse_comp: scale = 1/3; f_sparse_last: b0 = b1 = 0, scale = 1. */
+int mrg_gate_fwd(const float *s, const float *s_in, const float *norm, const float *uvc,
+                 float *out, int64_t b0, int64_t b1, int64_t M, int D, float scale, void *stream);
+int64_t mrg_gate_bwd_workspace_bytes(int64_t M, int D);
+/* gs, gs_in [M, D] (gs_in NULL allowed iff s_in NULL); d_uvc [3][MRG_GATE_LD(D)] receives
+ * d(loss)/d(u, v, c) per segment (deterministic two-stage reduction, no atomics). */
+int mrg_gate_bwd(const float *gout, const float *s, const float *s_in, const float *norm,
+                 const float *uvc, float *gs, float *gs_in, float *d_uvc, void *ws,
+                 int64_t b0, int64_t b1, int64_t M, int D, float scale, void *stream);
+/* chain rule back to the nn.Linear parameters:  d_uvc [in_dim+1] ->
+ * gW [D, in_dim] = a (x) d_uv,  gb [D] = a * d_c (NULL ok),  ga [D] = W d_uv + b d_c. */
+int mrg_gate_param_grad(const float *W, const float *b, const float *a, const float *d_uvc,
+                        float *gW, float *gb, float *ga, int D, int in_dim, void *stream);
+
+/* ---- a4 / a5 / a6: destination-segmented reducers --------------------------
+ * block.update_all(fn.copy_edge('msg_e','m'), fn.max|sum|mean('m','h')) + residual
+ * reference models/operations_lp.py:232-234, 247-249, 261-263  (DGL 0.5.3 gspmm).
+ *
+ * The in-edges of node v are eid[rowptr[v] .. rowptr[v+1]) (edge ids in the
+ * caller's order, ascending).  Long lists are cut into chunks:
+ *   chunk c covers CSR positions [chunk_start[c], chunk_end[c]) of node chunk_node[c];
+ *   every node has >= 1 chunk (an empty one if it has no in-edge);
+ *   chunk_slot[c] = -1 if the chunk is its node's whole list (result written
+ *   straight to out), else the index of its partial result in the workspace;
+ *   nodes with > 1 chunk are listed in hub_node[], their partial slots are
+ *   hub_first[j] .. hub_first[j] + hub_count[j] - 1 (consecutive, list order).
+ * out[v,:] = reduce_{e in N(v)} msg[e,:]  (+ self_rows[v,:] if not NULL); rows
+ * without in-edges reduce to 0.  arg [N, D] (max only) = the lowest edge id
+ * attaining the max, -1 where there is no in-edge. */
+int64_t mrg_seg_reduce_workspace_bytes(int64_t n_slots, int D);
+int mrg_seg_reduce_fwd(int mode, const float *msg, const float *self_rows,
+                       const int32_t *eid,
+                       const int32_t *chunk_node, const int32_t *chunk_start, const int32_t *chunk_end,
+                       const int32_t *chunk_slot, int64_t n_chunks,
+                       const int32_t *hub_node, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,
+                       int64_t n_slots, const int32_t *in_degree,
+                       float *out, int32_t *arg, void *ws,
+                       int64_t N, int D, void *stream);
+/* gmsg [E, D]: sum  gmsg[e] = gout[dst[e]];  mean  gout[dst[e]] / max(deg,1);
+ * max  gmsg[e,c] = (arg[dst[e],c] == e) ? gout[dst[e],c] : 0.
+ * gself [N, D] = gout (skipped when NULL). */
+int mrg_seg_reduce_bwd(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree,
+                       const int32_t *arg, float *gmsg, float *gself,
+                       int64_t E, int64_t N, int D, void *stream);
+
+/* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
+ * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)
+ * and the post-aggregation linears of CompGraphConv (reference models/compgcn.py:77-78,100,103).
+ * Y[rows, Nout] = act(X[rows, K] W[Nout, K]^T + bias) */
+int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y,
+                   int64_t rows, int K, int Nout, int act, void *stream);
+/* gX[rows, K] = gY[rows, Nout] W[Nout, K]   (gY already masked by the activation) */
+int mrg_linear_bwd_input(const float *gY, const float *W, float *gX,
+                         int64_t rows, int K, int Nout, void *stream);
+/* gW[Nout, K] = gY^T X,  gbias[Nout] = column sums of gY (NULL ok). */
+int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout);
+int mrg_linear_bwd_weight(const float *gY, const float *X, float *gW, float *gbias, void *ws,
+                          int64_t rows, int K, int Nout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRGNAS_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libmrgnas_hip.so (C ABI: include/mrgnas.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C mr-gnas_amd/csrc``.  Nothing here falls back to another
+implementation: a missing library raises ``MrgnasLibraryError``.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmrgnas_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
+
+ABI_VERSION = 1
+
+
+class MrgnasLibraryError(RuntimeError):
+    pass
+
+
+class MrgnasError(RuntimeError):
+    """A C-ABI call returned a non-zero code."""
+
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); must list every function declared in include/mrgnas.h
+SIGNATURES = {
+    "mrg_abi_version": (_I, []),
+    "mrg_error_string": (ctypes.c_char_p, [_I]),
+    "mrg_target_arch": (ctypes.c_char_p, []),
+    "mrg_compose_fwd": (_I, [_I, _P, _P, _P, _L, _I, _P]),
+    "mrg_compose_bwd": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_gather_compose_fwd": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_gate_collapse": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mrg_gate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),
+    "mrg_gate_bwd_workspace_bytes": (_L, [_L, _I]),
+    "mrg_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),
+    "mrg_gate_param_grad": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "mrg_seg_reduce_workspace_bytes": (_L, [_L, _I]),
+    "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "mrg_linear_bwd_input": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "mrg_linear_bwd_weight_workspace_bytes": (_L, [_L, _I, _I]),
+    "mrg_linear_bwd_weight": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Function names declared in include/mrgnas.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mrg_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrgnasLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mr-gnas_amd/csrc`). mr_gnas_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, do not hide it
+        fn.restype, fn.argtypes = res, args
+    if lib.mrg_abi_version() != ABI_VERSION:
+        raise MrgnasLibraryError(f"ABI version {lib.mrg_abi_version()} != expected {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().mrg_error_string(code).decode()
+        raise MrgnasError(f"{what}: {msg} (code {code})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_hip(*tensors):
+    """The kernels read raw HBM pointers: refuse anything else loudly."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise MrgnasError("mr_gnas_amd operators need tensors on a HIP device (no CPU fallback); got " + str(t.device))
+        if not t.is_contiguous():
+            raise MrgnasError("mr_gnas_amd operators need contiguous tensors")
+    load()
+
+
+def f32c(t):
+    """float32 + contiguous (what the reference feeds: `.float()` rows, cell_lp.py:32)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 kernels of libmrgnas_hip.so.
+// Wavefront = 64 lanes on CDNA4; every cross-lane idiom below is written for 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mrgnas.h"
+
+#define MRG_WAVE 64
+#define MRG_BLOCK 256            // 4 waves per workgroup, one per SIMD
+#define MRG_MAX_GRID 2048        // 256 CUs x 8 blocks: streaming kernels grid-stride past this
+
+#define MRG_LAUNCH_CHECK()                                  \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return (int)e__;                 \
+  } while (0)
+
+namespace mrg {
+
+// ---- vector-of-VEC floats ---------------------------------------------------
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+  float4 v;
+  __device__ __forceinline__ static Vec load(const float* p) { Vec r; r.v = *reinterpret_cast<const float4*>(p); return r; }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ static Vec fill(float x) { Vec r; r.v = make_float4(x, x, x, x); return r; }
+  __device__ __forceinline__ float& operator[](int i) { return (&v.x)[i]; }
+  __device__ __forceinline__ float operator[](int i) const { return (&v.x)[i]; }
+};
+template <> struct Vec<1> {
+  float v;
+  __device__ __forceinline__ static Vec load(const float* p) { Vec r; r.v = *p; return r; }
+  __device__ __forceinline__ void store(float* p) const { *p = v; }
+  __device__ __forceinline__ static Vec fill(float x) { Vec r; r.v = x; return r; }
+  __device__ __forceinline__ float& operator[](int) { return v; }
+  __device__ __forceinline__ float operator[](int) const { return v; }
+};
+
+template <int VEC> struct IVec;
+template <> struct IVec<4> {
+  int4 v;
+  __device__ __forceinline__ static IVec load(const int32_t* p) { IVec r; r.v = *reinterpret_cast<const int4*>(p); return r; }
+  __device__ __forceinline__ void store(int32_t* p) const { *reinterpret_cast<int4*>(p) = v; }
+  __device__ __forceinline__ static IVec fill(int x) { IVec r; r.v = make_int4(x, x, x, x); return r; }
+  __device__ __forceinline__ int& operator[](int i) { return (&v.x)[i]; }
+  __device__ __forceinline__ int operator[](int i) const { return (&v.x)[i]; }
+};
+template <> struct IVec<1> {
+  int v;
+  __device__ __forceinline__ static IVec load(const int32_t* p) { IVec r; r.v = *p; return r; }
+  __device__ __forceinline__ void store(int32_t* p) const { *p = v; }
+  __device__ __forceinline__ static IVec fill(int x) { IVec r; r.v = x; return r; }
+  __device__ __forceinline__ int& operator[](int) { return v; }
+  __device__ __forceinline__ int operator[](int) const { return v; }
+};
+
+// Sum over the LPR consecutive lanes that share one row (LPR = 16, 32 or 64).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, MRG_WAVE);
+  return x;
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// ---- row-tile geometry ---------------------------------------------------------
+// A row of D floats is covered by LPR lanes x KMAX steps x VEC floats.
+struct RowGeom {
+  int vec;    // 4 (D % 4 == 0 and 16-B aligned pointers) or 1
+  int lpr;    // lanes per row: 16 / 32 / 64
+  int kmax;   // 1 / 2 / 4
+  bool ok;
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline RowGeom row_geom(int D, bool all_aligned) {
+  RowGeom g{};
+  g.vec = (D % 4 == 0 && all_aligned) ? 4 : 1;
+  int dv = D / g.vec;
+  g.lpr = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
+  int k = (dv + g.lpr - 1) / g.lpr;
+  g.kmax = k <= 1 ? 1 : (k <= 2 ? 2 : 4);
+  g.ok = D > 0 && k <= 4;
+  return g;
+}
+
+// Dispatch a kernel template<VEC, LPR, KMAX> on a RowGeom.
+#define MRG_DISPATCH_GEOM(G, CALL)                                             \
+  do {                                                                         \
+    if ((G).vec == 4) {                                                        \
+      if ((G).lpr == 16)      { MRG_DISPATCH_K(4, 16, (G).kmax, CALL); }       \
+      else if ((G).lpr == 32) { MRG_DISPATCH_K(4, 32, (G).kmax, CALL); }       \
+      else                    { MRG_DISPATCH_K(4, 64, (G).kmax, CALL); }       \
+    } else {                                                                   \
+      if ((G).lpr == 16)      { MRG_DISPATCH_K(1, 16, (G).kmax, CALL); }       \
+      else if ((G).lpr == 32) { MRG_DISPATCH_K(1, 32, (G).kmax, CALL); }       \
+      else                    { MRG_DISPATCH_K(1, 64, (G).kmax, CALL); }       \
+    }                                                                          \
+  } while (0)
+// KMAX > 1 only ever occurs with LPR == 64.
+#define MRG_DISPATCH_K(V, L, K, CALL)                                          \
+  do {                                                                         \
+    if ((K) == 1) { CALL(V, L, 1); }                                           \
+    else if ((L) == 64 && (K) == 2) { CALL(V, 64, 2); }                        \
+    else if ((L) == 64) { CALL(V, 64, 4); }                                    \
+  } while (0)
+
+inline int grid_for(int64_t work_items, int items_per_block) {
+  int64_t b = (work_items + items_per_block - 1) / items_per_block;
+  if (b < 1) b = 1;
+  if (b > MRG_MAX_GRID) b = MRG_MAX_GRID;
+  return (int)b;
+}
+
+}  // namespace mrg

@@ -1,0 +1,315 @@
+// a2 / a3: collapsed scalar gates -- one streaming pass per direction segment.
+//   f_sparse_op_comp  reference models/operations_lp.py:304-343
+//   f_sparse_op_last  reference models/operations_lp.py:405-416
+// a_x(W_x[s ; s_in] + b_x) == u_x.s + v_x.s_in + c_x  with [u;v] = W_x^T a_x, c = a_x.b_x,
+// so the reference's three [rows,2D]x[2D,D] GEMMs become a 2D-long dot product per row.
+// Algorithmic bytes: fwd 12*D per row (+4 per edge row for norm); bwd 20*D per row.
+#include "common.hpp"
+
+namespace mrg {
+
+struct SegPlan {
+  int64_t lo[3], hi[3];   // row range of each segment
+  int blk[4];             // blocks [blk[s], blk[s+1]) work on segment s
+};
+
+static SegPlan make_plan(int64_t b0, int64_t b1, int64_t M, int grid) {
+  SegPlan p;
+  p.lo[0] = 0;  p.hi[0] = b0;
+  p.lo[1] = b0; p.hi[1] = b1;
+  p.lo[2] = b1; p.hi[2] = M;
+  int nseg = 0;
+  for (int s = 0; s < 3; ++s) nseg += (p.hi[s] > p.lo[s]);
+  int spare = grid - nseg;                     // every non-empty segment gets one block first
+  p.blk[0] = 0;
+  for (int s = 0; s < 3; ++s) {
+    int64_t rows = p.hi[s] - p.lo[s];
+    int nb = rows > 0 ? 1 + (int)((double)spare * (double)rows / (double)M) : 0;
+    p.blk[s + 1] = p.blk[s] + nb;
+  }
+  return p;                                    // blk[3] <= grid
+}
+
+template <int VEC, int LPR, int KMAX, bool HAS_IN>
+__global__ __launch_bounds__(MRG_BLOCK) void gate_fwd_k(const float* __restrict__ s, const float* __restrict__ sin_,
+                                                        const float* __restrict__ norm, const float* __restrict__ uvc,
+                                                        float* __restrict__ out, SegPlan p, int D, float scale) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int b = blockIdx.x;
+  if (b >= p.blk[3]) return;
+  const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
+  const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const float* u = uvc + (int64_t)seg * MRG_GATE_LD(D);
+  const float cc = u[HAS_IN ? 2 * D : D];
+  Vec<VEC> uk[KMAX], vk[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    uk[k] = c < dv ? Vec<VEC>::load(u + c * VEC) : Vec<VEC>::fill(0.f);
+    vk[k] = (HAS_IN && c < dv) ? Vec<VEC>::load(u + D + c * VEC) : Vec<VEC>::fill(0.f);
+  }
+  const bool use_norm = norm != nullptr && seg < 2;
+  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
+    Vec<VEC> sk[KMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        sk[k] = Vec<VEC>::load(s + r * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dot += sk[k][j] * uk[k][j];
+        if (HAS_IN) {
+          Vec<VEC> x = Vec<VEC>::load(sin_ + r * D + c * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dot += x[j] * vk[k][j];
+        }
+      }
+    }
+    float z = group_sum<LPR>(dot) + cc;
+    float f = sigmoidf_fast(z) * scale * (use_norm ? norm[r] : 1.0f);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = sk[k][j] * f;
+        o.store(out + r * D + c * VEC);
+      }
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX, bool HAS_IN>
+__global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict__ g, const float* __restrict__ s,
+                                                        const float* __restrict__ sin_, const float* __restrict__ norm,
+                                                        const float* __restrict__ uvc, float* __restrict__ gs,
+                                                        float* __restrict__ gsin, float* __restrict__ ws, SegPlan p,
+                                                        int D, float scale) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;                 // >= D
+  __shared__ float red[RPB * (2 * WIDTH + 1)];
+  const int b = blockIdx.x;
+  if (b >= p.blk[3]) return;
+  const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
+  const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int ld = MRG_GATE_LD(D);
+  const int cidx = HAS_IN ? 2 * D : D;
+  const float* u = uvc + (int64_t)seg * ld;
+  const float cc = u[HAS_IN ? 2 * D : D];
+  Vec<VEC> uk[KMAX], vk[KMAX], du[KMAX], dvv[KMAX];
+  float dc = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    uk[k] = c < dv ? Vec<VEC>::load(u + c * VEC) : Vec<VEC>::fill(0.f);
+    vk[k] = (HAS_IN && c < dv) ? Vec<VEC>::load(u + D + c * VEC) : Vec<VEC>::fill(0.f);
+    du[k] = Vec<VEC>::fill(0.f);
+    dvv[k] = Vec<VEC>::fill(0.f);
+  }
+  const bool use_norm = norm != nullptr && seg < 2;
+  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
+    Vec<VEC> sk[KMAX], xk[KMAX], gk[KMAX];
+    float dz_ = 0.f, dq = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        sk[k] = Vec<VEC>::load(s + r * D + c * VEC);
+        gk[k] = Vec<VEC>::load(g + r * D + c * VEC);
+        if (HAS_IN) xk[k] = Vec<VEC>::load(sin_ + r * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          dz_ += sk[k][j] * uk[k][j];
+          if (HAS_IN) dz_ += xk[k][j] * vk[k][j];
+          dq += gk[k][j] * sk[k][j];
+        }
+      }
+    }
+    float z = group_sum<LPR>(dz_) + cc;
+    float q = group_sum<LPR>(dq);
+    float gt = sigmoidf_fast(z);
+    float t = scale * (use_norm ? norm[r] : 1.0f);
+    float dz = q * t * gt * (1.0f - gt);
+    float f = gt * t;
+    dc += dz;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          o[j] = gk[k][j] * f + dz * uk[k][j];
+          du[k][j] += dz * sk[k][j];
+        }
+        o.store(gs + r * D + c * VEC);
+        if (HAS_IN) {
+          Vec<VEC> o2;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            o2[j] = dz * vk[k][j];
+            dvv[k][j] += dz * xk[k][j];
+          }
+          o2.store(gsin + r * D + c * VEC);
+        }
+      }
+    }
+  }
+  // block reduction of (du, dv, dc) over the RPB row groups, fixed order
+  float* mine = red + rw * (2 * WIDTH + 1);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mine[c * VEC + j] = du[k][j];
+      mine[WIDTH + c * VEC + j] = dvv[k][j];
+    }
+  }
+  if (sl == 0) mine[2 * WIDTH] = dc;
+  __syncthreads();
+  float* dst = ws + (int64_t)b * ld;
+  for (int t = threadIdx.x; t < ld; t += MRG_BLOCK) {
+    int srcidx = t < D ? t : ((HAS_IN && t < 2 * D) ? WIDTH + (t - D) : (t == cidx ? 2 * WIDTH : -1));
+    float acc = 0.f;
+    if (srcidx >= 0) {
+#pragma unroll
+      for (int q = 0; q < RPB; ++q) acc += red[q * (2 * WIDTH + 1) + srcidx];
+    }
+    dst[t] = acc;
+  }
+}
+
+// d_uvc[s][t] = sum over the blocks of segment s, in block order
+__global__ void gate_reduce_k(const float* __restrict__ ws, float* __restrict__ d_uvc, SegPlan p, int ld) {
+  int seg = blockIdx.y;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ld) return;
+  float acc = 0.f;
+  for (int b = p.blk[seg]; b < p.blk[seg + 1]; ++b) acc += ws[(int64_t)b * ld + t];
+  d_uvc[seg * ld + t] = acc;
+}
+
+// uvc[k] = sum_j W[j,k] a[j]  (k < in_dim);  uvc[in_dim] = sum_j a[j] b[j]
+__global__ void gate_collapse_k(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ a,
+                                float* __restrict__ uvc, int D, int in_dim) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > in_dim) return;
+  float acc = 0.f;
+  if (k < in_dim) {
+    for (int j = 0; j < D; ++j) acc += W[(int64_t)j * in_dim + k] * a[j];
+  } else if (b) {
+    for (int j = 0; j < D; ++j) acc += a[j] * b[j];
+  }
+  uvc[k] = acc;
+}
+
+// one block per output row j of W
+__global__ void gate_param_grad_k(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ a,
+                                  const float* __restrict__ d, float* __restrict__ gW, float* __restrict__ gb,
+                                  float* __restrict__ ga, int D, int in_dim) {
+  __shared__ float part[MRG_BLOCK / MRG_WAVE];
+  const int j = blockIdx.x;
+  const float aj = a[j];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < in_dim; k += blockDim.x) {
+    float dk = d[k];
+    gW[(int64_t)j * in_dim + k] = aj * dk;
+    acc += W[(int64_t)j * in_dim + k] * dk;
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < MRG_BLOCK / MRG_WAVE; ++w) tot += part[w];
+    float dc = d[in_dim];
+    ga[j] = tot + (b ? b[j] * dc : 0.f);
+    if (gb) gb[j] = aj * dc;
+  }
+}
+
+}  // namespace mrg
+
+using namespace mrg;
+
+extern "C" int mrg_gate_collapse(const float* W, const float* b, const float* a, float* uvc, int D, int in_dim, void* stream) {
+  if (!W || !a || !uvc) return MRG_E_NULLPTR;
+  if (D <= 0 || in_dim <= 0) return MRG_E_SHAPE;
+  hipLaunchKernelGGL(gate_collapse_k, dim3((in_dim + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, b, a, uvc, D, in_dim);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_gate_param_grad(const float* W, const float* b, const float* a, const float* d_uvc, float* gW, float* gb,
+                                   float* ga, int D, int in_dim, void* stream) {
+  if (!W || !a || !d_uvc || !gW || !ga) return MRG_E_NULLPTR;
+  if (D <= 0 || in_dim <= 0) return MRG_E_SHAPE;
+  hipLaunchKernelGGL(gate_param_grad_k, dim3(D), dim3(MRG_BLOCK), 0, (hipStream_t)stream, W, b, a, d_uvc, gW, gb, ga, D, in_dim);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_gate_fwd(const float* s, const float* s_in, const float* norm, const float* uvc, float* out, int64_t b0,
+                            int64_t b1, int64_t M, int D, float scale, void* stream) {
+  if (!s || !uvc || !out) return MRG_E_NULLPTR;
+  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (M == 0) return MRG_OK;
+  RowGeom g = row_geom(D, aligned16(s) && aligned16(s_in) && aligned16(out) && aligned16(uvc));
+  if (!g.ok) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 1;
+#define CALL(V, L, K)                                                                                                   \
+  do {                                                                                                                  \
+    grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                            \
+    if (grid < 3) grid = 3;                                                                                             \
+    SegPlan p = make_plan(b0, b1, M, grid);                                                                             \
+    if (s_in) hipLaunchKernelGGL((gate_fwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+    else hipLaunchKernelGGL((gate_fwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int64_t mrg_gate_bwd_workspace_bytes(int64_t M, int D) {
+  (void)M;
+  return (int64_t)(MRG_MAX_GRID + 3) * MRG_GATE_LD((int64_t)D) * sizeof(float);
+}
+
+extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in, const float* norm, const float* uvc,
+                            float* gs, float* gs_in, float* d_uvc, void* ws, int64_t b0, int64_t b1, int64_t M, int D,
+                            float scale, void* stream) {
+  if (!gout || !s || !uvc || !gs || !d_uvc) return MRG_E_NULLPTR;
+  if (s_in && !gs_in) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = MRG_GATE_LD(D);
+  RowGeom g = row_geom(D, aligned16(gout) && aligned16(s) && aligned16(s_in) && aligned16(gs) && aligned16(gs_in) && aligned16(uvc));
+  if (!g.ok) return MRG_E_SHAPE;
+  SegPlan p{};
+#define CALL(V, L, K)                                                                                                   \
+  do {                                                                                                                  \
+    int grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                        \
+    if (grid < 3) grid = 3;                                                                                             \
+    p = make_plan(b0, b1, M, grid);                                                                                     \
+    if (M > 0) {                                                                                                        \
+      if (s_in) hipLaunchKernelGGL((gate_bwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+      else hipLaunchKernelGGL((gate_bwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+    }                                                                                                                   \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gate_reduce_k, dim3((ld + 255) / 256, 3), dim3(256), 0, st, (const float*)ws, d_uvc, p, ld);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

@@ -1,0 +1,271 @@
+// a4 / a5 / a6: destination-segmented max / sum / mean over in-edges (HBM-bound gather of
+// whole rows through a CSR-by-destination), replacing DGL's gspmm(copy_e, max|sum|mean):
+//   reference models/operations_lp.py:232-234 (a_max), :247-249 (a_mean), :261-263 (a_sum).
+// One LPR-lane group walks one chunk of one destination's in-edge list; rows are read as
+// float4 per lane (a whole 800-byte row per wave at D = 200).  No float atomics: partial
+// results of split (hub) lists go to a workspace and are combined in list order, so the
+// result is bitwise reproducible.
+// Algorithmic bytes: fwd 4*D*(E + N) read + 4*D*N write (+ 4*E indices); bwd 4*D*N + 4*D*M.
+#include "common.hpp"
+#include <math.h>
+
+namespace mrg {
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+struct Acc {
+  Vec<VEC> val[KMAX];
+  IVec<VEC> arg[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      val[k] = Vec<VEC>::fill(IS_MAX ? -INFINITY : 0.f);
+      arg[k] = IVec<VEC>::fill(-1);
+    }
+  }
+  // strict '>' keeps the first (lowest edge id) of equal maxima
+  __device__ __forceinline__ void take(int k, const Vec<VEC>& x, int e) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (IS_MAX) {
+        if (x[j] > val[k][j]) { val[k][j] = x[j]; arg[k][j] = e; }
+      } else {
+        val[k][j] += x[j];
+      }
+    }
+  }
+  __device__ __forceinline__ void take_partial(int k, const Vec<VEC>& x, const IVec<VEC>& a) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (IS_MAX) {
+        if (x[j] > val[k][j]) { val[k][j] = x[j]; arg[k][j] = a[j]; }
+      } else {
+        val[k][j] += x[j];
+      }
+    }
+  }
+};
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+__device__ __forceinline__ void finalize_row(Acc<VEC, LPR, KMAX, IS_MAX>& acc, int v, int deg, bool is_mean,
+                                             const float* __restrict__ self_rows, float* __restrict__ out,
+                                             int32_t* __restrict__ arg, int D, int sl) {
+  const int dv = D / VEC;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    if (c < dv) {
+      Vec<VEC> o = acc.val[k];
+      if (IS_MAX) {
+        if (deg == 0) o = Vec<VEC>::fill(0.f);
+      } else if (is_mean) {
+        float d = (float)(deg > 1 ? deg : 1);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = o[j] / d;
+      }
+      if (self_rows) {
+        Vec<VEC> s = Vec<VEC>::load(self_rows + (int64_t)v * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += s[j];
+      }
+      o.store(out + (int64_t)v * D + c * VEC);
+      if (IS_MAX && arg) acc.arg[k].store(arg + (int64_t)v * D + c * VEC);
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+__global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict__ msg, const float* __restrict__ self_rows,
+                                                         const int32_t* __restrict__ eid, const int32_t* __restrict__ chunk_node,
+                                                         const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ chunk_end,
+                                                         const int32_t* __restrict__ chunk_slot, int64_t n_chunks,
+                                                         const int32_t* __restrict__ in_degree, float* __restrict__ out,
+                                                         int32_t* __restrict__ arg, float* __restrict__ ws_val,
+                                                         int32_t* __restrict__ ws_arg, int D, int is_mean) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int U = 4;                                      // rows in flight per lane group
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
+    const int v = chunk_node[ch];
+    const int j0 = chunk_start[ch], j1 = chunk_end[ch];
+    const int slot = chunk_slot[ch];
+    Acc<VEC, LPR, KMAX, IS_MAX> acc;
+    acc.init();
+    for (int j = j0; j < j1; j += U) {
+      int e[U];
+      Vec<VEC> x[U][KMAX];
+#pragma unroll
+      for (int q = 0; q < U; ++q) e[q] = (j + q < j1) ? eid[j + q] : -1;
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (e[q] >= 0 && c < dv) x[q][k] = Vec<VEC>::load(msg + (int64_t)e[q] * D + c * VEC);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (e[q] >= 0) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            if (sl + k * LPR < dv) acc.take(k, x[q][k], e[q]);
+          }
+        }
+      }
+    }
+    if (slot < 0) {
+      finalize_row<VEC, LPR, KMAX, IS_MAX>(acc, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
+    } else {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          acc.val[k].store(ws_val + (int64_t)slot * D + c * VEC);
+          if (IS_MAX) acc.arg[k].store(ws_arg + (int64_t)slot * D + c * VEC);
+        }
+      }
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+__global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__ self_rows, const int32_t* __restrict__ hub_node,
+                                                       const int32_t* __restrict__ hub_first, const int32_t* __restrict__ hub_count,
+                                                       int64_t n_hubs, const int32_t* __restrict__ in_degree,
+                                                       float* __restrict__ out, int32_t* __restrict__ arg,
+                                                       const float* __restrict__ ws_val, const int32_t* __restrict__ ws_arg,
+                                                       int D, int is_mean) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t h = (int64_t)blockIdx.x * RPB + rw; h < n_hubs; h += (int64_t)gridDim.x * RPB) {
+    const int v = hub_node[h], s0 = hub_first[h], cnt = hub_count[h];
+    Acc<VEC, LPR, KMAX, IS_MAX> acc;
+    acc.init();
+    for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          Vec<VEC> x = Vec<VEC>::load(ws_val + (int64_t)(s0 + q) * D + c * VEC);
+          IVec<VEC> a = IVec<VEC>::fill(-1);
+          if (IS_MAX) a = IVec<VEC>::load(ws_arg + (int64_t)(s0 + q) * D + c * VEC);
+          acc.take_partial(k, x, a);
+        }
+      }
+    }
+    finalize_row<VEC, LPR, KMAX, IS_MAX>(acc, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
+  }
+}
+
+// rows [0, E): gradient of the edge messages; rows [E, E + N): copy for the self-loop residual
+template <int VEC, int LPR, int KMAX, int MODE>
+__global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__ gout, const int32_t* __restrict__ dst,
+                                                       const int32_t* __restrict__ in_degree, const int32_t* __restrict__ arg,
+                                                       float* __restrict__ gmsg, float* __restrict__ gself, int64_t E,
+                                                       int64_t rows, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const bool edge = r < E;
+    const int64_t v = edge ? dst[r] : r - E;
+    float inv = 1.0f;
+    if (MODE == MRG_REDUCE_MEAN && edge) { int d = in_degree[v]; inv = (float)(d > 1 ? d : 1); }
+    float* o = edge ? gmsg + r * D : gself + (r - E) * D;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        Vec<VEC> g = Vec<VEC>::load(gout + v * D + c * VEC);
+        if (edge) {
+          if (MODE == MRG_REDUCE_MEAN) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] = g[j] / inv;
+          } else if (MODE == MRG_REDUCE_MAX) {
+            IVec<VEC> a = IVec<VEC>::load(arg + v * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] = (a[j] == (int)r) ? g[j] : 0.f;
+          }
+        }
+        g.store(o + c * VEC);
+      }
+    }
+  }
+}
+
+}  // namespace mrg
+
+using namespace mrg;
+
+extern "C" int64_t mrg_seg_reduce_workspace_bytes(int64_t n_slots, int D) {
+  if (n_slots < 0 || D <= 0) return 0;
+  return (n_slots + 1) * (int64_t)D * 8 + 64;   // float values + int32 arg per partial slot
+}
+
+extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_rows, const int32_t* eid,
+                                  const int32_t* chunk_node, const int32_t* chunk_start, const int32_t* chunk_end,
+                                  const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
+                                  const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
+                                  const int32_t* in_degree, float* out, int32_t* arg, void* ws, int64_t N, int D,
+                                  void* stream) {
+  if (mode < 0 || mode > 2) return MRG_E_ENUM;
+  if (N < 0 || D <= 0 || n_chunks < N || n_hubs < 0 || n_slots < 0) return MRG_E_SHAPE;
+  if (N == 0) return MRG_OK;
+  if (!out || !chunk_node || !chunk_start || !chunk_end || !chunk_slot || !in_degree) return MRG_E_NULLPTR;
+  if (mode == MRG_REDUCE_MAX && !arg) return MRG_E_NULLPTR;
+  if (n_hubs > 0 && (!hub_node || !hub_first || !hub_count)) return MRG_E_NULLPTR;
+  if (n_slots > 0 && !ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws_val = (float*)ws;
+  int32_t* ws_arg = ws ? (int32_t*)((float*)ws + (n_slots + 1) * (int64_t)D) : nullptr;
+  // the arg half starts at a multiple of D floats: 16-B aligned iff D % 4 == 0 (as the vector path requires)
+  RowGeom g = row_geom(D, aligned16(msg) && aligned16(self_rows) && aligned16(out) && aligned16(arg) && aligned16(ws));
+  if (!g.ok) return MRG_E_SHAPE;
+  const int is_mean = mode == MRG_REDUCE_MEAN;
+#define CALL(V, L, K)                                                                                                  \
+  do {                                                                                                                 \
+    int grid = grid_for(n_chunks, MRG_BLOCK / L);                                                                      \
+    if (mode == MRG_REDUCE_MAX)                                                                                        \
+      hipLaunchKernelGGL((seg_chunk_k<V, L, K, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((seg_chunk_k<V, L, K, false>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
+    if (n_hubs > 0) {                                                                                                  \
+      int gh = grid_for(n_hubs, MRG_BLOCK / L);                                                                        \
+      if (mode == MRG_REDUCE_MAX)                                                                                      \
+        hipLaunchKernelGGL((seg_hub_k<V, L, K, true>), dim3(gh), dim3(MRG_BLOCK), 0, st, self_rows, hub_node, hub_first, hub_count, n_hubs, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
+      else                                                                                                             \
+        hipLaunchKernelGGL((seg_hub_k<V, L, K, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, self_rows, hub_node, hub_first, hub_count, n_hubs, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
+    }                                                                                                                  \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_seg_reduce_bwd(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree,
+                                  const int32_t* arg, float* gmsg, float* gself, int64_t E, int64_t N, int D, void* stream) {
+  if (mode < 0 || mode > 2) return MRG_E_ENUM;
+  if (E < 0 || N < 0 || D <= 0) return MRG_E_SHAPE;
+  if (!gout || (E > 0 && (!dst || !gmsg))) return MRG_E_NULLPTR;
+  if (mode == MRG_REDUCE_MEAN && !in_degree) return MRG_E_NULLPTR;
+  if (mode == MRG_REDUCE_MAX && !arg) return MRG_E_NULLPTR;
+  const int64_t rows = E + (gself ? N : 0);
+  if (rows == 0) return MRG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  RowGeom g = row_geom(D, aligned16(gout) && aligned16(gmsg) && aligned16(gself) && aligned16(arg));
+  if (!g.ok) return MRG_E_SHAPE;
+#define CALL(V, L, K)                                                                                                  \
+  do {                                                                                                                 \
+    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                    \
+    if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
+    else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
+    else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

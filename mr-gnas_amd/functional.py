@@ -1,0 +1,271 @@
+"""autograd Functions over the C ABI (include/mrgnas.h).
+
+Each Function enqueues HIP kernels of libmrgnas_hip.so on torch's current
+stream through ctypes; tensors are only used for memory and stream plumbing.
+Inputs are never modified; outputs are fresh tensors.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, f32c, ptr, require_hip, stream_of
+
+COMPOSE = {"mult": 0, "sub": 1, "add": 2}
+REDUCE = {"sum": 0, "mean": 1, "max": 2}
+ACT = {None: 0, "none": 0, "relu": 1}
+
+
+def gate_ld(D):
+    return 2 * D + 4          # MRG_GATE_LD
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+# ---------------------------------------------------------------------------
+# a1: compose
+# ---------------------------------------------------------------------------
+class _Compose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, s, hr):
+        s, hr = f32c(s), f32c(hr)
+        if hr.shape != s.shape:
+            hr = hr.expand_as(s).contiguous()
+        require_hip(s, hr)
+        out = torch.empty_like(s)
+        rows, D = s.shape
+        check(_lib.load().mrg_compose_fwd(op, ptr(s), ptr(hr), ptr(out), rows, D, stream_of(s)), "mrg_compose_fwd")
+        ctx.op = op
+        ctx.save_for_backward(*((s, hr) if op == 0 else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = f32c(g)
+        s, hr = ctx.saved_tensors if ctx.op == 0 else (None, None)
+        need_s, need_hr = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gs = torch.empty_like(g) if need_s else None
+        ghr = torch.empty_like(g) if need_hr else None
+        rows, D = g.shape
+        check(_lib.load().mrg_compose_bwd(ctx.op, ptr(g), ptr(s), ptr(hr), ptr(gs), ptr(ghr), rows, D, stream_of(g)),
+              "mrg_compose_bwd")
+        return None, gs, ghr
+
+
+def compose(kind, s, hr):
+    """s (*|-|+) hr on [rows, D] (reference models/operations_lp.py:71-98)."""
+    return _Compose.apply(COMPOSE[kind], s, hr)
+
+
+def gather_rows(table, idx32, rel_table=None, rel_idx32=None, kind=None):
+    """out[i] = table[idx[i]] (kind None) or table[idx[i]] (op) rel_table[rel_idx[i]].
+    Forward-only helper (bit-exact gather, reference models/model_lp.py:131)."""
+    table = f32c(table)
+    require_hip(table, idx32, rel_table, rel_idx32)
+    rows, D = idx32.numel(), table.shape[1]
+    out = torch.empty(rows, D, dtype=torch.float32, device=table.device)
+    op = -1 if kind is None else COMPOSE[kind]
+    check(_lib.load().mrg_gather_compose_fwd(op, ptr(table), ptr(rel_table), ptr(idx32), ptr(rel_idx32), ptr(out),
+                                             rows, D, stream_of(table)), "mrg_gather_compose_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# a2 / a3: collapsed scalar gates
+# ---------------------------------------------------------------------------
+class _Gate(torch.autograd.Function):
+    """segments: list of (W, b, a) per row segment (None for absent segments);
+    flat parameter list follows: W0, b0, a0, W1, b1, a1, W2, b2, a2 (None allowed)."""
+
+    @staticmethod
+    def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
+        lib = _lib.load()
+        s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
+        params = tuple(f32c(p) for p in params)
+        require_hip(s, s_in, norm, *params)
+        M, D = s.shape
+        st = stream_of(s)
+        ld = gate_ld(D)
+        in_dim = 2 * D if s_in is not None else D
+        uvc = torch.zeros(3, ld, dtype=torch.float32, device=s.device)
+        for seg in range(3):
+            W, b, a = params[3 * seg: 3 * seg + 3]
+            if W is not None:
+                check(lib.mrg_gate_collapse(ptr(W), ptr(b), ptr(a), ptr(uvc[seg]), D, in_dim, st), "mrg_gate_collapse")
+        out = torch.empty_like(s)
+        check(lib.mrg_gate_fwd(ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(out), b0, b1, M, D, scale, st), "mrg_gate_fwd")
+        ctx.save_for_backward(s, s_in, norm, uvc, *params)
+        ctx.cfg = (b0, b1, scale, in_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        s, s_in, norm, uvc, *params = ctx.saved_tensors
+        b0, b1, scale, in_dim = ctx.cfg
+        g = f32c(g)
+        M, D = s.shape
+        st = stream_of(s)
+        gs = torch.empty_like(s)
+        gs_in = torch.empty_like(s) if s_in is not None else None
+        d_uvc = torch.empty(3, gate_ld(D), dtype=torch.float32, device=s.device)
+        ws = _ws(lib.mrg_gate_bwd_workspace_bytes(M, D), s)
+        check(lib.mrg_gate_bwd(ptr(g), ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(gs), ptr(gs_in), ptr(d_uvc), ptr(ws),
+                               b0, b1, M, D, scale, st), "mrg_gate_bwd")
+        gparams = []
+        for seg in range(3):
+            W, b, a = params[3 * seg: 3 * seg + 3]
+            if W is None:
+                gparams += [None, None, None]
+                continue
+            gW, ga = torch.empty_like(W), torch.empty_like(a)
+            gb = torch.empty_like(b) if b is not None else None
+            check(lib.mrg_gate_param_grad(ptr(W), ptr(b), ptr(a), ptr(d_uvc[seg]), ptr(gW), ptr(gb), ptr(ga), D, in_dim, st),
+                  "mrg_gate_param_grad")
+            gparams += [gW, gb, ga]
+        return (gs, gs_in, None, None, None, None, *gparams)
+
+
+def gate_comp(s, s_in, norm, b0, b1, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self):
+    """f_sparse_comp (reference models/operations_lp.py:317-343)."""
+    return _Gate.apply(s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self)
+
+
+def gate_last(s, W, b, a):
+    """f_sparse_last (reference models/operations_lp.py:412-416): all rows in segment 2."""
+    return _Gate.apply(s, None, None, 0, 0, 1.0, None, None, None, None, None, None, W, b, a)
+
+
+# ---------------------------------------------------------------------------
+# a4 / a5 / a6: destination-segmented reducers
+# ---------------------------------------------------------------------------
+class _SegReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mode, msg, self_rows, graph):
+        lib = _lib.load()
+        msg, self_rows = f32c(msg), f32c(self_rows)
+        require_hip(msg, self_rows)
+        p = graph.plan()
+        N, D = graph.number_of_nodes(), msg.shape[1]
+        if msg.shape[0] != graph.num_edges():
+            raise _lib.MrgnasError(f"message rows {msg.shape[0]} != number of edges {graph.num_edges()}")
+        out = torch.empty(N, D, dtype=torch.float32, device=msg.device)
+        arg = torch.empty(N, D, dtype=torch.int32, device=msg.device) if mode == 2 else None
+        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), msg) if p["n_slots"] > 0 else None
+        check(lib.mrg_seg_reduce_fwd(mode, ptr(msg), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]),
+                                     ptr(p["chunk_start"]), ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"],
+                                     ptr(p["hub_node"]), ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"],
+                                     p["n_slots"], ptr(p["in_degree"]), ptr(out), ptr(arg), ptr(ws), N, D,
+                                     stream_of(msg)), "mrg_seg_reduce_fwd")
+        ctx.mode, ctx.graph, ctx.has_self = mode, graph, self_rows is not None
+        ctx.save_for_backward(*((arg,) if arg is not None else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = f32c(g)
+        graph, p = ctx.graph, ctx.graph.plan()
+        arg = ctx.saved_tensors[0] if ctx.mode == 2 else None
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
+        gmsg = torch.empty(E, D, dtype=torch.float32, device=g.device)
+        check(lib.mrg_seg_reduce_bwd(ctx.mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), None,
+                                     E, N, D, stream_of(g)), "mrg_seg_reduce_bwd")
+        return None, gmsg, (g if ctx.has_self else None), None
+
+
+def seg_reduce(kind, msg, self_rows, graph):
+    """out[v] = reduce over in-edges of msg (+ self_rows[v]); DGL update_all(copy_e, max|sum|mean)."""
+    return _SegReduce.apply(REDUCE[kind], msg, self_rows, graph)
+
+
+class _AggRows(torch.autograd.Function):
+    """Aggregator on the reference's [M, D] layout: rows [0, E) are messages,
+    rows [E, M) the residual self rows; the gradient comes back as one [M, D]."""
+
+    @staticmethod
+    def forward(ctx, mode, x, graph, add_self):
+        lib = _lib.load()
+        x = f32c(x)
+        require_hip(x)
+        p = graph.plan()
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
+        if x.shape[0] != E + N:
+            raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
+        out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+        arg = torch.empty(N, D, dtype=torch.int32, device=x.device) if mode == 2 else None
+        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), x) if p["n_slots"] > 0 else None
+        self_rows = x[E:] if add_self else None
+        check(lib.mrg_seg_reduce_fwd(mode, ptr(x), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]),
+                                     ptr(p["chunk_start"]), ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"],
+                                     ptr(p["hub_node"]), ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"],
+                                     p["n_slots"], ptr(p["in_degree"]), ptr(out), ptr(arg), ptr(ws), N, D,
+                                     stream_of(x)), "mrg_seg_reduce_fwd")
+        ctx.mode, ctx.graph, ctx.add_self = mode, graph, add_self
+        ctx.save_for_backward(*((arg,) if arg is not None else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = f32c(g)
+        graph, p = ctx.graph, ctx.graph.plan()
+        arg = ctx.saved_tensors[0] if ctx.mode == 2 else None
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
+        gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
+        if not ctx.add_self:
+            gx[E:].zero_()
+        check(lib.mrg_seg_reduce_bwd(ctx.mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gx),
+                                     ptr(gx[E:]) if ctx.add_self else None, E, N, D, stream_of(g)), "mrg_seg_reduce_bwd")
+        return None, gx, None, None
+
+
+def aggregate_rows(kind, x, graph, add_self=True):
+    return _AggRows.apply(REDUCE[kind], x, graph, add_self)
+
+
+# ---------------------------------------------------------------------------
+# dense linear on rows (fp32 MFMA)
+# ---------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        lib = _lib.load()
+        x, W, b = f32c(x), f32c(W), f32c(b)
+        require_hip(x, W, b)
+        rows, K = x.shape
+        Nout = W.shape[0]
+        if W.shape[1] != K:
+            raise _lib.MrgnasError(f"linear: weight {tuple(W.shape)} does not match input width {K}")
+        y = torch.empty(rows, Nout, dtype=torch.float32, device=x.device)
+        check(lib.mrg_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), rows, K, Nout, act, stream_of(x)), "mrg_linear_fwd")
+        ctx.act, ctx.has_b = act, b is not None
+        ctx.save_for_backward(x, W, y if act == 1 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, W, y = ctx.saved_tensors
+        g = f32c(g)
+        if ctx.act == 1:
+            g = g * (y > 0)           # ReLU mask (elementwise; folded into the fused kernel later)
+        rows, K = x.shape
+        Nout = W.shape[0]
+        st = stream_of(x)
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.mrg_linear_bwd_input(ptr(g), ptr(W), ptr(gx), rows, K, Nout, st), "mrg_linear_bwd_input")
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            gW = torch.empty_like(W)
+            gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None
+            ws = _ws(lib.mrg_linear_bwd_weight_workspace_bytes(rows, K, Nout), x)
+            check(lib.mrg_linear_bwd_weight(ptr(g), ptr(x), ptr(gW), ptr(gb), ptr(ws), rows, K, Nout, st),
+                  "mrg_linear_bwd_weight")
+        return gx, gW, gb, None
+
+
+def linear(x, W, b=None, act=None):
+    """act(x W^T + b) with exact-f32 MFMA (nn.Linear semantics)."""
+    return _Linear.apply(x, W, b, ACT[act])

@@ -1,0 +1,188 @@
+"""RelGraph: the graph object handed to the operators in place of a DGLGraph.
+
+DGL is a third-party dependency of the reference (``dgl-cuda10.0==0.5.3``,
+reference README.md:16) and is not available on ROCm; the operators only need
+the small protocol below, which RelGraph honours:
+
+* callers:   ``g.nodes()``, ``g.edges(form='all')``, ``g.edata['e_type']``
+             (reference models/model_lp.py:126-129, models/model_search_lp.py:135-136)
+* operators: ``g.num_edges()``, ``g.edata['norm']``
+             (reference models/operations_lp.py:231,318,339)
+* CompGCN:   ``g.edata['etype'|'norm'|'in_edges_mask'|'out_edges_mask']``
+             (reference models/compgcn.py:58,74-75)
+
+On top of that it caches what the HIP kernels want: int32 index arrays in HBM
+and a CSR-by-destination whose long rows are cut into chunks (hub nodes), so
+the segmented reducers neither use float atomics nor serialise on one wave.
+
+Edge order is the caller's and is never changed: rows [0, E/2) are original
+direction edges, [E/2, E) inverse edges (both reference builders guarantee
+this: train/mr_lp_train.py:80-87, utils/utils_rgcn.py:138-152).
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+CHUNK_EDGES = 64     # in-edges reduced by one wave-group before the list is split
+
+
+def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
+    """CSR-by-destination + chunk plan for mrg_seg_reduce_fwd (include/mrgnas.h).
+
+    Pure tensor code (runs on the tensors' device; CPU works too, used by the
+    CPU tests).  Returns a dict of int32 tensors and python ints."""
+    dev = dst.device
+    dst = dst.long()
+    N = int(num_nodes)
+    deg = torch.bincount(dst, minlength=N)
+    eid = torch.argsort(dst, stable=True)                       # ascending edge ids inside each row
+    rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    nch = torch.clamp((deg + chunk - 1) // chunk, min=1)
+    first = torch.cumsum(nch, 0) - nch
+    chunk_node = torch.repeat_interleave(torch.arange(N, device=dev), nch)
+    k = torch.arange(chunk_node.numel(), device=dev) - first[chunk_node]
+    start = rowptr[chunk_node] + k * chunk
+    end = torch.minimum(start + chunk, rowptr[chunk_node + 1])
+    multi = nch[chunk_node] > 1
+    slot = torch.where(multi, torch.cumsum(multi.long(), 0) - 1, torch.full_like(k, -1))
+    hub_node = torch.nonzero(nch > 1).view(-1)
+    hub_count = nch[hub_node]
+    hub_first = torch.cumsum(hub_count, 0) - hub_count
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return {
+        "eid": i32(eid), "rowptr": i32(rowptr), "in_degree": i32(deg),
+        "chunk_node": i32(chunk_node), "chunk_start": i32(start), "chunk_end": i32(end), "chunk_slot": i32(slot),
+        "hub_node": i32(hub_node), "hub_first": i32(hub_first), "hub_count": i32(hub_count),
+        "n_chunks": int(chunk_node.numel()), "n_hubs": int(hub_node.numel()), "n_slots": int(multi.sum()),
+    }
+
+
+class RelGraph:
+    """Multi-relational edge-list graph resident in HBM (see module docstring)."""
+
+    def __init__(self, num_nodes, src, dst, etype=None, norm=None, device=None):
+        dev = torch.device(device) if device is not None else torch.as_tensor(src).device
+        as_idx = lambda x: torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(dev).long().contiguous()
+        self._n = int(num_nodes)
+        self._src = as_idx(src)
+        self._dst = as_idx(dst)
+        if self._src.shape != self._dst.shape or self._src.dim() != 1:
+            raise ValueError("src and dst must be 1-D and of equal length")
+        self.edata = {}
+        self.ndata = {}
+        if etype is not None:
+            self.edata["e_type"] = as_idx(etype)
+        if norm is not None:
+            self.edata["norm"] = torch.as_tensor(norm, dtype=torch.float32).to(dev)
+        self._plan = None
+        self._i32 = {}
+
+    # ---- DGL-style protocol ---------------------------------------------------
+    @property
+    def device(self):
+        return self._src.device
+
+    def num_edges(self):
+        return int(self._src.numel())
+
+    number_of_edges = num_edges
+
+    def number_of_nodes(self):
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def nodes(self):
+        return torch.arange(self._n, device=self.device)
+
+    def edges(self, form="uv"):
+        if form == "all":
+            return self._src, self._dst, torch.arange(self.num_edges(), device=self.device)
+        return self._src, self._dst
+
+    def in_degrees(self):
+        return torch.bincount(self._dst, minlength=self._n)
+
+    @property
+    def srcdata(self):
+        return self.ndata
+
+    @property
+    def dstdata(self):
+        return self.ndata
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        nd, ed = dict(self.ndata), dict(self.edata)
+        try:
+            yield
+        finally:
+            self.ndata.clear(); self.ndata.update(nd)
+            self.edata.clear(); self.edata.update(ed)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = RelGraph(self._n, self._src.to(device), self._dst.to(device))
+        g.edata = {k: v.to(device) for k, v in self.edata.items()}
+        g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        return g
+
+    # ---- what the kernels consume ------------------------------------------------
+    def plan(self):
+        """CSR-by-destination chunk plan (built once, cached)."""
+        if self._plan is None:
+            self._plan = dst_csr_plan(self._dst, self._n)
+        return self._plan
+
+    def i32(self, name):
+        """int32 copy of 'src' / 'dst' / an integer edata field, cached."""
+        if name not in self._i32:
+            t = {"src": self._src, "dst": self._dst}.get(name)
+            if t is None:
+                t = self.edata[name]
+            self._i32[name] = t.to(torch.int32).contiguous()
+        return self._i32[name]
+
+    def norm_flat(self):
+        """edata['norm'] as a contiguous float32 [E] (the reference stores [E] or [E,1])."""
+        n = self.edata["norm"]
+        n = n.reshape(-1)
+        if n.dtype != torch.float32 or not n.is_contiguous():
+            n = n.float().contiguous()
+        return n
+
+
+# ---- graph construction (the step before the hot path) ----------------------------
+def _deg_norm(in_deg):
+    with np.errstate(divide="ignore"):
+        norm = in_deg.astype(np.float32) ** np.float32(-0.5)
+    norm[np.isinf(norm)] = 0
+    return norm.astype(np.float32)
+
+
+def build_train_graph(num_nodes, num_rels, triples, device=None):
+    """Graph of the fixed-genotype training driver (reference train/mr_lp_train.py:77-89):
+    original edges then inverse edges, un-sorted; norm[e] = d_in(dst)^-1/2 * d_in(src)^-1/2, shape [E]."""
+    t = np.asarray(triples, dtype=np.int64)
+    src = np.concatenate([t[:, 0], t[:, 2]])
+    dst = np.concatenate([t[:, 2], t[:, 0]])
+    etype = np.concatenate([t[:, 1], t[:, 1] + num_rels])
+    nn_ = _deg_norm(np.bincount(dst, minlength=num_nodes))
+    return RelGraph(num_nodes, src, dst, etype, nn_[dst] * nn_[src], device=device or "cpu")
+
+
+def build_search_graph(num_nodes, num_rels, triples, device=None):
+    """Graph of the search driver (reference utils/utils_rgcn.py:129-158: inverse edges
+    appended, then sorted by (rel, dst, src); search/mr_lp_search.py:30-36: norm shape [E,1])."""
+    t = np.asarray(triples, dtype=np.int64)
+    src = np.concatenate([t[:, 0], t[:, 2]])
+    dst = np.concatenate([t[:, 2], t[:, 0]])
+    rel = np.concatenate([t[:, 1], t[:, 1] + num_rels])
+    order = np.lexsort((src, dst, rel))
+    src, dst, rel = src[order], dst[order], rel[order]
+    nn_ = _deg_norm(np.bincount(dst, minlength=num_nodes))
+    return RelGraph(num_nodes, src, dst, rel, (nn_[dst] * nn_[src]).reshape(-1, 1), device=device or "cpu")

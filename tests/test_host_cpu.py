@@ -1,0 +1,106 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every
+symbol include/mrgnas.h declares, host logic (graph plan, builders,
+registries) is right, and nothing silently falls back to the CPU."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import mr_gnas_amd
+from mr_gnas_amd import _lib, graph as G, operations_lp as O
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 18
+    assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/mrgnas.h but not exported"
+    lib = _lib.load()
+    assert lib.mrg_abi_version() == _lib.ABI_VERSION
+    assert lib.mrg_target_arch() == b"gfx950"
+    assert b"pointer" in lib.mrg_error_string(-1)
+    assert lib.mrg_gate_bwd_workspace_bytes(1000, 200) > 0
+
+
+def test_argument_errors_without_gpu():
+    lib = _lib.load()       # argument validation happens before any launch
+    assert lib.mrg_compose_fwd(0, None, None, None, 4, 8, None) == -1
+    assert lib.mrg_compose_fwd(7, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 8, None) == -3
+    assert lib.mrg_gate_fwd(ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), ctypes.c_void_p(16), 5, 3, 9, 8, 1.0, None) == -2
+    assert lib.mrg_seg_reduce_fwd(9, *([None] * 7), 0, None, None, None, 0, 0, None, None, None, None, 0, 8, None) == -3
+    with pytest.raises(_lib.MrgnasError):
+        _lib.check(-2, "x")
+
+
+def test_no_cpu_fallback():
+    z = load_golden("ops_tiny_train")
+    g = G.RelGraph(z["N"], z["src"], z["dst"], z["etype"], z["norm"])
+    for name in ("pre_sub", "f_sparse_comp", "a_sum", "a_max"):
+        op = O.MIXED_OPS[name]({"feature_dim": z["D"], "drop_aggr": 0.0})
+        with pytest.raises(_lib.MrgnasError):
+            op(g, z["x"], z["x_in"])
+
+
+def test_registries_match_reference_lists():
+    # reference models/operations_lp.py:8-37
+    assert O.PRE_OPS == ['pre_mult', 'pre_sub', 'pre_add']
+    assert O.FIRST_OPS == ['f_zero', 'f_identity', 'f_dense_comp', 'f_sparse_comp', 'f_comp']
+    assert O.MIDDLE_OPS == ['a_max', 'a_sum', 'a_mean']
+    assert O.LAST_OPS == ['f_zero', 'f_identity', 'f_dense_last', 'f_sparse_last']
+    assert O.SF_OPS == ['sf_TransE', 'sf_DisMult']
+    assert sorted(O.MIXED_OPS) == sorted(['pre_mult', 'pre_sub', 'pre_add', 'f_zero', 'f_identity', 'f_dense', 'f_dense_comp',
+                                          'f_comp', 'f_sparse', 'f_sparse_comp', 'f_dense_last', 'f_sparse_last', 'a_max',
+                                          'a_mean', 'a_sum'])
+    assert sorted(O.MIXED_OPS_sf) == ['sf_ConvE', 'sf_DisMult', 'sf_TransE']
+    z = load_golden("ops_tiny_train")
+    for name in O.MIXED_OPS:          # parameter names/shapes == the reference's state_dict
+        op = O.MIXED_OPS[name]({"feature_dim": z["D"], "drop_aggr": 0.0})
+        tag = name if (name + "/out") in z else name + "@node"
+        ref = {k[len(tag) + 7:]: tuple(v.shape) for k, v in z.items() if k.startswith(tag + "/param/")}
+        assert {k: tuple(v.shape) for k, v in op.state_dict().items()} == ref, name
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 64])
+def test_dst_csr_plan(chunk):
+    rng = np.random.default_rng(0)
+    N, E = 23, 400
+    dst = torch.from_numpy(rng.integers(0, N - 3, size=E))          # last 3 nodes have no in-edge
+    dst[:150] = 5                                                     # a hub
+    p = G.dst_csr_plan(dst, N, chunk=chunk)
+    eid = p["eid"].long()
+    assert sorted(eid.tolist()) == list(range(E))
+    assert torch.equal(p["in_degree"].long(), torch.bincount(dst, minlength=N))
+    seen = torch.zeros(E, dtype=torch.long)
+    nodes_seen = set()
+    for c in range(p["n_chunks"]):
+        v, a, b = int(p["chunk_node"][c]), int(p["chunk_start"][c]), int(p["chunk_end"][c])
+        nodes_seen.add(v)
+        assert 0 <= b - a <= chunk
+        ids = eid[a:b]
+        assert torch.all(dst[ids] == v)
+        assert torch.all(ids[1:] > ids[:-1])                          # ascending edge ids inside a row
+        seen[ids] += 1
+        whole = (b - a) == int(p["in_degree"][v])
+        assert (int(p["chunk_slot"][c]) == -1) == whole
+    assert torch.all(seen == 1) and nodes_seen == set(range(N))
+    slots = [int(s) for s in p["chunk_slot"] if int(s) >= 0]
+    assert slots == list(range(p["n_slots"]))
+    for j in range(p["n_hubs"]):
+        v, f, cnt = int(p["hub_node"][j]), int(p["hub_first"][j]), int(p["hub_count"][j])
+        mine = [int(p["chunk_slot"][c]) for c in range(p["n_chunks"]) if int(p["chunk_node"][c]) == v]
+        assert mine == list(range(f, f + cnt)) and cnt > 1
+
+
+def test_graph_builders_bit_exact_vs_reference():
+    z = load_golden("graph_small")
+    for order, fn in (("train", G.build_train_graph), ("search", G.build_search_graph)):
+        g = fn(z["N"], z["R"], z["triples"].numpy())
+        s, d, _ = g.edges(form="all")
+        assert torch.equal(s, z[order + "/src"]) and torch.equal(d, z[order + "/dst"])
+        assert torch.equal(g.edata["e_type"], z[order + "/etype"])
+        assert torch.equal(g.edata["norm"], z[order + "/norm"])
+    assert g.num_edges() == 2 * z["triples"].shape[0] and g.nodes().numel() == z["N"]

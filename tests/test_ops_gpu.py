@@ -1,0 +1,176 @@
+"""GPU parity of the HIP operators (through the C ABI) against (1) the golden
+vectors produced by the reference and (2) the CPU oracle on seeded inputs.
+Tolerance: 1e-4 relative (BASELINE.json north_star), bit-exact for gathers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+import mr_gnas_amd
+from mr_gnas_amd import functional as K, graph as G, operations_lp as O
+from oracle import ops as OO
+from oracle.graph import OGraph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OPS_CASES = ["ops_tiny_train", "ops_small_search", "ops_mid_train", "ops_d100_search", "ops_odd_train"]
+
+
+def close(a, b, what, rtol=1e-4, atol=2e-5):
+    a = a.detach().cpu()
+    scale = float(b.abs().max()) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    assert err <= atol + rtol * max(scale, 1.0), f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def dev_graph(z):
+    return G.RelGraph(z["N"], z["src"], z["dst"], z["etype"], z["norm"], device=DEV)
+
+
+def run_module(op, g, a, b, gout):
+    a = a.to(DEV).requires_grad_(True)
+    b = b.to(DEV).requires_grad_(True)
+    out = op(g, a, b)
+    out.backward(gout.to(DEV))
+    z = torch.zeros_like
+    return out, (a.grad if a.grad is not None else z(a)), (b.grad if b.grad is not None else z(b))
+
+
+@pytest.mark.parametrize("case", OPS_CASES)
+def test_ops_against_reference_golden(case):
+    z = load_golden(case)
+    g = dev_graph(z)
+    tags = sorted({k.split("/")[0] for k in z if k.endswith("/out") and not k.startswith("sf_")})
+    for tag in tags:
+        name = tag.split("@")[0]
+        if tag.endswith("@node"):
+            a, b, gout = z["xn"], z["xn"], z["gN"]
+        elif name.startswith("a_"):
+            a, b, gout = z["x"], z["x_in"], z["gN"]
+        elif name.startswith("pre_"):
+            a, b, gout = z["x"], z["hr"], z["gM"]
+        else:
+            a, b, gout = z["x"], z["x_in"], z["gM"]
+        op = O.MIXED_OPS[name]({"feature_dim": z["D"], "drop_aggr": 0.0}).to(DEV)
+        op.load_state_dict(sub(z, tag + "/param/"))          # reference state_dict loads unchanged
+        out, ga, gb = run_module(op, g, a, b, gout)
+        close(out, z[tag + "/out"], f"{case}:{tag} out")
+        close(ga, z[tag + "/ga"], f"{case}:{tag} grad src_emb")
+        close(gb, z[tag + "/gb"], f"{case}:{tag} grad src_emb_in")
+        for k, p in op.named_parameters():
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            close(got, z[f"{tag}/gparam/{k}"], f"{case}:{tag} grad {k}", rtol=2e-4, atol=5e-5)
+
+
+def test_gather_is_bit_exact():
+    gen = torch.Generator().manual_seed(0)
+    for D in (8, 10, 64, 200, 256, 512):
+        ent = torch.randn(301, D, generator=gen)
+        rel = torch.randn(17, D, generator=gen)
+        ei = torch.randint(0, 301, (1000,), generator=gen)
+        ri = torch.randint(0, 17, (1000,), generator=gen)
+        out = K.gather_rows(ent.to(DEV), ei.to(DEV).int())
+        assert torch.equal(out.cpu(), ent[ei]), D
+        for kind, f in (("sub", lambda a, b: a - b), ("mult", lambda a, b: a * b), ("add", lambda a, b: a + b)):
+            out = K.gather_rows(ent.to(DEV), ei.to(DEV).int(), rel.to(DEV), ri.to(DEV).int(), kind)
+            assert torch.equal(out.cpu(), f(ent[ei], rel[ri])), (D, kind)
+
+
+def synth(N, T, R, seed, hub_frac=0.3):
+    rng = np.random.default_rng(seed)
+    p = 1.0 / np.arange(1, N + 1) ** 0.75
+    p /= p.sum()
+    s, o = rng.choice(N, size=T, p=p), rng.choice(N, size=T, p=p)
+    o[: int(T * hub_frac)] = 1
+    r = rng.integers(0, R, size=T)
+    return np.stack([s, r, o], 1)
+
+
+@pytest.mark.parametrize("N,T,R,D,order", [(500, 6000, 11, 200, "train"), (300, 3000, 7, 64, "search"),
+                                           (200, 2500, 5, 256, "train"), (150, 1500, 5, 512, "search"),
+                                           (90, 700, 4, 6, "train")])
+def test_star_ops_against_oracle(N, T, R, D, order):
+    """Bigger seeded graphs with a hub whose in-edge list is split into many chunks."""
+    tri = synth(N, T, R, seed=N + D)
+    build = G.build_train_graph if order == "train" else G.build_search_graph
+    g_cpu = build(N, R, tri)
+    s, d, _ = g_cpu.edges(form="all")
+    og = OGraph(N, s, d, g_cpu.edata["e_type"], g_cpu.edata["norm"])
+    g = g_cpu.to(DEV)
+    assert g.plan()["n_hubs"] >= 1
+    E = g.num_edges()
+    gen = torch.Generator().manual_seed(D)
+    x, x_in = torch.randn(E + N, D, generator=gen), torch.randn(E + N, D, generator=gen)
+    gM, gN = torch.randn(E + N, D, generator=gen), torch.randn(N, D, generator=gen)
+    for name in ("pre_mult", "pre_sub", "pre_add", "f_sparse_comp", "a_sum", "a_mean", "a_max"):
+        P = OO.init_params(name, D, gen)
+        for k in P:
+            if k.endswith("bias"):
+                P[k] = torch.randn(P[k].shape, generator=gen) * 0.1
+        gout = gN if name.startswith("a_") else gM
+        a = x.clone().requires_grad_(True)
+        b = x_in.clone().requires_grad_(True)
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        ref = OO.OPS[name](og, Pr, a, b)
+        ref.backward(gout)
+        op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+        op.load_state_dict(P)
+        out, ga, gb = run_module(op, g, x, x_in, gout)
+        close(out, ref.detach(), f"{name} out")
+        close(ga, a.grad, f"{name} ga")
+        if b.grad is not None:
+            close(gb, b.grad, f"{name} gb")
+        for k, p in op.named_parameters():
+            close(p.grad, Pr[k].grad, f"{name} grad {k}", rtol=3e-4, atol=1e-4)
+    P = OO.init_params("f_sparse_last", D, gen)
+    xn = torch.randn(N, D, generator=gen)
+    a = xn.clone().requires_grad_(True)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = OO.f_sparse_last(og, Pr, a, a)
+    ref.backward(gN)
+    op = O.MIXED_OPS["f_sparse_last"]({"feature_dim": D}).to(DEV)
+    op.load_state_dict(P)
+    out, ga, _ = run_module(op, g, xn, xn, gN)
+    close(out, ref.detach(), "f_sparse_last out")
+    close(ga, a.grad, "f_sparse_last ga")
+    for k, p in op.named_parameters():
+        close(p.grad, Pr[k].grad, f"f_sparse_last grad {k}", rtol=3e-4, atol=1e-4)
+
+
+def test_edge_cases_empty_and_isolated():
+    D = 16
+    # a graph with no edges at all: aggregators return the self rows, gates only see self rows
+    g = G.RelGraph(5, torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long),
+                   torch.zeros(0, dtype=torch.long), torch.zeros(0), device=DEV)
+    x = torch.randn(5, D, device=DEV, requires_grad=True)
+    for name in ("a_sum", "a_max", "a_mean"):
+        op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+        out = op(g, x, x)
+        assert torch.equal(out, x.detach())
+        out.sum().backward()
+    op = O.MIXED_OPS["f_sparse_comp"]({"feature_dim": D}).to(DEV)
+    out = op(g, x, x)
+    assert out.shape == x.shape and torch.isfinite(out).all()
+    # zero rows
+    assert K.compose("sub", torch.zeros(0, D, device=DEV), torch.zeros(0, D, device=DEV)).shape == (0, D)
+
+
+def test_linear_mfma_shapes():
+    gen = torch.Generator().manual_seed(3)
+    for rows, Kd, Nout in ((1, 8, 8), (130, 200, 200), (257, 64, 40), (1000, 100, 256), (300, 10, 7), (513, 256, 256), (77, 400, 200)):
+        x = torch.randn(rows, Kd, generator=gen)
+        W = torch.randn(Nout, Kd, generator=gen) / Kd ** 0.5
+        b = torch.randn(Nout, generator=gen)
+        gy = torch.randn(rows, Nout, generator=gen)
+        for act in (None, "relu"):
+            xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+            ref = torch.nn.functional.linear(xr.double(), Wr.double(), br.double())
+            ref = torch.relu(ref) if act else ref
+            ref.backward(gy.double())
+            xd, Wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, W, b))
+            out = K.linear(xd, Wd, bd, act)
+            out.backward(gy.to(DEV))
+            close(out, ref.float().detach(), f"linear {rows}x{Kd}x{Nout} {act}", rtol=2e-5, atol=2e-5)
+            close(xd.grad, xr.grad, "linear gx", rtol=2e-5, atol=2e-5)
+            close(Wd.grad, Wr.grad, "linear gW", rtol=5e-5, atol=5e-5)
+            close(bd.grad, br.grad, "linear gb", rtol=5e-5, atol=5e-5)
