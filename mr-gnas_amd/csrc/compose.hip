@@ -88,11 +88,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void gather_compose_k(const float* __res
 using namespace mrg;
 
 extern "C" int mrg_compose_fwd(int op, const float* s, const float* hr, float* out, int64_t rows, int D, void* stream) {
-  if (!s || !hr || !out) return MRG_E_NULLPTR;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (op < 0 || op > 2) return MRG_E_ENUM;
   int64_t n = rows * D;
   if (n == 0) return MRG_OK;
+  if (!s || !hr || !out) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
   bool v4 = (n % 4 == 0) && aligned16(s) && aligned16(hr) && aligned16(out);
   int64_t nv = v4 ? n / 4 : n;
@@ -107,12 +107,12 @@ extern "C" int mrg_compose_fwd(int op, const float* s, const float* hr, float* o
 
 extern "C" int mrg_compose_bwd(int op, const float* gout, const float* s, const float* hr, float* gs, float* ghr,
                                int64_t rows, int D, void* stream) {
-  if (!gout) return MRG_E_NULLPTR;
-  if (op == MRG_COMPOSE_MULT && ((gs && !hr) || (ghr && !s))) return MRG_E_NULLPTR;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (op < 0 || op > 2) return MRG_E_ENUM;
   int64_t n = rows * D;
   if (n == 0 || (!gs && !ghr)) return MRG_OK;
+  if (!gout) return MRG_E_NULLPTR;
+  if (op == MRG_COMPOSE_MULT && ((gs && !hr) || (ghr && !s))) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
   bool v4 = (n % 4 == 0) && aligned16(gout) && aligned16(s) && aligned16(hr) && aligned16(gs) && aligned16(ghr);
   int64_t nv = v4 ? n / 4 : n;
@@ -127,11 +127,11 @@ extern "C" int mrg_compose_bwd(int op, const float* gout, const float* s, const 
 
 extern "C" int mrg_gather_compose_fwd(int op, const float* ent, const float* rel, const int32_t* ent_idx,
                                       const int32_t* rel_idx, float* out, int64_t rows, int D, void* stream) {
-  if (!ent || !ent_idx || !out) return MRG_E_NULLPTR;
-  if (op >= 0 && (!rel || !rel_idx)) return MRG_E_NULLPTR;
   if (op < -1 || op > 2) return MRG_E_ENUM;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
+  if (!ent || !ent_idx || !out) return MRG_E_NULLPTR;
+  if (op >= 0 && (!rel || !rel_idx)) return MRG_E_NULLPTR;
   RowGeom g = row_geom(D, aligned16(ent) && aligned16(out) && (op < 0 || aligned16(rel)));
   if (!g.ok) return MRG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;

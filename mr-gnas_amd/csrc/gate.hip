@@ -258,9 +258,9 @@ extern "C" int mrg_gate_param_grad(const float* W, const float* b, const float* 
 
 extern "C" int mrg_gate_fwd(const float* s, const float* s_in, const float* norm, const float* uvc, float* out, int64_t b0,
                             int64_t b1, int64_t M, int D, float scale, void* stream) {
-  if (!s || !uvc || !out) return MRG_E_NULLPTR;
   if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
   if (M == 0) return MRG_OK;
+  if (!s || !uvc || !out) return MRG_E_NULLPTR;
   RowGeom g = row_geom(D, aligned16(s) && aligned16(s_in) && aligned16(out) && aligned16(uvc));
   if (!g.ok) return MRG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
@@ -287,10 +287,11 @@ extern "C" int64_t mrg_gate_bwd_workspace_bytes(int64_t M, int D) {
 extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in, const float* norm, const float* uvc,
                             float* gs, float* gs_in, float* d_uvc, void* ws, int64_t b0, int64_t b1, int64_t M, int D,
                             float scale, void* stream) {
-  if (!gout || !s || !uvc || !gs || !d_uvc) return MRG_E_NULLPTR;
+  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (!uvc || !d_uvc) return MRG_E_NULLPTR;
+  if (M > 0 && (!gout || !s || !gs)) return MRG_E_NULLPTR;
   if (s_in && !gs_in) return MRG_E_NULLPTR;
   if (!ws) return MRG_E_WORKSPACE;
-  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int ld = MRG_GATE_LD(D);
   RowGeom g = row_geom(D, aligned16(gout) && aligned16(s) && aligned16(s_in) && aligned16(gs) && aligned16(gs_in) && aligned16(uvc));

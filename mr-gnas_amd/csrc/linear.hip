@@ -268,17 +268,17 @@ using namespace mrg;
 
 extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias, float* Y, int64_t rows, int K, int Nout,
                               int act, void* stream) {
-  if (!X || !W || !Y) return MRG_E_NULLPTR;
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
   if (act != MRG_ACT_NONE && act != MRG_ACT_RELU) return MRG_E_ENUM;
   if (rows == 0) return MRG_OK;
+  if (!X || !W || !Y) return MRG_E_NULLPTR;
   return launch_linear<false>(X, W, bias, Y, rows, K, Nout, act, (hipStream_t)stream);
 }
 
 extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, int64_t rows, int K, int Nout, void* stream) {
-  if (!gY || !W || !gX) return MRG_E_NULLPTR;
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
+  if (!gY || !W || !gX) return MRG_E_NULLPTR;
   // gX[rows, K] = gY[rows, Nout] * W[Nout, K]: reduction over Nout, W read as [k = Nout][n = K]
   return launch_linear<true>(gY, W, nullptr, gX, rows, Nout, K, MRG_ACT_NONE, (hipStream_t)stream);
 }
@@ -291,10 +291,16 @@ extern "C" int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, in
 
 extern "C" int mrg_linear_bwd_weight(const float* gY, const float* X, float* gW, float* gbias, void* ws, int64_t rows, int K,
                                      int Nout, void* stream) {
-  if (!gY || !X || !gW) return MRG_E_NULLPTR;
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
-  if (!ws) return MRG_E_WORKSPACE;
+  if (!gW) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {                       // no rows: the gradients are exactly zero
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)Nout * K, st);
+    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Nout, st);
+    return (int)e;
+  }
+  if (!gY || !X) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
   WgradPlan p = wgrad_plan(rows, K, Nout);
   if (!p.ok) return MRG_E_SHAPE;
   const int vecG = (Nout % 4 == 0) && aligned16(gY);

@@ -269,3 +269,44 @@ class _Linear(torch.autograd.Function):
 def linear(x, W, b=None, act=None):
     """act(x W^T + b) with exact-f32 MFMA (nn.Linear semantics)."""
     return _Linear.apply(x, W, b, ACT[act])
+
+
+# ---------------------------------------------------------------------------
+# G: row gather with a deterministic (atomic-free) backward
+# ---------------------------------------------------------------------------
+class GatherPlan:
+    """Index of a gather ``out[i] = table[idx[i]]``: the int32 index for the
+    forward and a CSR over table rows (graph.dst_csr_plan) for the backward,
+    which is a segmented sum of the incoming gradient rows."""
+
+    def __init__(self, idx, num_table_rows):
+        from .graph import dst_csr_plan
+        self.idx32 = idx.to(torch.int32).contiguous()
+        self.rows = int(num_table_rows)
+        self.plan = dst_csr_plan(idx, self.rows)
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, gp):
+        ctx.gp = gp
+        return gather_rows(table, gp.idx32)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = f32c(g)
+        p, N, D = ctx.gp.plan, ctx.gp.rows, g.shape[1]
+        out = torch.empty(N, D, dtype=torch.float32, device=g.device)
+        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), g) if p["n_slots"] > 0 else None
+        check(lib.mrg_seg_reduce_fwd(0, ptr(g), None, ptr(p["eid"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
+                                     ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"], ptr(p["hub_node"]),
+                                     ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"], p["n_slots"],
+                                     ptr(p["in_degree"]), ptr(out), None, ptr(ws), N, D, stream_of(g)),
+              "mrg_seg_reduce_fwd(gather backward)")
+        return out, None
+
+
+def gather(table, gp):
+    """table[gp.idx] with autograd (reference models/model_lp.py:131, models/model_search_lp.py:144-145,153-154)."""
+    return _Gather.apply(table, gp)

@@ -1,0 +1,293 @@
+"""Callers of the hot path: the DARTS-style mixed-op supernet and the fixed-genotype
+network, built on this package's operator registry.
+
+They exist so the benchmark and the parity tests can run a full MR-GNAS step on
+the GPU box (the reference's own ``models/cell_lp.py`` / ``models/model_lp.py`` /
+``models/model_search_lp.py`` work unchanged on ``mr_gnas_amd.operations_lp`` but
+cannot travel).  Module/attribute names follow the reference so that its
+``state_dict`` keys load here unchanged:
+
+* supernet   ``cells.{l}.cell_{zero,first,middle,last}._ops.{j}._ops.{k}.{0|1}.*``,
+             ``cells.{l}.concat_weights.*``, ``batchnorm_h.*``, ``embedding_h``,
+             ``embedding_e``, ``linear_e``, ``rel_wt``, ``w_rel``
+             (reference models/cell_lp.py:12-188, models/model_search_lp.py:16-163)
+* fixed      ``cells.{l}._ops.{center}.{pre}.0.{op|batchnorm_h}.*``, ``cells.{l}.concat.*``,
+             ``cells.{l}.batchnorm_h.*``  (reference models/model_lp.py:13-137)
+"""
+import collections
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as K
+from . import operations_lp as OPS
+
+Genotype = collections.namedtuple('Genotype', 'alpha_cell concat_node score_func')   # reference configs/genotypes.py:3
+
+
+def xavier_init_(module):
+    """What the reference drivers apply after construction (utils/utils.py:121-125)."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+    return module
+
+
+def _xavier_param(*shape):
+    p = nn.Parameter(torch.empty(*shape))
+    nn.init.xavier_normal_(p, gain=nn.init.calculate_gain('relu'))
+    return p
+
+
+# ---------------------------------------------------------------------------
+# supernet
+# ---------------------------------------------------------------------------
+class MixedOp(nn.Module):
+    """sum_k w_k * ReLU(BN_k(op_k(g, h, h_in)))   (reference models/cell_lp.py:12-33)."""
+
+    def __init__(self, feature_dim, drop_aggr, operations, registry=OPS.MIXED_OPS):
+        super().__init__()
+        args = {'feature_dim': feature_dim, 'drop_aggr': drop_aggr}
+        self._ops = nn.ModuleList(nn.ModuleList([registry[name](args), nn.BatchNorm1d(feature_dim), nn.ReLU()])
+                                  for name in operations)
+
+    def forward(self, weights, g, h, h_in):
+        total = 0
+        for w, (op, bn, act) in zip(weights, self._ops):
+            total = total + w * act(bn(op(g, h, h_in).float()))
+        return total
+
+
+class _Stage(nn.Module):
+    """A list of MixedOps under the attribute name ``_ops`` (the reference's Cell_* classes)."""
+
+    def __init__(self, count, feature_dim, drop_aggr, operations, registry):
+        super().__init__()
+        self._ops = nn.ModuleList(MixedOp(feature_dim, drop_aggr, operations, registry) for _ in range(count))
+
+
+class SuperCell(nn.Module):
+    """Zero -> First -> Middle -> Last stages and the concat linear
+    (reference models/cell_lp.py:53-188)."""
+
+    def __init__(self, n_zero, n_first, n_last, feature_dim, drop_aggr, registry=OPS.MIXED_OPS):
+        super().__init__()
+        self.n_first, self.n_last = n_first, n_last
+        mk = lambda cnt, names: _Stage(cnt, feature_dim, drop_aggr, names, registry)
+        self.cell_zero = mk(1, OPS.PRE_OPS)
+        self.cell_first = mk(sum(i + 1 for i in range(n_first)), OPS.FIRST_OPS)
+        self.cell_middle = mk(n_first, OPS.MIDDLE_OPS)
+        self.cell_last = mk(sum(n_first + i for i in range(n_last)), OPS.LAST_OPS)
+        self.concat_weights = nn.Linear((n_first + n_last) * feature_dim, feature_dim)
+
+    @staticmethod
+    def _dense_stage(stage, states, weights, g, h_in, steps):
+        off = 0
+        for _ in range(steps):
+            s = sum(stage._ops[off + j](weights[off + j], g, h, h_in) for j, h in enumerate(states))
+            off += len(states)
+            states.append(s)
+        return states
+
+    def forward(self, g, src_emb, hr, w_zero, w_first, w_middle, w_last):
+        h_in = self.cell_zero._ops[0](w_zero[0], g, src_emb, hr)
+        states = self._dense_stage(self.cell_first, [h_in], w_first, g, h_in, self.n_first)[1:]
+        states = [self.cell_middle._ops[i](w_middle[i], g, states[i], h_in) for i in range(self.n_first)]
+        states = self._dense_stage(self.cell_last, states, w_last, g, h_in, self.n_last)
+        return self.concat_weights(torch.cat(states, dim=1))
+
+
+class SearchNetwork(nn.Module):
+    """The mixed-op supernet (reference models/model_search_lp.py:16-194)."""
+
+    def __init__(self, device, number_of_nodes, num_rels, layers, zero_nodes, first_nodes, last_nodes, feature_dim,
+                 init_fea_dim, num_base_r, gamma, dropout_cell, drop_aggr, registry=OPS.MIXED_OPS):
+        super().__init__()
+        self._device = device
+        self._layers, self._num_ent, self._num_rel = layers, number_of_nodes, num_rels * 2 + 1
+        self._feature_dim, self._dropout, self.gamma = feature_dim, dropout_cell, gamma
+        self.nz, self.nf, self.nl = zero_nodes, first_nodes, last_nodes
+        self.n_first_edges = sum(zero_nodes + i for i in range(first_nodes))
+        self.n_last_edges = sum(first_nodes + i for i in range(last_nodes))
+        self.embedding_h = nn.Embedding(number_of_nodes, init_fea_dim)
+        self.embedding_e = nn.Embedding(num_base_r, feature_dim)
+        self.linear_e = nn.Linear(init_fea_dim, feature_dim)
+        self.rel_wt = _xavier_param(self._num_rel, num_base_r)
+        self.w_rel = _xavier_param(feature_dim, feature_dim)
+        self.cells = nn.ModuleList(SuperCell(zero_nodes, first_nodes, last_nodes, feature_dim, drop_aggr, registry)
+                                   for _ in range(layers))
+        self.batchnorm_h = nn.BatchNorm1d(feature_dim)
+        # architecture parameters: not part of state_dict, exactly as in the reference (:99-129)
+        mk = lambda rows, cols: (1e-3 * torch.randn(rows * layers, cols, device=device)).requires_grad_(True)
+        self._arch_parameters = [mk(zero_nodes, len(OPS.PRE_OPS)), mk(self.n_first_edges, len(OPS.FIRST_OPS)),
+                                 mk(first_nodes, len(OPS.MIDDLE_OPS)), mk(self.n_last_edges, len(OPS.LAST_OPS)),
+                                 (1e-3 * torch.randn(1, len(OPS.SF_OPS), device=device)).requires_grad_(True)]
+        self._gather_cache = {}
+
+    def arch_parameters(self):
+        return self._arch_parameters
+
+    def load_alpha(self, alphas):
+        for x, y in zip(self._arch_parameters, alphas):
+            x.data.copy_(y.data)
+
+    def layer_weights(self, l):
+        a = self._arch_parameters
+        sl = lambda t, n: F.softmax(t[l * n:(l + 1) * n], dim=1)
+        return sl(a[0], self.nz), sl(a[1], self.n_first_edges), sl(a[2], self.nf), sl(a[3], self.n_last_edges)
+
+    def _plans(self, g, node_id, src_in, edge_type):
+        """Gather indices of a step graph (computed once per graph object, cached on it)."""
+        key = "_mrg_search_plans"
+        if getattr(g, key, None) is None:
+            n = g.number_of_nodes()
+            dev = src_in.device
+            src_in_f = torch.cat((src_in.long(), torch.arange(n, device=dev)))
+            ent_idx = node_id.view(-1).long()[src_in_f]
+            rel_idx = torch.cat((edge_type.long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
+            setattr(g, key, (K.GatherPlan(ent_idx, self._num_ent), K.GatherPlan(rel_idx, self._num_rel),
+                             K.GatherPlan(src_in.long(), n)))
+        return getattr(g, key)
+
+    def forward(self, g_train, node_id, src_in, edge_type):
+        ent_all = self.linear_e(self.embedding_h.weight)
+        rel = torch.mm(self.rel_wt, self.embedding_e.weight)
+        p_ent, p_rel, p_in = self._plans(g_train, node_id, src_in, edge_type)
+        ent = None
+        for l, cell in enumerate(self.cells):
+            wz, wf, wm, wl = self.layer_weights(l)
+            x = K.gather(ent_all, p_ent) if l == 0 else torch.cat((K.gather(ent, p_in), ent), dim=0)
+            ent = self.batchnorm_h(cell(g_train, x, K.gather(rel, p_rel), wz, wf, wm, wl))
+            if l > 0 or self._layers == 1:
+                ent = F.relu(ent)
+            ent = F.dropout(ent, self._dropout, training=self.training)
+            rel = torch.matmul(rel, self.w_rel)
+        return ent, rel
+
+    @staticmethod
+    def calc_score(ent, rel, triplets):
+        return torch.sum(ent[triplets[:, 0]] * rel[triplets[:, 1]] * ent[triplets[:, 2]], dim=1)
+
+    def get_loss(self, g_train, ent, rel, triplets, labels):
+        return F.binary_cross_entropy_with_logits(self.calc_score(ent, rel, triplets), labels)
+
+    def show_genotype(self, l):
+        """Arg-max decoding of one layer (reference models/model_search_lp.py:215-311)."""
+        wz, wf, wm, wl = (w.detach().cpu() for w in self.layer_weights(l))
+        gene, nz, nf, nl = [], self.nz, self.nf, self.nl
+        for n in range(nz):
+            gene.append((OPS.PRE_OPS[int(wz[n].argmax())], n + 1, n))
+        top = nz                                           # == max(pre_nodes) after the zero stage
+
+        def best_edge(W, names, count):
+            skip = names.index('f_zero')
+            cols = [k for k in range(len(names)) if k != skip]
+            j = max(range(count), key=lambda x: (max(float(W[x][k]) for k in cols), -x))
+            k = max(cols, key=lambda c: (float(W[j][c]), -c))
+            return j, k
+
+        start = 0
+        for n in range(1, nf + 1):
+            j, k = best_edge(wf[start:start + n], OPS.FIRST_OPS, n)
+            gene.append((OPS.FIRST_OPS[k], top + n, top + j))
+            start += n
+        concat, middle = [], list(range(2, 2 + nf))
+        for n in range(nf):
+            new = max(middle) + 1
+            gene.append((OPS.MIDDLE_OPS[int(wm[n].argmax())], new, middle[n]))
+            concat.append(new)
+            middle[n] = new
+        start = 0
+        for n in range(nl):
+            cnt = nf + n
+            j, k = best_edge(wl[start:start + cnt], OPS.LAST_OPS, cnt)
+            node = n + max(middle) + 1
+            gene.append((OPS.LAST_OPS[k], node, middle[j] if j < nf else j - nf + max(middle) + 1))
+            concat.append(node)
+            start += cnt
+        return Genotype(alpha_cell=gene, concat_node=concat, score_func=None)
+
+    def show_genotypes(self):
+        return [self.show_genotype(l) for l in range(self._layers)]
+
+
+# ---------------------------------------------------------------------------
+# fixed genotype
+# ---------------------------------------------------------------------------
+class OpModule(nn.Module):
+    """op -> BN -> ReLU; only 'pre_mult' skips BN/ReLU (the reference's condition at
+    models/model_lp.py:31 reduces to ``op_name != 'pre_mult'``; :34 discards its dropout)."""
+
+    def __init__(self, feature_dim, drop_aggr, name, registry=OPS.MIXED_OPS):
+        super().__init__()
+        self.op = registry[name]({'feature_dim': feature_dim, 'drop_aggr': drop_aggr})
+        self.op_name = name
+        self.batchnorm_h = nn.BatchNorm1d(feature_dim)
+
+    def forward(self, g, h, h_in):
+        h = self.op(g, h, h_in)
+        return F.relu(self.batchnorm_h(h)) if self.op_name != 'pre_mult' else h
+
+
+class FixedCell(nn.Module):
+    def __init__(self, feature_dim, drop_aggr, genotype, registry=OPS.MIXED_OPS):
+        super().__init__()
+        nb = len({c for _, c, _ in genotype.alpha_cell})
+        self._nb = nb
+        self._concat_node = list(range(1, 1 + nb)) if genotype.concat_node is None else list(genotype.concat_node)
+        self._ops = nn.ModuleList(nn.ModuleList(nn.ModuleList() for _ in range(n)) for n in range(1, 1 + nb))
+        for name, center, pre in genotype.alpha_cell:
+            self._ops[center - 1][pre].append(OpModule(feature_dim, drop_aggr, name, registry))
+        self.concat = nn.Linear(len(self._concat_node) * feature_dim, feature_dim)
+        self.batchnorm_h = nn.BatchNorm1d(feature_dim)
+
+    def forward(self, g, src_emb, hr):
+        zero_out = self._ops[0][0][0](g, src_emb, hr)
+        states = [src_emb, zero_out]
+        for n in range(1, self._nb):
+            states.append(sum(self._ops[n][i][0](g, states[i], zero_out) for i in range(n + 1) if len(self._ops[n][i])))
+        h = self.concat(torch.cat([states[i] for i in self._concat_node], dim=1))
+        return F.relu(self.batchnorm_h(h))
+
+
+class FixedNetwork(nn.Module):
+    """Fixed-genotype link-prediction network (reference models/model_lp.py:77-150)."""
+
+    def __init__(self, device, genotype, number_of_nodes, num_rels, feature_dim, init_fea_dim, num_base_r,
+                 criterion=None, dropout_cell=0.0, drop_aggr=0.0, score_args=None, registry=OPS.MIXED_OPS):
+        super().__init__()
+        self._device, self._num_ent, self._num_rel = device, number_of_nodes, num_rels * 2 + 1
+        self._dropout, self.criterion = dropout_cell, criterion or nn.BCELoss()
+        self.embedding_h = nn.Embedding(number_of_nodes, init_fea_dim)
+        self.embedding_e = nn.Embedding(num_base_r, feature_dim)
+        self.linear_e = nn.Linear(init_fea_dim, feature_dim)
+        self.rel_wt = _xavier_param(self._num_rel, num_base_r)
+        self.cells = nn.ModuleList(FixedCell(feature_dim, drop_aggr, gt, registry) for gt in genotype)
+        self.score_func = OPS.MIXED_OPS_sf[genotype[-1].score_func](score_args or {})
+        self.w_rel = _xavier_param(feature_dim, feature_dim)
+
+    def _plans(self, g):
+        key = "_mrg_fixed_plans"
+        if getattr(g, key, None) is None:
+            src, _, _ = g.edges(form='all')
+            n, dev = g.number_of_nodes(), src.device
+            ent_idx = torch.cat((src, torch.arange(n, device=dev)))
+            rel_idx = torch.cat((g.edata['e_type'].long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
+            setattr(g, key, (K.GatherPlan(ent_idx, n), K.GatherPlan(rel_idx, self._num_rel)))
+        return getattr(g, key)
+
+    def forward(self, g, subj, rel):
+        ent = self.linear_e(self.embedding_h.weight)
+        rel_emb = torch.mm(self.rel_wt, self.embedding_e.weight)
+        p_ent, p_rel = self._plans(g)
+        for cell in self.cells:
+            ent = cell(g, K.gather(ent, p_ent), K.gather(rel_emb, p_rel))
+            ent = F.dropout(ent, self._dropout, training=self.training)
+            rel_emb = torch.matmul(rel_emb, self.w_rel)
+        return self.score_func(ent, ent[subj], rel_emb[rel])
+
+    def _loss(self, g, subj, rel, label):
+        return self.criterion(self.forward(g, subj, rel), label)

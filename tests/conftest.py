@@ -23,7 +23,7 @@ def load_golden(name):
             v = z[k]
             if v.dtype.kind in "US":
                 out[k] = str(v)
-            elif v.ndim == 0 and v.dtype.kind in "iu":
+            elif v.ndim == 0 and v.dtype.kind in "iu" and "/" not in k:
                 out[k] = int(v)
             else:
                 out[k] = torch.from_numpy(np.array(v))

@@ -104,3 +104,25 @@ def test_graph_builders_bit_exact_vs_reference():
         assert torch.equal(g.edata["e_type"], z[order + "/etype"])
         assert torch.equal(g.edata["norm"], z[order + "/norm"])
     assert g.num_edges() == 2 * z["triples"].shape[0] and g.nodes().numel() == z["N"]
+
+
+def test_harness_state_dict_keys_match_reference():
+    """The reference's checkpoints must load into the harness unchanged (keys and shapes)."""
+    from conftest import sub
+    from mr_gnas_amd import supernet as S
+    z = load_golden("supernet_tiny")
+    net = S.SearchNetwork("cpu", z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0)
+    ref = {**sub(z, "param/"), **sub(z, "buffer/")}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.items()}
+    net.load_state_dict(ref)
+    assert [tuple(a.shape) for a in net.arch_parameters()] == [tuple(z[f"alpha/{i}"].shape) for i in range(5)]
+    net.load_alpha([z[f"alpha/{i}"] for i in range(5)])
+    assert repr(net.show_genotype(0)) == z["genotype0"]
+
+    z = load_golden("fixednet_tiny")
+    geno = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2),
+                                   ('a_max', 5, 3), ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)],
+                       concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+    net = S.FixedNetwork("cpu", geno, z["N"], z["R"], z["D"], z["D0"], z["nbase"])
+    ref = {**sub(z, "param/"), **sub(z, "buffer/")}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.items()}

@@ -1,0 +1,61 @@
+"""GPU parity of the callers (fixed-genotype network, mixed-op supernet) running on
+the HIP operators, against the reference's golden vectors."""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from mr_gnas_amd import graph as G, supernet as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+README_GENOTYPE = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2),
+                                          ('a_max', 5, 3), ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)],
+                              concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+
+
+def grads_close(net, z, rtol, what):
+    for k, p in net.named_parameters():
+        ref = z["gparam/" + k]
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu()
+        scale = max(float(ref.abs().max()), 1e-6)
+        err = float((got - ref).abs().max())
+        assert err <= rtol * scale + 5e-6, f"{what} grad {k}: err {err:.3e} scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("case", ["fixednet_tiny", "fixednet_d64"])
+def test_fixed_genotype_network(case):
+    z = load_golden(case)
+    g = G.RelGraph(z["N"], z["src"], z["dst"], z["etype"], z["norm"], device=DEV)
+    net = S.FixedNetwork(DEV, README_GENOTYPE, z["N"], z["R"], z["D"], z["D0"], z["nbase"], score_args={"gamma": 9.0}).to(DEV)
+    net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+    net.train()
+    pred = net(g, z["subj"].to(DEV), z["rel"].to(DEV))
+    loss = torch.nn.functional.binary_cross_entropy(pred, z["label"].to(DEV))
+    loss.backward()
+    torch.testing.assert_close(pred.cpu(), z["pred"], rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(loss.detach().cpu(), z["loss"], rtol=1e-4, atol=1e-6)
+    grads_close(net, z, 5e-4, case)
+
+
+@pytest.mark.parametrize("case", ["supernet_tiny", "supernet_d24"])
+def test_supernet_step(case):
+    z = load_golden(case)
+    n = z["node_id"].numel()
+    g = G.RelGraph(n, z["src"], z["dst"], z["edge_type"], z["norm"], device=DEV)
+    net = S.SearchNetwork(DEV, z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0).to(DEV)
+    net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+    net.load_alpha([z[f"alpha/{i}"].to(DEV) for i in range(5)])
+    net.train()
+    ent, rel = net(g, z["node_id"].to(DEV), z["src_in"].to(DEV), z["edge_type"].to(DEV))
+    loss = net.get_loss(g, ent, rel, z["data"].to(DEV), z["labels"].to(DEV))
+    loss.backward()
+    torch.testing.assert_close(ent.cpu(), z["ent"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(rel.cpu(), z["rel_out"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss.detach().cpu(), z["loss"], rtol=1e-4, atol=1e-6)
+    for i in range(4):
+        ref = z[f"galpha/{i}"]
+        err = float((net.arch_parameters()[i].grad.cpu() - ref).abs().max())
+        assert err <= 2e-3 * max(float(ref.abs().max()), 1e-8) + 1e-7, f"alpha {i}: {err:.3e}"
+    grads_close(net, z, 2e-3, case)
+    assert repr(net.show_genotype(0)) == z["genotype0"]
