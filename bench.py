@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Benchmark of the MR-GNAS hot path on MI355X: one mixed-op supernet search step
+(forward + loss + backward + clip + SGD) per "step", FB15k-237-shaped synthetic
+KG, feature_dim = 200 (BASELINE.json config 2).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = million directed edges of the step graph
+processed per second (E / t_step / 1e6), inputs resident in HBM before timing.
+`roofline` prices the libmrgnas kernel with the largest device time in the timed
+steps (HIP events on the launch stream); `kernels` lists every libmrgnas entry
+point of one instrumented step; `cpu_baseline` times the CPU oracle on a bounded
+sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+MFMA_F32_PEAK_TFS = 157.3  # dense f32-input MFMA peak (same guide)
+MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_linrelu_segmax_fwd"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="fb15k237_supernet_full",
+                    choices=["fb15k237_supernet_full", "fb15k237_supernet_30k", "fb15k237_supernet_300", "wn18rr_supernet_full"])
+    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--negative", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=30000, help="graph_batch_size of the CPU-baseline sample")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_step_inputs(workload, negative, seed):
+    """numpy inputs of one search step: (num_ent, num_rels, node_id, graph_triples, samples, labels)."""
+    from mr_gnas_amd import synth
+    ds, _, size = workload.split("_")
+    N, R, T = synth.SHAPES[ds]
+    tri = synth.synth_kg(N, R, T, seed)
+    if size == "full":
+        rng = np.random.default_rng(seed + 1)
+        samples, labels = synth.negative_sampling(tri, N, negative, rng)
+        return N, R, np.arange(N), tri, samples, labels
+    sample = {"30k": 30000, "300": 300}[size]
+    node_id, gtri, samples, labels = synth.sample_step_graph(tri, sample, 0.5, negative, seed + 1)
+    return N, R, node_id, gtri, samples, labels
+
+
+class Step:
+    """One search step on the HIP operators (reference search/mr_lp_search.py:187-245, without
+    the sampler and the architect step)."""
+
+    def __init__(self, args, device, inputs):
+        from mr_gnas_amd import graph as G, supernet as S
+        N, R, node_id, gtri, samples, labels = inputs
+        torch.manual_seed(args.seed)
+        self.g = G.build_search_graph(len(node_id), R, gtri).to(device)
+        self.E = self.g.num_edges()
+        src, _, _ = self.g.edges(form="all")
+        self.node_id = torch.from_numpy(node_id).view(-1, 1).long().to(device)
+        self.src_in = src
+        self.edge_type = self.g.edata["e_type"]
+        self.samples = torch.from_numpy(samples).to(device)
+        self.labels = torch.from_numpy(labels).to(device)
+        # reference defaults (search/mr_lp_search.py:284-326)
+        self.model = S.SearchNetwork(device, N, R, 2, 1, 2, 2, args.dim, 100, 2 * R + 1, 40.0, 0.3, 0.1).to(device)
+        S.xavier_init_(self.model)
+        self.model.train()
+        self.opt = torch.optim.SGD(self.model.parameters(), 1e-3, momentum=0.9, weight_decay=0.0)
+        self.clip = 5.0
+        self.last_loss = None
+
+    def __call__(self):
+        ent, rel = self.model(self.g, self.node_id, self.src_in, self.edge_type)
+        loss = self.model.get_loss(self.g, ent, rel, self.samples, self.labels)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        for a in self.model.arch_parameters():
+            a.grad = None
+        self.last_loss = loss.detach()
+
+
+def kernel_table(stats):
+    rows = {}
+    for name, r in stats.items():
+        if r["launches"] == 0 or r["ms"] <= 0:
+            continue
+        sec = r["ms"] / 1e3
+        if name in MFMA_BOUND:
+            ach, peak, unit, bound = r["flops"] / sec / 1e12, MFMA_F32_PEAK_TFS, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = r["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        rows[name] = {"bound": bound, "launches": r["launches"], "ms_total": round(r["ms"], 4),
+                      "us_per_launch": round(r["ms"] * 1e3 / r["launches"], 2), "achieved": round(ach, 2),
+                      "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+    return rows
+
+
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota
+    (the GPU boxes show 256 CPUs but grant a 16-CPU share)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(args, state, alphas):
+    """The CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores
+    on a bounded sample: one supernet step on a `--cpu-sample`-triple sampled step graph."""
+    from mr_gnas_amd import graph as G, synth
+    from oracle import nets as ON
+    from oracle.graph import OGraph
+    ds = args.workload.split("_")[0]
+    N, R, T = synth.SHAPES[ds]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    tri = synth.synth_kg(N, R, T, args.seed)
+    node_id, gtri, samples, labels = synth.sample_step_graph(tri, args.cpu_sample, 0.5, args.negative, args.seed + 1)
+    g = G.build_search_graph(len(node_id), R, gtri)
+    src, dst, _ = g.edges(form="all")
+    og = OGraph(len(node_id), src, dst, g.edata["e_type"], g.edata["norm"])
+    S = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    al = [a.detach().cpu().clone().requires_grad_(True) for a in alphas]
+    nid, st, lt = torch.from_numpy(node_id), torch.from_numpy(samples), torch.from_numpy(labels)
+
+    def step():
+        ent, rel = ON.supernet_forward(og, S, al, nid, src, g.edata["e_type"], 2 * R + 1, 2)
+        loss = ON.distmult_bce(ent, rel, st, lt)
+        loss.backward()
+        for v in list(S.values()) + al:
+            v.grad = None
+
+    t0 = time.perf_counter()
+    step()                                   # warm-up (also bounds the cost: skip the timed step if it is slow)
+    warm = time.perf_counter() - t0
+    if warm < 60:
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+    else:
+        dt = warm
+    E = og.E
+    return {"value": round(E / dt / 1e6, 6), "unit": "M edges/s", "cores": cores, "kind": "port",
+            "sample": f"1 supernet fwd+bwd step, sampled step graph graph_batch_size={args.cpu_sample} "
+                      f"(E={E}, n={og.n}), D={args.dim}, torch {torch.__version__} CPU, {dt:.2f} s/step",
+            "seconds_per_step": round(dt, 3)}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from mr_gnas_amd import _lib
+    _lib.load()
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from mr_gnas_amd import dist as MD
+        step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), rank, world)
+        barrier = dist.barrier
+    else:
+        step = Step(args, device, build_step_inputs(args.workload, args.negative, args.seed))
+        barrier = lambda: None
+
+    log(f"inputs resident: E={getattr(step, 'E_global', step.E)} world={world}")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done, loss {float(step.last_loss):.5f}, "
+            f"HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+    # one instrumented step: every libmrgnas entry point bracketed by events -> decomposition table
+    _lib.meter.start()
+    step()
+    table = kernel_table(_lib.meter.stop())
+    dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides --------------------
+    if dominant:
+        _lib.meter.start([dominant])
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    dom_stats = kernel_table(_lib.meter.stop()) if dominant else {}
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    E_total = step.E_global if hasattr(step, "E_global") else step.E
+    ms_per_step = dt / args.steps * 1e3
+    value = E_total / (dt / args.steps) / 1e6
+
+    out = {
+        "metric": "million edges/sec per supernet fwd+bwd step (FB15k-237, dim=200)",
+        "value": round(value, 4), "unit": "M edges/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "edges": int(E_total), "nodes": int(step.g.number_of_nodes()),
+                   "feature_dim": args.dim, "layers": 2, "scoring_triples": int(step.samples.shape[0]),
+                   "step": "supernet fwd + DistMult BCE + bwd + clip_grad_norm + SGD(momentum)",
+                   "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL"},
+        "loss": float(step.last_loss) if step.last_loss is not None else None,
+    }
+    if dominant and dominant in dom_stats:
+        d = dom_stats[dominant]
+        out["roofline"] = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                           "unit": d["unit"], "frac": d["frac"], "traffic": None, "launches": d["launches"],
+                           "us_per_launch": d["us_per_launch"],
+                           "share_of_step": round(d["ms_total"] / (ms_per_step * args.steps), 4)}
+    out["kernels"] = table
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        state = step.model.state_dict()
+        log("timing the CPU oracle on the bounded sample")
+        out["cpu_baseline"] = cpu_baseline(args, state, step.model.arch_parameters())
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,54 @@ def load():
     return lib
 
 
+class KernelMeter:
+    """Optional per-entry-point timing with HIP events on the launch stream.
+
+    ``meter.start(names)`` brackets every call of the named C-ABI functions with a
+    pair of events recorded on torch's current stream (the stream the kernels are
+    enqueued on); ``meter.stop()`` synchronises and returns, per name, the number
+    of launches, the summed device time and the summed algorithmic bytes / flops
+    the call sites declared.  Used by bench.py for the roofline figures."""
+
+    def __init__(self):
+        self.names = None
+        self.records = {}
+
+    def start(self, names=None):
+        self.names = set(names) if names is not None else True
+        self.records = {}
+
+    def active(self, name):
+        return self.names is not None and (self.names is True or name in self.names)
+
+    def stop(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+            out[name] = {"launches": len(recs), "ms": ms, "bytes": sum(r[2] for r in recs), "flops": sum(r[3] for r in recs)}
+        self.names, self.records = None, {}
+        return out
+
+
+meter = KernelMeter()
+
+
+def call(name, args, nbytes=0, flops=0):
+    """Invoke C-ABI function `name`; raise on a non-zero return code."""
+    fn = getattr(load(), name)
+    if meter.active(name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        code = fn(*args)
+        b.record()
+        meter.records.setdefault(name, []).append((a, b, nbytes, flops))
+    else:
+        code = fn(*args)
+    if code != 0:
+        check(code, name)
+
+
 def check(code, what=""):
     if code != 0:
         msg = load().mrg_error_string(code).decode()

@@ -2,12 +2,14 @@
 
 Each Function enqueues HIP kernels of libmrgnas_hip.so on torch's current
 stream through ctypes; tensors are only used for memory and stream plumbing.
-Inputs are never modified; outputs are fresh tensors.
+Inputs are never modified; outputs are fresh tensors.  Every call site states
+the algorithmic bytes / flops of the launch so bench.py can
+price the kernels against the roofline.
 """
 import torch
 
 from . import _lib
-from ._lib import check, f32c, ptr, require_hip, stream_of
+from ._lib import call, f32c, ptr, require_hip, stream_of
 
 COMPOSE = {"mult": 0, "sub": 1, "add": 2}
 REDUCE = {"sum": 0, "mean": 1, "max": 2}
@@ -22,6 +24,10 @@ def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+def _ws_bytes(name, *args):
+    return getattr(_lib.load(), name)(*args)
+
+
 # ---------------------------------------------------------------------------
 # a1: compose
 # ---------------------------------------------------------------------------
@@ -34,7 +40,7 @@ class _Compose(torch.autograd.Function):
         require_hip(s, hr)
         out = torch.empty_like(s)
         rows, D = s.shape
-        check(_lib.load().mrg_compose_fwd(op, ptr(s), ptr(hr), ptr(out), rows, D, stream_of(s)), "mrg_compose_fwd")
+        call("mrg_compose_fwd", (op, ptr(s), ptr(hr), ptr(out), rows, D, stream_of(s)), nbytes=12 * D * rows)
         ctx.op = op
         ctx.save_for_backward(*((s, hr) if op == 0 else ()))
         return out
@@ -47,8 +53,8 @@ class _Compose(torch.autograd.Function):
         gs = torch.empty_like(g) if need_s else None
         ghr = torch.empty_like(g) if need_hr else None
         rows, D = g.shape
-        check(_lib.load().mrg_compose_bwd(ctx.op, ptr(g), ptr(s), ptr(hr), ptr(gs), ptr(ghr), rows, D, stream_of(g)),
-              "mrg_compose_bwd")
+        nb = 4 * D * rows * (1 + (2 if ctx.op == 0 else 1) * (int(need_s) + int(need_hr)))
+        call("mrg_compose_bwd", (ctx.op, ptr(g), ptr(s), ptr(hr), ptr(gs), ptr(ghr), rows, D, stream_of(g)), nbytes=nb)
         return None, gs, ghr
 
 
@@ -65,8 +71,9 @@ def gather_rows(table, idx32, rel_table=None, rel_idx32=None, kind=None):
     rows, D = idx32.numel(), table.shape[1]
     out = torch.empty(rows, D, dtype=torch.float32, device=table.device)
     op = -1 if kind is None else COMPOSE[kind]
-    check(_lib.load().mrg_gather_compose_fwd(op, ptr(table), ptr(rel_table), ptr(idx32), ptr(rel_idx32), ptr(out),
-                                             rows, D, stream_of(table)), "mrg_gather_compose_fwd")
+    nb = rows * (4 * D * (2 if kind is None else 3) + (4 if kind is None else 8))
+    call("mrg_gather_compose_fwd", (op, ptr(table), ptr(rel_table), ptr(idx32), ptr(rel_idx32), ptr(out), rows, D,
+                                    stream_of(table)), nbytes=nb)
     return out
 
 
@@ -74,33 +81,31 @@ def gather_rows(table, idx32, rel_table=None, rel_idx32=None, kind=None):
 # a2 / a3: collapsed scalar gates
 # ---------------------------------------------------------------------------
 class _Gate(torch.autograd.Function):
-    """segments: list of (W, b, a) per row segment (None for absent segments);
-    flat parameter list follows: W0, b0, a0, W1, b1, a1, W2, b2, a2 (None allowed)."""
+    """Parameters come flat, three per row segment (in, out, self): W, b, a -- None for
+    an absent segment."""
 
     @staticmethod
     def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
-        lib = _lib.load()
         s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
         params = tuple(f32c(p) for p in params)
         require_hip(s, s_in, norm, *params)
         M, D = s.shape
         st = stream_of(s)
-        ld = gate_ld(D)
         in_dim = 2 * D if s_in is not None else D
-        uvc = torch.zeros(3, ld, dtype=torch.float32, device=s.device)
+        uvc = torch.zeros(3, gate_ld(D), dtype=torch.float32, device=s.device)
         for seg in range(3):
             W, b, a = params[3 * seg: 3 * seg + 3]
             if W is not None:
-                check(lib.mrg_gate_collapse(ptr(W), ptr(b), ptr(a), ptr(uvc[seg]), D, in_dim, st), "mrg_gate_collapse")
+                call("mrg_gate_collapse", (ptr(W), ptr(b), ptr(a), ptr(uvc[seg]), D, in_dim, st), nbytes=4 * D * in_dim)
         out = torch.empty_like(s)
-        check(lib.mrg_gate_fwd(ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(out), b0, b1, M, D, scale, st), "mrg_gate_fwd")
+        nb = 4 * D * M * (3 if s_in is not None else 2) + (4 * b1 if norm is not None else 0)
+        call("mrg_gate_fwd", (ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(out), b0, b1, M, D, scale, st), nbytes=nb)
         ctx.save_for_backward(s, s_in, norm, uvc, *params)
         ctx.cfg = (b0, b1, scale, in_dim)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         s, s_in, norm, uvc, *params = ctx.saved_tensors
         b0, b1, scale, in_dim = ctx.cfg
         g = f32c(g)
@@ -109,9 +114,10 @@ class _Gate(torch.autograd.Function):
         gs = torch.empty_like(s)
         gs_in = torch.empty_like(s) if s_in is not None else None
         d_uvc = torch.empty(3, gate_ld(D), dtype=torch.float32, device=s.device)
-        ws = _ws(lib.mrg_gate_bwd_workspace_bytes(M, D), s)
-        check(lib.mrg_gate_bwd(ptr(g), ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(gs), ptr(gs_in), ptr(d_uvc), ptr(ws),
-                               b0, b1, M, D, scale, st), "mrg_gate_bwd")
+        ws = _ws(_ws_bytes("mrg_gate_bwd_workspace_bytes", M, D), s)
+        nb = 4 * D * M * (5 if s_in is not None else 3) + (4 * b1 if norm is not None else 0)
+        call("mrg_gate_bwd", (ptr(g), ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(gs), ptr(gs_in), ptr(d_uvc), ptr(ws),
+                              b0, b1, M, D, scale, st), nbytes=nb)
         gparams = []
         for seg in range(3):
             W, b, a = params[3 * seg: 3 * seg + 3]
@@ -120,8 +126,8 @@ class _Gate(torch.autograd.Function):
                 continue
             gW, ga = torch.empty_like(W), torch.empty_like(a)
             gb = torch.empty_like(b) if b is not None else None
-            check(lib.mrg_gate_param_grad(ptr(W), ptr(b), ptr(a), ptr(d_uvc[seg]), ptr(gW), ptr(gb), ptr(ga), D, in_dim, st),
-                  "mrg_gate_param_grad")
+            call("mrg_gate_param_grad", (ptr(W), ptr(b), ptr(a), ptr(d_uvc[seg]), ptr(gW), ptr(gb), ptr(ga), D, in_dim, st),
+                 nbytes=8 * D * in_dim)
             gparams += [gW, gb, ga]
         return (gs, gs_in, None, None, None, None, *gparams)
 
@@ -139,38 +145,46 @@ def gate_last(s, W, b, a):
 # ---------------------------------------------------------------------------
 # a4 / a5 / a6: destination-segmented reducers
 # ---------------------------------------------------------------------------
+def _seg_fwd(mode, msg, self_rows, p, N, D, want_arg=True):
+    """Launch mrg_seg_reduce_fwd over plan p (graph.dst_csr_plan); returns (out, arg)."""
+    out = torch.empty(N, D, dtype=torch.float32, device=msg.device)
+    arg = torch.empty(N, D, dtype=torch.int32, device=msg.device) if mode == 2 else None
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", p["n_slots"], D), msg) if p["n_slots"] > 0 else None
+    E = int(p["eid"].numel())
+    nb = 4 * D * E + 4 * E + 4 * D * N * (1 + (self_rows is not None) + (mode == 2))
+    call("mrg_seg_reduce_fwd", (mode, ptr(msg), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
+                                ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"], ptr(p["hub_node"]),
+                                ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"], p["n_slots"], ptr(p["in_degree"]),
+                                ptr(out), ptr(arg), ptr(ws), N, D, stream_of(msg)), nbytes=nb)
+    return out, arg
+
+
+def _seg_bwd(mode, g, graph, arg, gmsg, gself):
+    p = graph.plan()
+    E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
+    nb = 4 * D * E + 4 * E + 4 * D * N * (1 + (gself is not None) + (mode == 2))
+    call("mrg_seg_reduce_bwd", (mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), ptr(gself),
+                                E, N, D, stream_of(g)), nbytes=nb)
+
+
 class _SegReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, msg, self_rows, graph):
-        lib = _lib.load()
         msg, self_rows = f32c(msg), f32c(self_rows)
         require_hip(msg, self_rows)
-        p = graph.plan()
-        N, D = graph.number_of_nodes(), msg.shape[1]
         if msg.shape[0] != graph.num_edges():
             raise _lib.MrgnasError(f"message rows {msg.shape[0]} != number of edges {graph.num_edges()}")
-        out = torch.empty(N, D, dtype=torch.float32, device=msg.device)
-        arg = torch.empty(N, D, dtype=torch.int32, device=msg.device) if mode == 2 else None
-        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), msg) if p["n_slots"] > 0 else None
-        check(lib.mrg_seg_reduce_fwd(mode, ptr(msg), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]),
-                                     ptr(p["chunk_start"]), ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"],
-                                     ptr(p["hub_node"]), ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"],
-                                     p["n_slots"], ptr(p["in_degree"]), ptr(out), ptr(arg), ptr(ws), N, D,
-                                     stream_of(msg)), "mrg_seg_reduce_fwd")
+        out, arg = _seg_fwd(mode, msg, self_rows, graph.plan(), graph.number_of_nodes(), msg.shape[1])
         ctx.mode, ctx.graph, ctx.has_self = mode, graph, self_rows is not None
         ctx.save_for_backward(*((arg,) if arg is not None else ()))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         g = f32c(g)
-        graph, p = ctx.graph, ctx.graph.plan()
         arg = ctx.saved_tensors[0] if ctx.mode == 2 else None
-        E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
-        gmsg = torch.empty(E, D, dtype=torch.float32, device=g.device)
-        check(lib.mrg_seg_reduce_bwd(ctx.mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), None,
-                                     E, N, D, stream_of(g)), "mrg_seg_reduce_bwd")
+        gmsg = torch.empty(ctx.graph.num_edges(), g.shape[1], dtype=torch.float32, device=g.device)
+        _seg_bwd(ctx.mode, g, ctx.graph, arg, gmsg, None)
         return None, gmsg, (g if ctx.has_self else None), None
 
 
@@ -185,38 +199,26 @@ class _AggRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mode, x, graph, add_self):
-        lib = _lib.load()
         x = f32c(x)
         require_hip(x)
-        p = graph.plan()
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         if x.shape[0] != E + N:
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
-        out = torch.empty(N, D, dtype=torch.float32, device=x.device)
-        arg = torch.empty(N, D, dtype=torch.int32, device=x.device) if mode == 2 else None
-        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), x) if p["n_slots"] > 0 else None
-        self_rows = x[E:] if add_self else None
-        check(lib.mrg_seg_reduce_fwd(mode, ptr(x), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]),
-                                     ptr(p["chunk_start"]), ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"],
-                                     ptr(p["hub_node"]), ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"],
-                                     p["n_slots"], ptr(p["in_degree"]), ptr(out), ptr(arg), ptr(ws), N, D,
-                                     stream_of(x)), "mrg_seg_reduce_fwd")
+        out, arg = _seg_fwd(mode, x, x[E:] if add_self else None, graph.plan(), N, D)
         ctx.mode, ctx.graph, ctx.add_self = mode, graph, add_self
         ctx.save_for_backward(*((arg,) if arg is not None else ()))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         g = f32c(g)
-        graph, p = ctx.graph, ctx.graph.plan()
+        graph = ctx.graph
         arg = ctx.saved_tensors[0] if ctx.mode == 2 else None
         E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
         gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
         if not ctx.add_self:
             gx[E:].zero_()
-        check(lib.mrg_seg_reduce_bwd(ctx.mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gx),
-                                     ptr(gx[E:]) if ctx.add_self else None, E, N, D, stream_of(g)), "mrg_seg_reduce_bwd")
+        _seg_bwd(ctx.mode, g, graph, arg, gx, gx[E:] if ctx.add_self else None)
         return None, gx, None, None
 
 
@@ -230,7 +232,6 @@ def aggregate_rows(kind, x, graph, add_self=True):
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act):
-        lib = _lib.load()
         x, W, b = f32c(x), f32c(W), f32c(b)
         require_hip(x, W, b)
         rows, K = x.shape
@@ -238,14 +239,14 @@ class _Linear(torch.autograd.Function):
         if W.shape[1] != K:
             raise _lib.MrgnasError(f"linear: weight {tuple(W.shape)} does not match input width {K}")
         y = torch.empty(rows, Nout, dtype=torch.float32, device=x.device)
-        check(lib.mrg_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), rows, K, Nout, act, stream_of(x)), "mrg_linear_fwd")
+        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), rows, K, Nout, act, stream_of(x)),
+             nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
         ctx.act, ctx.has_b = act, b is not None
         ctx.save_for_backward(x, W, y if act == 1 else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         x, W, y = ctx.saved_tensors
         g = f32c(g)
         if ctx.act == 1:
@@ -254,15 +255,15 @@ class _Linear(torch.autograd.Function):
         Nout = W.shape[0]
         st = stream_of(x)
         gx = gW = gb = None
+        work = dict(nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            check(lib.mrg_linear_bwd_input(ptr(g), ptr(W), ptr(gx), rows, K, Nout, st), "mrg_linear_bwd_input")
+            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), rows, K, Nout, st), **work)
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             gW = torch.empty_like(W)
             gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-            ws = _ws(lib.mrg_linear_bwd_weight_workspace_bytes(rows, K, Nout), x)
-            check(lib.mrg_linear_bwd_weight(ptr(g), ptr(x), ptr(gW), ptr(gb), ptr(ws), rows, K, Nout, st),
-                  "mrg_linear_bwd_weight")
+            ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K, Nout), x)
+            call("mrg_linear_bwd_weight", (ptr(g), ptr(x), ptr(gW), ptr(gb), ptr(ws), rows, K, Nout, st), **work)
         return gx, gW, gb, None
 
 
@@ -294,16 +295,8 @@ class _Gather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         g = f32c(g)
-        p, N, D = ctx.gp.plan, ctx.gp.rows, g.shape[1]
-        out = torch.empty(N, D, dtype=torch.float32, device=g.device)
-        ws = _ws(lib.mrg_seg_reduce_workspace_bytes(p["n_slots"], D), g) if p["n_slots"] > 0 else None
-        check(lib.mrg_seg_reduce_fwd(0, ptr(g), None, ptr(p["eid"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
-                                     ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"], ptr(p["hub_node"]),
-                                     ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"], p["n_slots"],
-                                     ptr(p["in_degree"]), ptr(out), None, ptr(ws), N, D, stream_of(g)),
-              "mrg_seg_reduce_fwd(gather backward)")
+        out, _ = _seg_fwd(0, g, None, ctx.gp.plan, ctx.gp.rows, g.shape[1])
         return out, None
 
 
