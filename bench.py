@@ -193,9 +193,13 @@ def main():
     from mr_gnas_amd import _lib
     _lib.load()
 
-    if world > 1:
+    sharded = world > 1 or os.environ.get("MRG_FORCE_SHARDED") == "1"     # the env switch rehearses the N>1 code on one GPU
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29671")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         from mr_gnas_amd import dist as MD
         step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), rank, world)
         barrier = dist.barrier
@@ -229,7 +233,7 @@ def main():
     dt = time.perf_counter() - t0
     dom_stats = kernel_table(_lib.meter.stop()) if dominant else {}
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -263,7 +267,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, state, step.model.arch_parameters())
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

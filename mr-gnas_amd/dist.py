@@ -1,0 +1,346 @@
+"""Relation-block sharding of one supernet step over the GPUs of a node (RCCL over xGMI).
+
+One process per GPU (``torch.distributed``, backend "nccl" == RCCL on ROCm; the CPU
+tests run the same code over "gloo").  Everything row-shaped is partitioned, nothing
+edge- or node-shaped is replicated:
+
+* directed edges, sorted by (relation, dst), are cut into P contiguous *relation
+  blocks* balanced by edge count; a cut is snapped to a (relation, dst) group
+  boundary so one destination's edges of one relation stay together, and a relation
+  bigger than E/P is split by dst range (WN18RR: 2 of 11 relations hold ~3/4 of the
+  edges).  Relation ids < R are original-direction edges, so a contiguous slice of
+  the relation-sorted list is still [in-edges | out-edges]: the shard only carries
+  its local split (b0, b1) instead of a per-edge direction flag;
+* node rows (self-loop rows, the [N, D] stage of the cell, the scoring triples) are
+  cut into P contiguous ranges;
+* tables ([N_all, D] entities, [R', D] relations), parameters and alphas are
+  replicated.
+
+Exchange steps (the only collectives):
+  1. per aggregator: all-reduce (sum | max) of the per-node partial accumulators
+     [N, D] built from local edges; each rank keeps its own node rows;
+  2. per BatchNorm: all-reduce of [2, D] (sum x, sum x^2) forward and of
+     (sum g, sum g*xhat) backward -- BN normalises over all M rows
+     (reference models/cell_lp.py:21), so shards must share statistics;
+  3. per layer: all-gather of the [N, D] node embeddings (next layer's gather and
+     the scorer read rows of other ranks);
+  4. per step: one flat all-reduce (sum) of all parameter / alpha gradients.
+Every collective is an autograd Function whose backward is its adjoint collective,
+so ``loss.backward()`` on each rank yields exact partial gradients.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import functional as K
+from . import operations_lp as OPS
+from .graph import RelGraph
+
+
+# ---------------------------------------------------------------------------
+# partitioning
+# ---------------------------------------------------------------------------
+def relation_block_cuts(etype_sorted, dst_sorted, parts):
+    """Cut positions (len parts+1) into a (relation, dst)-sorted edge list: the k-th cut is
+    the (relation, dst) group boundary nearest to k*E/parts."""
+    E = len(etype_sorted)
+    if E == 0:
+        return [0] * (parts + 1)
+    key = etype_sorted.astype(np.int64) * (int(dst_sorted.max()) + 1) + dst_sorted
+    bounds = np.concatenate(([0], np.nonzero(np.diff(key))[0] + 1, [E]))     # group starts + E
+    cuts = [0]
+    for k in range(1, parts):
+        ideal = k * E / parts
+        j = int(np.argmin(np.abs(bounds - ideal)))
+        cuts.append(max(int(bounds[j]), cuts[-1]))
+    cuts.append(E)
+    return cuts
+
+
+def node_ranges(n, parts):
+    base, extra = divmod(n, parts)
+    lo = [r * base + min(r, extra) for r in range(parts + 1)]
+    return lo
+
+
+class EdgeShard(RelGraph):
+    """Rank-local view of a step graph: a relation block of edges + a node range."""
+
+    def __init__(self, n, src, dst, etype, norm, num_rels, rank, world, device):
+        src, dst, etype = (np.asarray(t.cpu() if torch.is_tensor(t) else t).astype(np.int64) for t in (src, dst, etype))
+        norm = np.asarray(norm.cpu() if torch.is_tensor(norm) else norm, dtype=np.float32).reshape(-1)
+        order = np.lexsort((np.arange(len(src)), dst, etype))          # (relation, dst, caller id)
+        cuts = relation_block_cuts(etype[order], dst[order], world)
+        mine = order[cuts[rank]:cuts[rank + 1]]
+        super().__init__(n, src[mine], dst[mine], etype[mine], norm[mine], device=device)
+        self.rank, self.world = rank, world
+        self.global_edge_ids = torch.from_numpy(mine).to(device)       # caller-order ids of the local rows
+        self.E_global = len(src)
+        self._b0 = int((etype[mine] < num_rels).sum())
+        lo = node_ranges(n, world)
+        self.node_lo, self.node_hi = lo[rank], lo[rank + 1]
+        self.node_cuts = lo
+        self.global_in_degree = torch.from_numpy(np.bincount(dst, minlength=n)).to(device)
+        self.cuts = cuts
+
+    def bounds(self):
+        return self._b0, self.num_edges()
+
+    @property
+    def n_own(self):
+        return self.node_hi - self.node_lo
+
+
+# ---------------------------------------------------------------------------
+# collectives with adjoint backward
+# ---------------------------------------------------------------------------
+class _AllReduceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+class _AllReduceMax(torch.autograd.Function):
+    """y = elementwise max over ranks; the gradient returns to the ranks that attain it
+    (ties only occur at 0 after ReLU, where the ReLU mask removes the gradient anyway)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.MAX, group=group)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g * (x == y), None
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[n_own, D] per rank -> [N, D] everywhere (ranges from node_cuts); backward = the
+    sum over ranks of the gradient rows this rank owns."""
+
+    @staticmethod
+    def forward(ctx, x, cuts, rank, group):
+        world = len(cuts) - 1
+        width = max(cuts[r + 1] - cuts[r] for r in range(world))
+        pad = torch.zeros(width, x.shape[1], dtype=x.dtype, device=x.device)
+        pad[: x.shape[0]] = x
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        ctx.cuts, ctx.rank, ctx.group = cuts, rank, group
+        return torch.cat([parts[r][: cuts[r + 1] - cuts[r]] for r in range(world)], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g[ctx.cuts[ctx.rank]: ctx.cuts[ctx.rank + 1]], None, None, None
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """Training-mode BatchNorm1d over rows that are spread over the ranks."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, total_rows, eps, group):
+        stats = torch.stack((x.sum(0), (x * x).sum(0)))
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        mean = stats[0] / total_rows
+        var = (stats[1] / total_rows - mean * mean).clamp_(min=0)
+        invstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * invstd
+        ctx.save_for_backward(xhat, weight, invstd)
+        ctx.total, ctx.group = total_rows, group
+        ctx.mark_non_differentiable(mean, var)
+        return xhat * weight + bias, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        xhat, weight, invstd = ctx.saved_tensors
+        gw_local, gb_local = (g * xhat).sum(0), g.sum(0)
+        red = torch.stack((gw_local, gb_local))
+        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=ctx.group)
+        gx = (g - red[1] / ctx.total - xhat * (red[0] / ctx.total)) * (weight * invstd)
+        return gx, gw_local, gb_local, None, None, None
+
+
+def sync_batch_norm(x, bn, total_rows, group):
+    """F.batch_norm(training=True) semantics of module `bn` (nn.BatchNorm1d) over rows that are
+    partitioned across `group`; updates bn.running_* like torch does (unbiased variance)."""
+    y, mean, var = _SyncBatchNorm.apply(x, bn.weight, bn.bias, total_rows, bn.eps, group)
+    if bn.training and bn.track_running_stats:
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.1
+            unbiased = var * (total_rows / max(total_rows - 1, 1))
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(unbiased, alpha=m)
+            bn.num_batches_tracked += 1
+    return y
+
+
+# ---------------------------------------------------------------------------
+# the sharded supernet step
+# ---------------------------------------------------------------------------
+class ShardedSupernet:
+    """Forward of supernet.SearchNetwork on one relation block (same parameters, same
+    arithmetic, rows partitioned).  `kernels` is the namespace providing gather / seg_reduce /
+    linear / GatherPlan -- the HIP `functional` module in the product; the CPU tests pass an
+    oracle-backed stand-in to exercise the collectives over gloo."""
+
+    def __init__(self, model, shard, node_id, group=None, kernels=K):
+        self.m, self.s, self.group, self.k = model, shard, group, kernels
+        s, dev = shard, shard.device
+        src, _, _ = s.edges(form="all")
+        own = torch.arange(s.node_lo, s.node_hi, device=dev)
+        node_id = node_id.view(-1).long().to(dev)
+        self.rows_total = s.E_global + s.number_of_nodes()            # M of the whole step graph
+        self.p_ent0 = kernels.GatherPlan(node_id[torch.cat((src, own))], model._num_ent)
+        self.p_ent = kernels.GatherPlan(torch.cat((src, own)), s.number_of_nodes())
+        rel_idx = torch.cat((s.edata["e_type"], torch.full((s.n_own,), model._num_rel - 1, dtype=torch.long, device=dev)))
+        self.p_rel = kernels.GatherPlan(rel_idx, model._num_rel)
+
+    # -- pieces ---------------------------------------------------------------------------
+    def _mixed(self, mixed_op, w, h, h_in, total_rows):
+        out = 0
+        for wk, (op, bn, act) in zip(w, mixed_op._ops):
+            out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
+        return out
+
+    def _aggregate(self, op, name, x):
+        """a_max / a_sum / a_mean on a shard: local partial over local edges -> all-reduce ->
+        own node rows (+ residual self rows)  (reference models/operations_lp.py:223-264)."""
+        s, E = self.s, self.s.num_edges()
+        if name == "a_sum":
+            part = self.k.seg_reduce("sum", x[:E], None, s)
+            h = _AllReduceSum.apply(part, self.group)[s.node_lo:s.node_hi]
+            h = op.drop_sum(h)
+        else:
+            m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
+            if name == "a_max":
+                h = _AllReduceMax.apply(self.k.seg_reduce("max", m, None, s), self.group)[s.node_lo:s.node_hi]
+            else:
+                h = _AllReduceSum.apply(self.k.seg_reduce("sum", m, None, s), self.group)[s.node_lo:s.node_hi]
+                h = h / s.global_in_degree[s.node_lo:s.node_hi].clamp(min=1).to(h.dtype).view(-1, 1)
+        return h + x[E:]
+
+    def _mixed_middle(self, mixed_op, w, h, total_nodes):
+        out = 0
+        for wk, name, (op, bn, act) in zip(w, OPS.MIDDLE_OPS, mixed_op._ops):
+            out = out + wk * act(sync_batch_norm(self._aggregate(op, name, h), bn, total_nodes, self.group))
+        return out
+
+    def _cell(self, cell, x, hr, wz, wf, wm, wl):
+        M, N = self.rows_total, self.s.number_of_nodes()
+        h_in = self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M)
+        states, off = [h_in], 0
+        for _ in range(cell.n_first):
+            sN = sum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
+            off += len(states)
+            states.append(sN)
+        states = [self._mixed_middle(cell.cell_middle._ops[i], wm[i], states[1 + i], N) for i in range(cell.n_first)]
+        off = 0
+        for _ in range(cell.n_last):
+            sN = sum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
+            off += len(states)
+            states.append(sN)
+        return cell.concat_weights(torch.cat(states, dim=1))
+
+    # -- the step ---------------------------------------------------------------------------
+    def forward(self):
+        """Returns (ent [N, D] gathered on every rank, rel [R', D])."""
+        m, s = self.m, self.s
+        ent_all = m.linear_e(m.embedding_h.weight)
+        rel = torch.mm(m.rel_wt, m.embedding_e.weight)
+        N = s.number_of_nodes()
+        ent = None
+        for l, cell in enumerate(m.cells):
+            wz, wf, wm, wl = m.layer_weights(l)
+            x = self.k.gather(ent_all, self.p_ent0) if l == 0 else self.k.gather(ent, self.p_ent)
+            own = sync_batch_norm(self._cell(cell, x, self.k.gather(rel, self.p_rel), wz, wf, wm, wl), m.batchnorm_h, N, self.group)
+            if l > 0 or m._layers == 1:
+                own = F.relu(own)
+            own = F.dropout(own, m._dropout, training=m.training)
+            ent = _AllGatherRows.apply(own, s.node_cuts, s.rank, self.group)
+            rel = torch.matmul(rel, m.w_rel)
+        return ent, rel
+
+    def loss(self, ent, rel, samples_local, labels_local, total_samples):
+        """This rank's share of the mean BCE (reference models/model_search_lp.py:181-188):
+        the ranks' values add up to the reference loss."""
+        key = (samples_local.data_ptr(), tuple(samples_local.shape), samples_local._version)
+        if getattr(self, "_score_key", None) != key:
+            t = samples_local.long()
+            self._score_plans = (self.k.GatherPlan(t[:, 0].contiguous(), ent.shape[0]),
+                                 self.k.GatherPlan(t[:, 1].contiguous(), rel.shape[0]),
+                                 self.k.GatherPlan(t[:, 2].contiguous(), ent.shape[0]))
+            self._score_key = key
+        ps, pr, po = self._score_plans
+        score = torch.sum(self.k.gather(ent, ps) * self.k.gather(rel, pr) * self.k.gather(ent, po), dim=1)
+        return F.binary_cross_entropy_with_logits(score, labels_local, reduction="sum") / total_samples
+
+
+def all_reduce_gradients(tensors, group=None):
+    """One flat all-reduce (sum) over the gradients of `tensors` (parameters and alphas);
+    tensors that received no gradient on this rank contribute zeros."""
+    tensors = [t for t in tensors if t.requires_grad]
+    flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.grad = flat[off:off + n].view_as(t).clone()
+        off += n
+
+
+class ShardedStep:
+    """bench.py's step on N GPUs: same graph, same model, same optimiser as the single-GPU
+    Step; edges in relation blocks, one process per GPU."""
+
+    def __init__(self, args, device, inputs, rank, world, group=None):
+        from . import graph as G, supernet as S
+        N, R, node_id, gtri, samples, labels = inputs
+        torch.manual_seed(args.seed)                      # identical parameters on every rank
+        g = G.build_search_graph(len(node_id), R, gtri)
+        src, dst, _ = g.edges(form="all")
+        self.g = EdgeShard(len(node_id), src, dst, g.edata["e_type"], g.edata["norm"], R, rank, world, device)
+        self.E, self.E_global = self.g.num_edges(), self.g.E_global
+        self.model = S.SearchNetwork(device, N, R, 2, 1, 2, 2, args.dim, 100, 2 * R + 1, 40.0, 0.3, 0.1).to(device)
+        S.xavier_init_(self.model)
+        self.model.train()
+        self.net = ShardedSupernet(self.model, self.g, torch.from_numpy(node_id), group)
+        lo = node_ranges(len(samples), world)
+        self.samples = torch.from_numpy(samples[lo[rank]:lo[rank + 1]]).to(device)
+        self.labels = torch.from_numpy(labels[lo[rank]:lo[rank + 1]]).to(device)
+        self.total_samples = len(samples)
+        self.opt = torch.optim.SGD(self.model.parameters(), 1e-3, momentum=0.9, weight_decay=0.0)
+        self.clip, self.group, self.last_loss = 5.0, group, None
+        torch.manual_seed(args.seed + 1000 + rank)         # dropout masks differ per rank (disjoint rows)
+
+    def __call__(self):
+        ent, rel = self.net.forward()
+        loss = self.net.loss(ent, rel, self.samples, self.labels, self.total_samples)
+        loss.backward()
+        params = list(self.model.parameters())
+        all_reduce_gradients(params + self.model.arch_parameters()[:4], self.group)
+        torch.nn.utils.clip_grad_norm_(params, self.clip)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        for a in self.model.arch_parameters():
+            a.grad = None
+        total = loss.detach().clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        self.last_loss = total

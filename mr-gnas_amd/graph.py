@@ -147,6 +147,13 @@ class RelGraph:
             self._i32[name] = t.to(torch.int32).contiguous()
         return self._i32[name]
 
+    def bounds(self):
+        """(b0, b1): rows [0, b0) are original-direction edges, [b0, b1) inverse edges.
+        The reference's convention is (E/2, E) (models/operations_lp.py:318,323,327);
+        relation-block shards override it with their local split."""
+        E = self.num_edges()
+        return E // 2, E
+
     def norm_flat(self):
         """edata['norm'] as a contiguous float32 [E] (the reference stores [E] or [E,1])."""
         n = self.edata["norm"]

@@ -29,6 +29,8 @@ SF_OPS = ['sf_TransE', 'sf_DisMult']
 
 
 def _bounds(g):
+    if hasattr(g, "bounds"):
+        return g.bounds()
     E = g.num_edges()
     return E // 2, E
 

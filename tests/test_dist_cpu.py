@@ -1,0 +1,89 @@
+"""world_size-2 (and 3) gloo tests of the relation-block sharded supernet step: partitioning,
+collectives with adjoint backward, SyncBatchNorm and the flat gradient all-reduce must
+reproduce the single-process result of the reference (golden vectors)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, sub
+from mr_gnas_amd import dist as MD
+
+
+def test_relation_block_cuts_balanced_and_group_aligned():
+    rng = np.random.default_rng(0)
+    E, R, N = 20000, 11, 500
+    w = np.array([0.4, 0.35] + [0.25 / 9] * 9)              # two relations hold 3/4 of the edges (WN18RR-like)
+    et = np.sort(rng.choice(R, size=E, p=w))
+    dst = rng.integers(0, N, size=E)
+    order = np.lexsort((dst, et))
+    et, dst = et[order], dst[order]
+    for parts in (2, 4, 8):
+        cuts = MD.relation_block_cuts(et, dst, parts)
+        assert cuts[0] == 0 and cuts[-1] == E and all(b >= a for a, b in zip(cuts, cuts[1:]))
+        sizes = np.diff(cuts)
+        assert sizes.max() <= 1.15 * E / parts, (parts, sizes)
+        for c in cuts[1:-1]:                                   # never inside a (relation, dst) group
+            assert (et[c - 1], dst[c - 1]) != (et[c], dst[c])
+    assert MD.node_ranges(10, 4) == [0, 3, 6, 8, 10]
+    assert MD.relation_block_cuts(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 3) == [0, 0, 0, 0]
+
+
+def _worker(rank, world, port, case, out):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels as CK
+    from mr_gnas_amd import supernet as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        z = load_golden(case)
+        n = z["node_id"].numel()
+        net = S.SearchNetwork("cpu", z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0,
+                              registry=CK.registry())
+        net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+        net.load_alpha([z[f"alpha/{i}"] for i in range(5)])
+        net.train()
+        shard = MD.EdgeShard(n, z["src"], z["dst"], z["edge_type"], z["norm"], z["R"], rank, world, "cpu")
+        sn = MD.ShardedSupernet(net, shard, z["node_id"], kernels=CK)
+        ent, rel = sn.forward()
+        lo = MD.node_ranges(len(z["data"]), world)
+        loss = sn.loss(ent, rel, z["data"][lo[rank]:lo[rank + 1]], z["labels"][lo[rank]:lo[rank + 1]], len(z["data"]))
+        loss.backward()
+        params = list(net.parameters())
+        MD.all_reduce_gradients(params + net.arch_parameters()[:4])
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        if rank == 0:
+            res = {"ent": ent.detach(), "rel": rel.detach(), "loss": total,
+                   "edges": [int(shard.num_edges())]}
+            for k, p in net.named_parameters():
+                res["g/" + k] = p.grad
+            for i in range(4):
+                res[f"ga/{i}"] = net.arch_parameters()[i].grad
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "supernet_tiny"), (2, "supernet_d24"), (3, "supernet_tiny")])
+def test_sharded_supernet_matches_reference(tmp_path, world, case):
+    out = str(tmp_path / "res.pt")
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, case, out), nprocs=world, join=True)
+    res = torch.load(out)
+    z = load_golden(case)
+    torch.testing.assert_close(res["ent"], z["ent"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(res["rel"], z["rel_out"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(res["loss"], z["loss"], rtol=1e-5, atol=1e-6)
+    for i in range(4):
+        ref = z[f"galpha/{i}"]
+        assert float((res[f"ga/{i}"] - ref).abs().max()) <= 2e-3 * max(float(ref.abs().max()), 1e-8) + 1e-7, f"alpha {i}"
+    for k, v in sub(z, "gparam/").items():
+        got = res["g/" + k]
+        scale = max(float(v.abs().max()), 1e-6)
+        assert float((got - v).abs().max()) <= 2e-3 * scale + 5e-6, k

@@ -59,3 +59,33 @@ def test_supernet_step(case):
         assert err <= 2e-3 * max(float(ref.abs().max()), 1e-8) + 1e-7, f"alpha {i}: {err:.3e}"
     grads_close(net, z, 2e-3, case)
     assert repr(net.show_genotype(0)) == z["genotype0"]
+
+
+def test_sharded_step_world1_on_hip():
+    """The relation-block sharded forward (RCCL process group of one rank) on the HIP kernels
+    must reproduce the reference like the plain path does; multi-rank behaviour of the same
+    code is covered on CPU over gloo (tests/test_dist_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from mr_gnas_amd import dist as MD
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        z = load_golden("supernet_d24")
+        n = z["node_id"].numel()
+        net = S.SearchNetwork(DEV, z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0).to(DEV)
+        net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+        net.load_alpha([z[f"alpha/{i}"].to(DEV) for i in range(5)])
+        net.train()
+        shard = MD.EdgeShard(n, z["src"], z["dst"], z["edge_type"], z["norm"], z["R"], 0, 1, DEV)
+        sn = MD.ShardedSupernet(net, shard, z["node_id"])
+        ent, rel = sn.forward()
+        loss = sn.loss(ent, rel, z["data"].to(DEV), z["labels"].to(DEV), len(z["data"]))
+        loss.backward()
+        MD.all_reduce_gradients(list(net.parameters()) + net.arch_parameters()[:4])
+        torch.testing.assert_close(ent.cpu(), z["ent"], rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(loss.detach().cpu(), z["loss"], rtol=1e-4, atol=1e-6)
+        grads_close(net, z, 2e-3, "sharded world=1")
+    finally:
+        dist.destroy_process_group()
