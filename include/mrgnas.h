@@ -50,6 +50,13 @@ extern "C" {
 #define MRG_REDUCE_SUM   0
 #define MRG_REDUCE_MEAN  1
 #define MRG_REDUCE_MAX   2
+/* compose codes of mrg_fused_gcs: x = X[xi[e]], y = Y[yi[e]], s = scal[e] (1 if scal is NULL) */
+#define MRG_GCS_SUB      0   /* x - y*s                          CompGCN 'sub'  (u_sub_e)            */
+#define MRG_GCS_MUL      1   /* x * (y*s)                        CompGCN 'mul'  (u_mul_e)            */
+#define MRG_GCS_COPY     2   /* x*s                (Y unused)    gather backward, d/dh of 'sub'       */
+#define MRG_GCS_NEGS     3   /* -(x*s)             (Y unused)    d/dr of 'sub'                        */
+#define MRG_GCS_CCORR    4   /* sum_i x[i] * y[(i+k)%D] * s      CompGCN 'ccorr' and its d/dh         */
+#define MRG_GCS_CCONV    5   /* s * sum_i x[i] * y[(k-i)%D]      d/dr of 'ccorr'                      */
 /* activation codes for mrg_linear_fwd */
 #define MRG_ACT_NONE     0
 #define MRG_ACT_RELU     1
@@ -139,6 +146,23 @@ int mrg_seg_reduce_fwd(int mode, const float *msg, const float *self_rows,
 int mrg_seg_reduce_bwd(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree,
                        const int32_t *arg, float *gmsg, float *gself,
                        int64_t E, int64_t N, int D, void *stream);
+
+/* ---- a9: fused gather -> compose -> segmented sum ------------------------------
+ * CompGraphConv.forward steps 1-3, reference models/compgcn.py:58-87:
+ *   g.edata['h'] = r_feats[etype] * norm;  apply_edges(u_sub_e | u_mul_e | ccorr);
+ *   mask + scatter (in/out edges);  update_all(copy_e, sum)
+ * (the per-direction linears W_O / W_I commute with the sum and run on the [N, D] result).
+ *   out[seg,:] = sum_{e in list(seg)} combine(mode, X[xi[e],:], Y[yi[e],:], scal[e])
+ * Segment lists use the chunk plan of mrg_seg_reduce_fwd (eid = element ids grouped by
+ * segment; seg_len[nseg] = list lengths).  The same entry point with other index arrays is
+ * the backward (segments keyed by src / by etype) and the backward of row gathers. */
+int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, const int32_t *yi,
+                  const float *scal, const int32_t *eid,
+                  const int32_t *chunk_node, const int32_t *chunk_start, const int32_t *chunk_end,
+                  const int32_t *chunk_slot, int64_t n_chunks,
+                  const int32_t *hub_node, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,
+                  int64_t n_slots, const int32_t *seg_len,
+                  float *out, void *ws, int64_t nseg, int D, void *stream);
 
 /* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
  * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)

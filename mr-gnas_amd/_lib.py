@@ -43,6 +43,7 @@ SIGNATURES = {
     "mrg_seg_reduce_workspace_bytes": (_L, [_L, _I]),
     "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mrg_linear_bwd_input": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "mrg_linear_bwd_weight_workspace_bytes": (_L, [_L, _I, _I]),

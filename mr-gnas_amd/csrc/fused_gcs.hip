@@ -1,0 +1,214 @@
+// The fused per-relation kernel: gather -> compose(node row, relation row) -> segmented sum.
+//   out[seg,:] = sum over e in list(seg) of  combine(X[xi[e],:], Y[yi[e],:], s[e])
+// It replaces, for CompGraphConv (reference models/compgcn.py:58-87):
+//   r_feats[etype] * norm  (:58)  ->  apply_edges(u_sub_e | u_mul_e | ccorr)  (:62-67)
+//   -> mask + scatter into new_comp_h (:74-82) -> update_all(copy_e, sum) (:87)
+// without materialising any [E, D] tensor (the per-direction linears W_O / W_I commute with
+// the sum and are applied to the [N, D] result afterwards), and the same kernel with other
+// index arrays is its backward (gradients w.r.t. node rows: segments keyed by src; w.r.t.
+// relation rows: segments keyed by etype) and the backward of plain gathers.
+//
+// Work decomposition = segreduce.hip: one LPR-lane group per chunk of a segment's list, whole
+// rows as float4 per lane, hub lists split and recombined in order (no float atomics).
+// Algorithmic bytes per launch: E*(8 + 4*D) + 4*(nseg+1) + 4*D*(rows(Y) + nseg):
+// the gathered X row is counted once per edge, index + scalar 8 B per edge.
+#include "segcommon.hpp"
+
+namespace mrg {
+
+template <int MODE> struct NeedsY { static constexpr bool value = MODE == MRG_GCS_SUB || MODE == MRG_GCS_MUL; };
+
+// elementwise modes: SUB, MUL, COPY, NEGS
+template <int VEC, int LPR, int KMAX, int MODE>
+__global__ __launch_bounds__(MRG_BLOCK) void gcs_k(const float* __restrict__ X, const int32_t* __restrict__ xi,
+                                                   const float* __restrict__ Y, const int32_t* __restrict__ yi,
+                                                   const float* __restrict__ scal, const int32_t* __restrict__ eid,
+                                                   const int32_t* __restrict__ chunk_node, const int32_t* __restrict__ chunk_start,
+                                                   const int32_t* __restrict__ chunk_end, const int32_t* __restrict__ chunk_slot,
+                                                   int64_t n_chunks, float* __restrict__ out, float* __restrict__ ws_val, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int U = 4;
+  constexpr bool NY = NeedsY<MODE>::value;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
+    const int v = chunk_node[ch];
+    const int j0 = chunk_start[ch], j1 = chunk_end[ch];
+    const int slot = chunk_slot[ch];
+    Vec<VEC> acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = Vec<VEC>::fill(0.f);
+    for (int j = j0; j < j1; j += U) {
+      int e[U], ex[U], ey[U];
+      float s[U];
+      Vec<VEC> x[U][KMAX], y[U][KMAX];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        e[q] = (j + q < j1) ? eid[j + q] : -1;
+        ex[q] = e[q] >= 0 ? xi[e[q]] : 0;
+        ey[q] = (NY && e[q] >= 0) ? yi[e[q]] : 0;
+        s[q] = (scal != nullptr && e[q] >= 0) ? scal[e[q]] : 1.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (e[q] >= 0 && c < dv) {
+            x[q][k] = Vec<VEC>::load(X + (int64_t)ex[q] * D + c * VEC);
+            if (NY) y[q][k] = Vec<VEC>::load(Y + (int64_t)ey[q] * D + c * VEC);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (e[q] >= 0) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            if (sl + k * LPR < dv) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                float xv = x[q][k][i];
+                float val;
+                if (MODE == MRG_GCS_SUB) val = xv - y[q][k][i] * s[q];
+                else if (MODE == MRG_GCS_MUL) val = xv * (y[q][k][i] * s[q]);
+                else if (MODE == MRG_GCS_COPY) val = xv * s[q];
+                else val = -(xv * s[q]);
+                acc[k][i] += val;
+              }
+            }
+          }
+        }
+      }
+    }
+    float* dst = slot < 0 ? out + (int64_t)v * D : ws_val + (int64_t)slot * D;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) acc[k].store(dst + c * VEC);
+    }
+  }
+}
+
+// circular correlation / convolution modes: per edge O(D^2) through an LDS copy of both rows
+//   CCORR: val[k] = sum_i x[i] * (y[(i+k) % D] * s)      CCONV: val[k] = s * sum_i x[i] * y[(k-i) % D]
+template <int VEC, int LPR, int KMAX, int MODE>
+__global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict__ X, const int32_t* __restrict__ xi,
+                                                        const float* __restrict__ Y, const int32_t* __restrict__ yi,
+                                                        const float* __restrict__ scal, const int32_t* __restrict__ eid,
+                                                        const int32_t* __restrict__ chunk_node, const int32_t* __restrict__ chunk_start,
+                                                        const int32_t* __restrict__ chunk_end, const int32_t* __restrict__ chunk_slot,
+                                                        int64_t n_chunks, float* __restrict__ out, float* __restrict__ ws_val, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  __shared__ float lds[RPB * 2 * WIDTH];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  float* lx = lds + rw * 2 * WIDTH;
+  float* ly = lx + WIDTH;
+  for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
+    const int v = chunk_node[ch];
+    const int j0 = chunk_start[ch], j1 = chunk_end[ch];
+    const int slot = chunk_slot[ch];
+    Vec<VEC> acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = Vec<VEC>::fill(0.f);
+    for (int j = j0; j < j1; ++j) {
+      const int e = eid[j];
+      const float s = scal != nullptr ? scal[e] : 1.0f;
+      const float* xr = X + (int64_t)xi[e] * D;
+      const float* yr = Y + (int64_t)yi[e] * D;
+      __threadfence_block();                    // earlier reads of lx/ly by this wave are done
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          Vec<VEC> a = Vec<VEC>::load(xr + c * VEC), b = Vec<VEC>::load(yr + c * VEC);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            lx[c * VEC + i] = a[i];
+            ly[c * VEC + i] = b[i];
+          }
+        }
+      }
+      __threadfence_block();                    // the group's rows are in LDS before anyone reads them
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          float part[VEC];
+          int idx[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { part[i] = 0.f; idx[i] = c * VEC + i; }
+          for (int t = 0; t < D; ++t) {
+            const float xv = lx[t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              part[i] += xv * ly[idx[i]];
+              if (MODE == MRG_GCS_CCORR) { idx[i] = idx[i] + 1 == D ? 0 : idx[i] + 1; }
+              else { idx[i] = idx[i] == 0 ? D - 1 : idx[i] - 1; }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[k][i] += part[i] * s;
+        }
+      }
+    }
+    float* dst = slot < 0 ? out + (int64_t)v * D : ws_val + (int64_t)slot * D;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) acc[k].store(dst + c * VEC);
+    }
+  }
+}
+
+}  // namespace mrg
+
+using namespace mrg;
+
+extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const float* Y, const int32_t* yi,
+                             const float* scal, const int32_t* eid, const int32_t* chunk_node, const int32_t* chunk_start,
+                             const int32_t* chunk_end, const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
+                             const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
+                             const int32_t* seg_len, float* out, void* ws, int64_t nseg, int D, void* stream) {
+  if (mode < 0 || mode > MRG_GCS_CCONV) return MRG_E_ENUM;
+  if (nseg < 0 || D <= 0 || n_chunks < nseg || n_hubs < 0 || n_slots < 0) return MRG_E_SHAPE;
+  if (nseg == 0) return MRG_OK;
+  if (!out || !chunk_node || !chunk_start || !chunk_end || !chunk_slot || !seg_len) return MRG_E_NULLPTR;
+  const bool needs_y = mode == MRG_GCS_SUB || mode == MRG_GCS_MUL || mode == MRG_GCS_CCORR || mode == MRG_GCS_CCONV;
+  if (n_hubs > 0 && (!hub_node || !hub_first || !hub_count)) return MRG_E_NULLPTR;
+  if (n_slots > 0 && !ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws_val = (float*)ws;
+  RowGeom g = row_geom(D, aligned16(X) && aligned16(Y) && aligned16(out) && aligned16(ws));
+  if (!g.ok) return MRG_E_SHAPE;
+  (void)needs_y;
+#define LAUNCH(KERN, V, L, K, M)                                                                                       \
+  hipLaunchKernelGGL((KERN<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, eid, chunk_node,       \
+                     chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D)
+#define CALL(V, L, K)                                                                                                  \
+  do {                                                                                                                 \
+    int grid = grid_for(n_chunks, MRG_BLOCK / L);                                                                      \
+    switch (mode) {                                                                                                    \
+      case MRG_GCS_SUB: LAUNCH(gcs_k, V, L, K, MRG_GCS_SUB); break;                                                    \
+      case MRG_GCS_MUL: LAUNCH(gcs_k, V, L, K, MRG_GCS_MUL); break;                                                    \
+      case MRG_GCS_COPY: LAUNCH(gcs_k, V, L, K, MRG_GCS_COPY); break;                                                  \
+      case MRG_GCS_NEGS: LAUNCH(gcs_k, V, L, K, MRG_GCS_NEGS); break;                                                  \
+      case MRG_GCS_CCORR: LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCORR); break;                                           \
+      default: LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCONV); break;                                                      \
+    }                                                                                                                  \
+    if (n_hubs > 0) {                                                                                                  \
+      int gh = grid_for(n_hubs, MRG_BLOCK / L);                                                                        \
+      hipLaunchKernelGGL((seg_hub_k<V, L, K, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, (const float*)nullptr, hub_node, \
+                         hub_first, hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0); \
+    }                                                                                                                  \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+#undef LAUNCH
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

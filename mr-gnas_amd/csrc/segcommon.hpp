@@ -1,0 +1,102 @@
+// Shared pieces of the destination-segmented reducers (segreduce.hip, fused_gcs.hip):
+// per-lane accumulators, row finalisation, and the ordered combine of hub partials.
+#pragma once
+#include "common.hpp"
+#include <math.h>
+
+namespace mrg {
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+struct Acc {
+  Vec<VEC> val[KMAX];
+  IVec<VEC> arg[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      val[k] = Vec<VEC>::fill(IS_MAX ? -INFINITY : 0.f);
+      arg[k] = IVec<VEC>::fill(-1);
+    }
+  }
+  // strict '>' keeps the first (lowest edge id) of equal maxima
+  __device__ __forceinline__ void take(int k, const Vec<VEC>& x, int e) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (IS_MAX) {
+        if (x[j] > val[k][j]) { val[k][j] = x[j]; arg[k][j] = e; }
+      } else {
+        val[k][j] += x[j];
+      }
+    }
+  }
+  __device__ __forceinline__ void take_partial(int k, const Vec<VEC>& x, const IVec<VEC>& a) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (IS_MAX) {
+        if (x[j] > val[k][j]) { val[k][j] = x[j]; arg[k][j] = a[j]; }
+      } else {
+        val[k][j] += x[j];
+      }
+    }
+  }
+};
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+__device__ __forceinline__ void finalize_row(Acc<VEC, LPR, KMAX, IS_MAX>& acc, int v, int deg, bool is_mean,
+                                             const float* __restrict__ self_rows, float* __restrict__ out,
+                                             int32_t* __restrict__ arg, int D, int sl) {
+  const int dv = D / VEC;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    if (c < dv) {
+      Vec<VEC> o = acc.val[k];
+      if (IS_MAX) {
+        if (deg == 0) o = Vec<VEC>::fill(0.f);
+      } else if (is_mean) {
+        float d = (float)(deg > 1 ? deg : 1);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = o[j] / d;
+      }
+      if (self_rows) {
+        Vec<VEC> s = Vec<VEC>::load(self_rows + (int64_t)v * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += s[j];
+      }
+      o.store(out + (int64_t)v * D + c * VEC);
+      if (IS_MAX && arg) acc.arg[k].store(arg + (int64_t)v * D + c * VEC);
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX>
+__global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__ self_rows, const int32_t* __restrict__ hub_node,
+                                                       const int32_t* __restrict__ hub_first, const int32_t* __restrict__ hub_count,
+                                                       int64_t n_hubs, const int32_t* __restrict__ in_degree,
+                                                       float* __restrict__ out, int32_t* __restrict__ arg,
+                                                       const float* __restrict__ ws_val, const int32_t* __restrict__ ws_arg,
+                                                       int D, int is_mean) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t h = (int64_t)blockIdx.x * RPB + rw; h < n_hubs; h += (int64_t)gridDim.x * RPB) {
+    const int v = hub_node[h], s0 = hub_first[h], cnt = hub_count[h];
+    Acc<VEC, LPR, KMAX, IS_MAX> acc;
+    acc.init();
+    for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          Vec<VEC> x = Vec<VEC>::load(ws_val + (int64_t)(s0 + q) * D + c * VEC);
+          IVec<VEC> a = IVec<VEC>::fill(-1);
+          if (IS_MAX) a = IVec<VEC>::load(ws_arg + (int64_t)(s0 + q) * D + c * VEC);
+          acc.take_partial(k, x, a);
+        }
+      }
+    }
+    finalize_row<VEC, LPR, KMAX, IS_MAX>(acc, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
+  }
+}
+
+
+}  // namespace mrg

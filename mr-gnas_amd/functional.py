@@ -303,3 +303,85 @@ class _Gather(torch.autograd.Function):
 def gather(table, gp):
     """table[gp.idx] with autograd (reference models/model_lp.py:131, models/model_search_lp.py:144-145,153-154)."""
     return _Gather.apply(table, gp)
+
+
+# ---------------------------------------------------------------------------
+# a9: fused gather -> compose -> segmented sum (CompGCN) and its backward
+# ---------------------------------------------------------------------------
+GCS = {"sub": 0, "mul": 1, "copy": 2, "negs": 3, "ccorr": 4, "cconv": 5}
+
+
+def fused_gcs(mode, X, xi, Y, yi, scal, plan, nseg):
+    """out[seg] = sum_{e in seg} combine(mode, X[xi[e]], Y[yi[e]], scal[e]); forward-only primitive
+    (mrg_fused_gcs).  `plan` = graph.dst_csr_plan(segment key per element, nseg)."""
+    X, Y, scal = f32c(X), f32c(Y), f32c(scal)
+    require_hip(X, Y, scal, xi, yi)
+    D = X.shape[1]
+    out = torch.empty(nseg, D, dtype=torch.float32, device=X.device)
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
+    E = int(plan["eid"].numel())
+    rows_y = Y.shape[0] if Y is not None else 0
+    nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)          # SURVEY section 8d
+    call("mrg_fused_gcs", (GCS[mode], ptr(X), ptr(xi), ptr(Y), ptr(yi), ptr(scal), ptr(plan["eid"]), ptr(plan["chunk_node"]),
+                           ptr(plan["chunk_start"]), ptr(plan["chunk_end"]), ptr(plan["chunk_slot"]), plan["n_chunks"],
+                           ptr(plan["hub_node"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), plan["n_hubs"],
+                           plan["n_slots"], ptr(plan["in_degree"]), ptr(out), ptr(ws), nseg, D, stream_of(X)),
+         nbytes=nb, flops=(2 * E * D * D if mode in ("ccorr", "cconv") else 0))
+    return out
+
+
+class ComposePlan:
+    """Index structure of one compose-and-aggregate: element e reads node row xi[e] and relation
+    row yi[e], is scaled by scal[e] and summed into segment seg[e].  Holds the three chunk plans
+    (by segment for the forward, by node row and by relation row for the backward)."""
+
+    def __init__(self, xi, yi, seg, scal, n_x, n_y, n_seg):
+        from .graph import dst_csr_plan
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        self.xi, self.yi, self.seg = i32(xi), i32(yi), i32(seg)
+        self.scal = None if scal is None else scal.float().contiguous()
+        self.n_x, self.n_y, self.n_seg = int(n_x), int(n_y), int(n_seg)
+        self.by_seg = dst_csr_plan(seg, n_seg)
+        self.by_x = dst_csr_plan(xi, n_x)
+        self.by_y = dst_csr_plan(yi, n_y)
+
+
+class _ComposeAggregate(torch.autograd.Function):
+    """A[seg] = sum_e phi(X[xi_e], Y[yi_e] * s_e), phi in {sub, mul, ccorr}
+    (reference models/compgcn.py:58-87 without the per-direction linears)."""
+
+    @staticmethod
+    def forward(ctx, kind, X, Y, cp):
+        X, Y = f32c(X), f32c(Y)
+        ctx.kind, ctx.cp = kind, cp
+        ctx.save_for_backward(X, Y)
+        return fused_gcs(kind, X, cp.xi, Y, cp.yi, cp.scal, cp.by_seg, cp.n_seg)
+
+    @staticmethod
+    def backward(ctx, G):
+        X, Y = ctx.saved_tensors
+        cp, kind = ctx.cp, ctx.kind
+        G = f32c(G)
+        gX = gY = None
+        if kind == "sub":       # x - y s
+            if ctx.needs_input_grad[1]:
+                gX = fused_gcs("copy", G, cp.seg, None, None, None, cp.by_x, cp.n_x)
+            if ctx.needs_input_grad[2]:
+                gY = fused_gcs("negs", G, cp.seg, None, None, cp.scal, cp.by_y, cp.n_y)
+        elif kind == "mul":     # x * y s
+            if ctx.needs_input_grad[1]:
+                gX = fused_gcs("mul", G, cp.seg, Y, cp.yi, cp.scal, cp.by_x, cp.n_x)
+            if ctx.needs_input_grad[2]:
+                gY = fused_gcs("mul", G, cp.seg, X, cp.xi, cp.scal, cp.by_y, cp.n_y)
+        else:                   # ccorr(x, y s)
+            if ctx.needs_input_grad[1]:
+                gX = fused_gcs("ccorr", G, cp.seg, Y, cp.yi, cp.scal, cp.by_x, cp.n_x)
+            if ctx.needs_input_grad[2]:
+                gY = fused_gcs("cconv", X, cp.xi, G, cp.seg, cp.scal, cp.by_y, cp.n_y)
+        return None, gX, gY, None
+
+
+def compose_aggregate(kind, X, Y, cp):
+    if kind not in ("sub", "mul", "ccorr"):
+        raise Exception('Only supports sub, mul, and ccorr')
+    return _ComposeAggregate.apply(kind, X, Y, cp)

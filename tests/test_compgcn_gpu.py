@@ -1,0 +1,91 @@
+"""GPU parity of the fused CompGCN path against the reference's golden vectors
+(tests/golden/compgcn_small.npz, produced by running reference models/compgcn.py)."""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from mr_gnas_amd import compgcn as C, functional as K, graph as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_graph(z):
+    g = G.RelGraph(z["N"], z["src"], z["dst"], device=DEV)
+    m = z["in_edges_mask"].bool().to(DEV)
+    g.edata.update(etype=z["etype"].to(DEV), norm=z["norm"].to(DEV), in_edges_mask=m, out_edges_mask=~m)
+    return g
+
+
+def close(a, b, what, rtol=2e-4, atol=5e-5):
+    err = float((a.detach().cpu() - b).abs().max())
+    assert err <= atol + rtol * max(float(b.abs().max()), 1.0), f"{what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("fn_", ["sub", "mul", "ccorr"])
+@pytest.mark.parametrize("bnorm", [True, False])
+def test_comp_graph_conv(fn_, bnorm):
+    z = load_golden("compgcn_small")
+    g = make_graph(z)
+    tag = f"conv_{fn_}_{'bn' if bnorm else 'nobn'}"
+    layer = C.CompGraphConv(z["Din"], z["Dout"], comp_fn=fn_, batchnorm=bnorm, dropout=0.0).to(DEV)
+    state = sub(z, tag + "/param/")
+    if bnorm:
+        state.update({"bn.running_mean": torch.zeros(z["Dout"]), "bn.running_var": torch.ones(z["Dout"]),
+                      "bn.num_batches_tracked": torch.tensor(0)})
+    layer.load_state_dict(state)                                   # reference state_dict keys
+    layer.train()
+    a = z["n_in"].to(DEV).requires_grad_(True)
+    b = z["r_in"].to(DEV).requires_grad_(True)
+    no, ro = layer(g, a, b)
+    ((no * z["gn"].to(DEV)).sum() + (ro * z["gr"].to(DEV)).sum()).backward()
+    close(no, z[tag + "/n_out"], tag + " n_out")
+    close(ro, z[tag + "/r_out"], tag + " r_out")
+    close(a.grad, z[tag + "/gn_in"], tag + " grad n_in")
+    close(b.grad, z[tag + "/gr_in"], tag + " grad r_in")
+    for k, p in layer.named_parameters():
+        close(p.grad, z[f"{tag}/gparam/{k}"], f"{tag} grad {k}", rtol=5e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,fn_,nb", [("net_sub_b3", "sub", 3), ("net_mul_b0", "mul", 0)])
+def test_comp_gcn_stack(tag, fn_, nb):
+    z = load_golden("compgcn_small")
+    g = make_graph(z)
+    net = C.CompGCN(nb, 2 * z["R"], z["N"], in_dim=z["Din"], layer_size=[z["Dout"], z["Din"]], comp_fn=fn_, batchnorm=True,
+                    dropout=0.0, layer_dropout=[0.0, 0.0]).to(DEV)
+    net.load_state_dict(sub(z, tag + "/param/"), strict=False)     # BN buffers keep their defaults
+    net.train()
+    no, ro = net(g)
+    ((no * z[tag + "/go_n"].to(DEV)).sum() + (ro * z[tag + "/go_r"].to(DEV)).sum()).backward()
+    close(no, z[tag + "/n_out"], tag + " n_out")
+    close(ro, z[tag + "/r_out"], tag + " r_out")
+    for k, p in net.named_parameters():
+        close(p.grad, z[f"{tag}/gparam/{k}"], f"{tag} grad {k}", rtol=1e-3, atol=1e-4)
+    with pytest.raises(Exception, match="Only supports sub, mul, and ccorr"):
+        C.CompGraphConv(4, 4, comp_fn="nope").to(DEV)(g, torch.zeros(z["N"], 4, device=DEV), torch.zeros(2 * z["R"], 4, device=DEV))
+
+
+def test_fused_gcs_large_with_hubs():
+    """sub/mul/ccorr on a bigger graph with hub destinations against a float64 evaluation."""
+    gen = torch.Generator().manual_seed(5)
+    N, E, R, D = 400, 9000, 9, 200
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    dst[:3000] = 7
+    et = torch.randint(0, R, (E,), generator=gen)
+    s = torch.rand(E, generator=gen)
+    X, Y = torch.randn(N, D, generator=gen), torch.randn(R, D, generator=gen)
+    cp = K.ComposePlan(src.to(DEV), et.to(DEV), dst.to(DEV), s.to(DEV), N, R, N)
+    idx = (torch.arange(D).view(-1, 1) + torch.arange(D).view(1, -1)) % D
+    for kind in ("sub", "mul", "ccorr"):
+        out = K.fused_gcs(kind, X.to(DEV), cp.xi, Y.to(DEV), cp.yi, cp.scal, cp.by_seg, N).cpu()
+        x, y = X[src].double(), (Y[et] * s.view(-1, 1)).double()
+        if kind == "sub":
+            msg = x - y
+        elif kind == "mul":
+            msg = x * y
+        else:
+            msg = torch.einsum("ei,eik->ek", x, y[:, idx])
+        ref = torch.zeros(N, D, dtype=torch.float64).index_add(0, dst, msg)
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (kind, err)
