@@ -164,6 +164,37 @@ int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, c
                   int64_t n_slots, const int32_t *seg_len,
                   float *out, void *ws, int64_t nseg, int D, void *stream);
 
+/* ---- X: MixedOp epilogue  out = sum_k w_k * ReLU(BatchNorm_k(y_k)) -----------------
+ * MixedOp.forward / op_forward, reference models/cell_lp.py:25-33, with nn.BatchNorm1d in
+ * training mode (:21).  K <= 8 operator outputs y_k [rows, D]; a NULL y_k is an all-zero
+ * output (f_zero).  *_host arguments are HOST arrays of K DEVICE pointers.
+ *   mrg_mix_colstats      sums[k][0|1][c] = sum_r y_k, sum_r y_k^2        (float64 [K][2][D])
+ *   mrg_mix_finalize_fwd  coef[k][0..3] = scale (gamma*invstd), shift (beta - mean*scale),
+ *                         invstd, mean*invstd; updates running_mean / running_var like torch
+ *                         (momentum, unbiased variance) when their pointers are given.
+ *                         `total_rows` = rows of the whole (possibly sharded) tensor.
+ *   mrg_mix_fwd           out = sum_k w[k] * relu(y_k * scale_k + shift_k)
+ *   mrg_mix_bwd_reduce    red[k][0] = sum_r gr, [1] = sum_r gr*xhat, [2] = sum_r g*relu(z),
+ *                         gr = w[k] * g * [z > 0]                         (float32 [K][3][D])
+ *   mrg_mix_finalize_bwd  coef2[k][0|1] = red[k][0|1] / total_rows; dw[k] = sum_c red[k][2][c];
+ *                         optional dgamma_k = red[k][1], dbeta_k = red[k][0]
+ *   mrg_mix_bwd_apply     gy_k = (gr - coef2[k][0] - xhat * coef2[k][1]) * scale_k  (NULL gy_k skipped)
+ * Statistics may be all-reduced between colstats/finalize (and reduce/finalize) when rows
+ * are sharded over GPUs.  Needs K*6*D*4 <= 64 KiB of LDS. */
+int64_t mrg_mix_workspace_bytes(int K, int D);
+int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, double *sums, void *ws, void *stream);
+int mrg_mix_finalize_fwd(const double *sums, const float *const *gamma_host, const float *const *beta_host,
+                         float *const *rmean_host, float *const *rvar_host, int K, double total_rows, int D,
+                         float eps, float momentum, float *coef, void *stream);
+int mrg_mix_fwd(const float *const *y_host, int K, const float *coef, const float *w, float *out,
+                int64_t rows, int D, void *stream);
+int mrg_mix_bwd_reduce(const float *g, const float *const *y_host, int K, const float *coef, const float *w,
+                       float *red, void *ws, int64_t rows, int D, void *stream);
+int mrg_mix_finalize_bwd(const float *red, int K, double total_rows, int D, float *coef2,
+                         float *const *dgamma_host, float *const *dbeta_host, float *dw, void *stream);
+int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *gy_host, int K,
+                      const float *coef, const float *coef2, const float *w, int64_t rows, int D, void *stream);
+
 /* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
  * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)
  * and the post-aggregation linears of CompGraphConv (reference models/compgcn.py:77-78,100,103).

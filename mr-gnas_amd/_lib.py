@@ -44,6 +44,13 @@ SIGNATURES = {
     "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_workspace_bytes": (_L, [_I, _I]),
+    "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
+    "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
+    "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_finalize_bwd": (_I, [_P, _I, ctypes.c_double, _I, _P, _P, _P, _P, _P]),
+    "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mrg_linear_bwd_input": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "mrg_linear_bwd_weight_workspace_bytes": (_L, [_L, _I, _I]),
@@ -136,6 +143,14 @@ def check(code, what=""):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (NULL for None) for the *_host arguments."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
 
 
 def stream_of(t):

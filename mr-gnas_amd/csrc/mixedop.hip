@@ -1,0 +1,448 @@
+// MixedOp epilogue:  out = sum_k w_k * ReLU(BatchNorm_k(y_k))  over K operator outputs y_k [rows, D]
+//   reference models/cell_lp.py:25-33 (MixedOp.forward / op_forward) with nn.BatchNorm1d in
+//   training mode (:21) -- in the reference 3 ATen launches per branch + the weighted sum,
+//   each a full pass over [rows, D], and as many again in backward.
+// Here: one statistics pass (column sums in float64, deterministic two-stage reduction), one
+// combine pass (reads every y_k once, writes out once), and in backward one reduction pass
+// and one apply pass.  A NULL branch pointer stands for an all-zero operator output (f_zero).
+// HBM-bound: algorithmic bytes  stats 4*D*rows*Kt,  fwd 4*D*rows*(Kt+1),
+// bwd-reduce 4*D*rows*(Kt+1),  bwd-apply 4*D*rows*(2*Kt+1)   (Kt = non-NULL branches).
+#include "common.hpp"
+
+#define MRG_MIX_MAXK 8
+
+namespace mrg {
+
+struct PtrPack { const float* p[MRG_MIX_MAXK]; };
+struct MutPack { float* p[MRG_MIX_MAXK]; };
+
+// ---- column statistics: sums[k][0][c] = sum_r y_k[r][c], sums[k][1][c] = sum_r y_k[r][c]^2 (float64)
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, int64_t rows, int D, double* __restrict__ ws) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  __shared__ double red[RPB * 2 * WIDTH];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int k = 0; k < K; ++k) {
+    const float* __restrict__ y = ys.p[k];
+    double s1[KMAX][VEC], s2[KMAX][VEC];
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s1[q][j] = 0.0; s2[q][j] = 0.0; }
+    if (y != nullptr) {
+      for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q) {
+          int c = sl + q * LPR;
+          if (c < dv) {
+            Vec<VEC> v = Vec<VEC>::load(y + r * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { double d = (double)v[j]; s1[q][j] += d; s2[q][j] += d * d; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        red[(rw * 2 + 0) * WIDTH + c * VEC + j] = s1[q][j];
+        red[(rw * 2 + 1) * WIDTH + c * VEC + j] = s2[q][j];
+      }
+    }
+    __syncthreads();
+    double* dst = ws + ((int64_t)blockIdx.x * K + k) * 2 * D;
+    for (int t = threadIdx.x; t < 2 * D; t += MRG_BLOCK) {
+      int which = t / D, c = t - which * D;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < RPB; ++q) acc += red[(q * 2 + which) * WIDTH + c];
+      dst[t] = acc;
+    }
+  }
+}
+
+// generic ordered reduction of per-block partial vectors: out[t] = sum_b ws[b*len + t]
+template <typename T>
+__global__ void mix_reduce_k(const T* __restrict__ ws, T* __restrict__ out, int nblocks, int len) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= len) return;
+  T acc = 0;
+  for (int b = 0; b < nblocks; ++b) acc += ws[(int64_t)b * len + t];
+  out[t] = acc;
+}
+
+// ---- finalize forward: statistics -> per-column coefficients, running-stat update
+// coef[k][0]=scale=gamma*invstd, [1]=shift=beta-mean*scale, [2]=invstd, [3]=mean*invstd
+__global__ void mix_finalize_fwd_k(const double* __restrict__ sums, PtrPack gamma, PtrPack beta, MutPack rmean, MutPack rvar,
+                                   int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef) {
+  int k = blockIdx.y;
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D || k >= K) return;
+  double mean = sums[(k * 2 + 0) * D + c] / total_rows;
+  double var = sums[(k * 2 + 1) * D + c] / total_rows - mean * mean;
+  if (var < 0) var = 0;
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  float g = gamma.p[k] ? gamma.p[k][c] : 1.f, b = beta.p[k] ? beta.p[k][c] : 0.f;
+  float* o = coef + (int64_t)k * 4 * D;
+  o[c] = (float)(g * invstd);
+  o[D + c] = (float)(b - mean * g * invstd);
+  o[2 * D + c] = (float)invstd;
+  o[3 * D + c] = (float)(mean * invstd);
+  if (rmean.p[k]) {
+    double unbiased = total_rows > 1 ? var * (total_rows / (total_rows - 1.0)) : var;
+    rmean.p[k][c] = (1.f - momentum) * rmean.p[k][c] + momentum * (float)mean;
+    rvar.p[k][c] = (1.f - momentum) * rvar.p[k][c] + momentum * (float)unbiased;
+  }
+}
+
+// ---- forward combine
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
+                                                       float* __restrict__ out, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // [K][2][D] scale, shift
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int t = threadIdx.x; t < K * 2 * D; t += MRG_BLOCK) {
+    int k = t / (2 * D), rem = t - k * 2 * D;
+    lds[t] = coef[(int64_t)k * 4 * D + rem];
+  }
+  __syncthreads();
+  float wk[MRG_MIX_MAXK];
+#pragma unroll
+  for (int k = 0; k < MRG_MIX_MAXK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        Vec<VEC> acc = Vec<VEC>::fill(0.f);
+#pragma unroll
+        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          if (k < K) {
+            const float* y = ys.p[k];
+            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float z = v[j] * sc[j] + sh[j];
+              acc[j] += wk[k] * (z > 0.f ? z : 0.f);
+            }
+          }
+        }
+        acc.store(out + r * D + c * VEC);
+      }
+    }
+  }
+}
+
+// ---- backward reduce: per branch  red[k][0] = sum gr, [1] = sum gr*xhat, [2] = sum g*relu(z)  (gr = w g [z>0])
+// rows outermost: g is read once, every y_k once; per-branch column accumulators live in registers.
+template <int VEC, int LPR, int KMAX, int KB>
+__global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __restrict__ g, PtrPack ys, int K,
+                                                              const float* __restrict__ coef, const float* __restrict__ w,
+                                                              float* __restrict__ ws, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  float* red = lds + K * 4 * D;                  // [RPB][3][WIDTH]
+  for (int t = threadIdx.x; t < K * 4 * D; t += MRG_BLOCK) lds[t] = coef[t];
+  __syncthreads();
+  float wk[KB];
+  Vec<VEC> a0[KB][KMAX], a1[KB][KMAX], a2[KB][KMAX];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    wk[k] = k < K ? w[k] : 0.f;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) { a0[k][q] = Vec<VEC>::fill(0.f); a1[k][q] = Vec<VEC>::fill(0.f); a2[k][q] = Vec<VEC>::fill(0.f); }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          if (k < K) {
+            const float* y = ys.p[k];
+            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            const float* cf = lds + k * 4 * D + c * VEC;
+            const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D), c3 = Vec<VEC>::load(cf + 3 * D);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float z = v[j] * c0[j] + c1[j];
+              float xh = v[j] * c2[j] - c3[j];
+              float rl = z > 0.f ? z : 0.f;
+              float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              a0[k][q][j] += gr;
+              a1[k][q][j] += gr * xh;
+              a2[k][q][j] += gv[j] * rl;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    if (k < K) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q) {
+        int c = sl + q * LPR;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          red[(rw * 3 + 0) * WIDTH + c * VEC + j] = a0[k][q][j];
+          red[(rw * 3 + 1) * WIDTH + c * VEC + j] = a1[k][q][j];
+          red[(rw * 3 + 2) * WIDTH + c * VEC + j] = a2[k][q][j];
+        }
+      }
+      __syncthreads();
+      float* dst = ws + ((int64_t)blockIdx.x * K + k) * 3 * D;
+      for (int t = threadIdx.x; t < 3 * D; t += MRG_BLOCK) {
+        int which = t / D, c = t - which * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int q2 = 0; q2 < RPB; ++q2) acc += red[(q2 * 3 + which) * WIDTH + c];
+        dst[t] = acc;
+      }
+    }
+  }
+}
+
+// ---- finalize backward: red[k][3][D] -> c1 = sum gr / rows, c2 = sum gr*xhat / rows into coef2[k][2][D];
+//      dgamma_k = sum gr*xhat, dbeta_k = sum gr, dw[k] = sum_c sum g*relu(z)
+__global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double total_rows, int D, float* __restrict__ coef2,
+                                   MutPack dgamma, MutPack dbeta, float* __restrict__ dw) {
+  __shared__ float part[256];
+  int k = blockIdx.x;
+  float accw = 0.f;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float s0 = red[(k * 3 + 0) * D + c], s1 = red[(k * 3 + 1) * D + c];
+    coef2[(k * 2 + 0) * D + c] = (float)(s0 / total_rows);
+    coef2[(k * 2 + 1) * D + c] = (float)(s1 / total_rows);
+    if (dgamma.p[k]) dgamma.p[k][c] = s1;
+    if (dbeta.p[k]) dbeta.p[k][c] = s0;
+    accw += red[(k * 3 + 2) * D + c];
+  }
+  part[threadIdx.x] = accw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < (int)blockDim.x; ++i) tot += part[i];
+    dw[k] = tot;
+  }
+}
+
+// ---- backward apply: gy_k = (gr - c1 - xhat*c2) * scale      (skipped where gy_k is NULL)
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
+                                                             const float* __restrict__ coef, const float* __restrict__ coef2,
+                                                             const float* __restrict__ w, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int t = threadIdx.x; t < K * 6 * D; t += MRG_BLOCK) {
+    int k = t / (6 * D), rem = t - k * 6 * D;
+    lds[t] = rem < 4 * D ? coef[(int64_t)k * 4 * D + rem] : coef2[(int64_t)k * 2 * D + rem - 4 * D];
+  }
+  __syncthreads();
+  float wk[MRG_MIX_MAXK];
+#pragma unroll
+  for (int k = 0; k < MRG_MIX_MAXK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+#pragma unroll
+        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          if (k < K && gys.p[k] != nullptr) {
+            const float* y = ys.p[k];
+            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            const float* cf = lds + k * 6 * D + c * VEC;
+            const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D),
+                           c3 = Vec<VEC>::load(cf + 3 * D), c4 = Vec<VEC>::load(cf + 4 * D), c5 = Vec<VEC>::load(cf + 5 * D);
+            Vec<VEC> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float z = v[j] * c0[j] + c1[j];
+              float xh = v[j] * c2[j] - c3[j];
+              float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              o[j] = (gr - c4[j] - xh * c5[j]) * c0[j];
+            }
+            o.store(gys.p[k] + r * D + c * VEC);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int mix_grid(int64_t rows, int lpr) {
+  int g = grid_for(rows, (MRG_BLOCK / lpr) * 8);
+  return g > 1024 ? 1024 : g;                      // partial buffers are sized for 1024 blocks
+}
+
+static bool pack_ok(const void* const* host, int K) { return host != nullptr && K >= 1 && K <= MRG_MIX_MAXK; }
+
+}  // namespace mrg
+
+using namespace mrg;
+
+extern "C" int64_t mrg_mix_workspace_bytes(int K, int D) {
+  if (K < 1 || K > MRG_MIX_MAXK || D <= 0) return 0;
+  return (int64_t)1024 * K * 3 * D * sizeof(double);
+}
+
+// sums [K][2][D] float64
+extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows, int D, double* sums, void* ws, void* stream) {
+  if (!pack_ok((const void* const*)y_host, K)) return MRG_E_SHAPE;
+  if (rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (!sums) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PtrPack ys{};
+  bool al = true;
+  for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  RowGeom g = row_geom(D, al);
+  if (!g.ok) return MRG_E_SHAPE;
+  int grid = 1;
+#define CALL(V, L, KM)                                                                                    \
+  do {                                                                                                    \
+    grid = mix_grid(rows, L);                                                                             \
+    hipLaunchKernelGGL((mix_colstats_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws); \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  int len = K * 2 * D;
+  hipLaunchKernelGGL((mix_reduce_k<double>), dim3((len + 255) / 256), dim3(256), 0, st, (const double*)ws, sums, grid, len);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// coef [K][4][D]; gamma/beta/running_mean/running_var: host arrays of K device pointers (entries may be NULL)
+extern "C" int mrg_mix_finalize_fwd(const double* sums, const float* const* gamma_host, const float* const* beta_host,
+                                    float* const* rmean_host, float* const* rvar_host, int K, double total_rows, int D,
+                                    float eps, float momentum, float* coef, void* stream) {
+  if (K < 1 || K > MRG_MIX_MAXK || D <= 0 || total_rows < 0) return MRG_E_SHAPE;
+  if (!sums || !coef || !gamma_host || !beta_host) return MRG_E_NULLPTR;
+  PtrPack ga{}, be{};
+  MutPack rm{}, rv{};
+  for (int k = 0; k < K; ++k) {
+    ga.p[k] = gamma_host[k]; be.p[k] = beta_host[k];
+    rm.p[k] = rmean_host ? rmean_host[k] : nullptr;
+    rv.p[k] = rvar_host ? rvar_host[k] : nullptr;
+    if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
+  }
+  hipLaunchKernelGGL(mix_finalize_fwd_k, dim3((D + 127) / 128, K), dim3(128), 0, (hipStream_t)stream, sums, ga, be, rm, rv, K,
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef, const float* w, float* out, int64_t rows, int D,
+                           void* stream) {
+  if (!pack_ok((const void* const*)y_host, K) || rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (rows == 0) return MRG_OK;
+  if (!coef || !w || !out) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  PtrPack ys{};
+  bool al = aligned16(out);
+  for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  RowGeom g = row_geom(D, al);
+  if (!g.ok) return MRG_E_SHAPE;
+  size_t lds = (size_t)K * 2 * D * sizeof(float);
+  if (lds > 64 * 1024) return MRG_E_SHAPE;
+#define CALL(V, L, KM)                                                                                    \
+  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// red [K][3][D] float32
+extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, int K, const float* coef, const float* w, float* red,
+                                  void* ws, int64_t rows, int D, void* stream) {
+  if (!pack_ok((const void* const*)y_host, K) || rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (!coef || !w || !red || (rows > 0 && !g)) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PtrPack ys{};
+  bool al = aligned16(g);
+  for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  RowGeom gm = row_geom(D, al);
+  if (!gm.ok) return MRG_E_SHAPE;
+  int grid = 1;
+#define CALL(V, L, KM)                                                                                    \
+  do {                                                                                                    \
+    grid = mix_grid(rows, L);                                                                             \
+    size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
+    if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
+    if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D); \
+    else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D); \
+  } while (0)
+  MRG_DISPATCH_GEOM(gm, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  int len = K * 3 * D;
+  hipLaunchKernelGGL((mix_reduce_k<float>), dim3((len + 255) / 256), dim3(256), 0, st, (const float*)ws, red, grid, len);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// coef2 [K][2][D]; dgamma/dbeta: host arrays of K device pointers (NULL entries skipped); dw [K]
+extern "C" int mrg_mix_finalize_bwd(const float* red, int K, double total_rows, int D, float* coef2, float* const* dgamma_host,
+                                    float* const* dbeta_host, float* dw, void* stream) {
+  if (K < 1 || K > MRG_MIX_MAXK || D <= 0) return MRG_E_SHAPE;
+  if (!red || !coef2 || !dw) return MRG_E_NULLPTR;
+  MutPack dg{}, db{};
+  for (int k = 0; k < K; ++k) {
+    dg.p[k] = dgamma_host ? dgamma_host[k] : nullptr;
+    db.p[k] = dbeta_host ? dbeta_host[k] : nullptr;
+  }
+  hipLaunchKernelGGL(mix_finalize_bwd_k, dim3(K), dim3(256), 0, (hipStream_t)stream, red, K, total_rows > 0 ? total_rows : 1.0, D,
+                     coef2, dg, db, dw);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, float* const* gy_host, int K, const float* coef,
+                                 const float* coef2, const float* w, int64_t rows, int D, void* stream) {
+  if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (rows == 0) return MRG_OK;
+  if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  PtrPack ys{};
+  MutPack gys{};
+  bool al = aligned16(g);
+  bool any = false;
+  for (int k = 0; k < K; ++k) {
+    ys.p[k] = y_host[k]; gys.p[k] = gy_host[k];
+    al = al && aligned16(y_host[k]) && aligned16(gy_host[k]);
+    any = any || gy_host[k] != nullptr;
+  }
+  if (!any) return MRG_OK;
+  RowGeom gm = row_geom(D, al);
+  if (!gm.ok) return MRG_E_SHAPE;
+  size_t lds = (size_t)K * 6 * D * sizeof(float);
+  if (lds > 64 * 1024) return MRG_E_SHAPE;
+#define CALL(V, L, KM)                                                                                    \
+  hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D)
+  MRG_DISPATCH_GEOM(gm, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

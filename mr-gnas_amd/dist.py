@@ -215,6 +215,8 @@ class ShardedSupernet:
 
     # -- pieces ---------------------------------------------------------------------------
     def _mixed(self, mixed_op, w, h, h_in, total_rows):
+        if h.is_cuda:          # fused HIP epilogue with the statistics all-reduced in between
+            return mixed_op(w, self.s, h, h_in, group=self._stat_group(), total_rows=total_rows)
         out = 0
         for wk, (op, bn, act) in zip(w, mixed_op._ops):
             out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
@@ -237,7 +239,13 @@ class ShardedSupernet:
                 h = h / s.global_in_degree[s.node_lo:s.node_hi].clamp(min=1).to(h.dtype).view(-1, 1)
         return h + x[E:]
 
+    def _stat_group(self):
+        return self.group if self.group is not None else dist.group.WORLD
+
     def _mixed_middle(self, mixed_op, w, h, total_nodes):
+        if h.is_cuda:
+            ys = [self._aggregate(op, name, h) for name, (op, _, _) in zip(OPS.MIDDLE_OPS, mixed_op._ops)]
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in mixed_op._ops], w, self._stat_group(), total_nodes)
         out = 0
         for wk, name, (op, bn, act) in zip(w, OPS.MIDDLE_OPS, mixed_op._ops):
             out = out + wk * act(sync_batch_norm(self._aggregate(op, name, h), bn, total_nodes, self.group))

@@ -385,3 +385,111 @@ def compose_aggregate(kind, X, Y, cp):
     if kind not in ("sub", "mul", "ccorr"):
         raise Exception('Only supports sub, mul, and ccorr')
     return _ComposeAggregate.apply(kind, X, Y, cp)
+
+
+# ---------------------------------------------------------------------------
+# X: MixedOp epilogue   out = sum_k w_k * ReLU(BatchNorm_k(y_k))
+# ---------------------------------------------------------------------------
+class _MixCfg:
+    """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
+    updated in place like torch does), which branches are all-zero, sharding info."""
+
+    def __init__(self, bns, present, group=None, total_rows=None):
+        self.bns, self.present, self.group, self.total_rows = bns, present, group, total_rows
+
+
+class _MixedEpilogue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, w, *tensors):
+        from ._lib import ptr_array
+        K_ = len(cfg.bns)
+        nz = sum(cfg.present)
+        ys_nz = [f32c(t) for t in tensors[:nz]]
+        gam, bet = list(tensors[nz:nz + K_]), list(tensors[nz + K_:nz + 2 * K_])
+        it = iter(ys_nz)
+        ys = [next(it) if p else None for p in cfg.present]
+        ref = ys_nz[0] if ys_nz else None
+        if ref is None:
+            raise _lib.MrgnasError("mixed epilogue needs at least one non-zero branch to know the row count")
+        require_hip(w, *ys_nz, *gam, *bet)
+        rows, D = ref.shape
+        dev, st = ref.device, stream_of(ref)
+        w = f32c(w)
+        total = float(cfg.total_rows if cfg.total_rows is not None else rows)
+        coef = torch.empty(K_, 4, D, dtype=torch.float32, device=dev)
+        ypa = ptr_array(ys)
+        bn0 = cfg.bns[0]
+        training = bn0.training or not bn0.track_running_stats
+        if training:
+            ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), ref)
+            sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
+            call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), st), nbytes=4 * D * rows * nz)
+            if cfg.group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=cfg.group)
+            track = bn0.track_running_stats
+            rm = ptr_array([b.running_mean if track else None for b in cfg.bns])
+            rv = ptr_array([b.running_var if track else None for b in cfg.bns])
+            mom = bn0.momentum if bn0.momentum is not None else 0.1
+            call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
+            if track:
+                for b in cfg.bns:
+                    b.num_batches_tracked += 1
+        else:   # eval: fixed statistics
+            for k, b in enumerate(cfg.bns):
+                invstd = torch.rsqrt(b.running_var + b.eps)
+                coef[k, 0] = gam[k] * invstd
+                coef[k, 1] = bet[k] - b.running_mean * gam[k] * invstd
+                coef[k, 2] = invstd
+                coef[k, 3] = b.running_mean * invstd
+        out = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(out), rows, D, st), nbytes=4 * D * rows * (nz + 1))
+        ctx.cfg, ctx.training, ctx.total, ctx.nz = cfg, training, total, nz
+        ctx.save_for_backward(w, coef, *ys_nz)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import ptr_array
+        w, coef, *ys_nz = ctx.saved_tensors
+        cfg, K_, nz = ctx.cfg, len(ctx.cfg.bns), ctx.nz
+        g = f32c(g)
+        it = iter(ys_nz)
+        ys = [next(it) if p else None for p in cfg.present]
+        rows, D = g.shape
+        dev, st = g.device, stream_of(g)
+        ypa = ptr_array(ys)
+        ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
+        red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
+        call("mrg_mix_bwd_reduce", (ptr(g), ypa, K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, st), nbytes=4 * D * rows * (nz + 1))
+        red_local = red
+        if cfg.group is not None and ctx.training:
+            import torch.distributed as dist
+            red = red.clone()
+            dist.all_reduce(red, group=cfg.group)
+        coef2 = torch.empty(K_, 2, D, dtype=torch.float32, device=dev)
+        dw = torch.empty(K_, dtype=torch.float32, device=dev)
+        call("mrg_mix_finalize_bwd", (ptr(red), K_, ctx.total, D, ptr(coef2), None, None, ptr(dw), st))
+        if not ctx.training:
+            coef2.zero_()
+        if red_local is not red:                      # sharded: parameter / alpha gradients stay local partial sums
+            dw = red_local[:, 2].sum(dim=1)
+        need_y = ctx.needs_input_grad[2:2 + nz]
+        gys_nz = [torch.empty_like(y) if nd else None for y, nd in zip(ys_nz, need_y)]
+        it = iter(gys_nz)
+        gys = [next(it) if p else None for p in cfg.present]
+        n_out = sum(t is not None for t in gys_nz)
+        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rows, D, st),
+             nbytes=4 * D * rows * (1 + nz + n_out))
+        dgam = [red_local[k, 1] for k in range(K_)]
+        dbet = [red_local[k, 0] for k in range(K_)]
+        return (None, dw, *gys_nz, *dgam, *dbet)
+
+
+def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
+    """sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
+    all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine)."""
+    present = [y is not None for y in ys]
+    cfg = _MixCfg(list(bns), present, group, total_rows)
+    tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns]
+    return _MixedEpilogue.apply(cfg, w, *tensors)

@@ -54,11 +54,17 @@ class MixedOp(nn.Module):
         self._ops = nn.ModuleList(nn.ModuleList([registry[name](args), nn.BatchNorm1d(feature_dim), nn.ReLU()])
                                   for name in operations)
 
-    def forward(self, weights, g, h, h_in):
-        total = 0
-        for w, (op, bn, act) in zip(weights, self._ops):
-            total = total + w * act(bn(op(g, h, h_in).float()))
-        return total
+    def forward(self, weights, g, h, h_in, group=None, total_rows=None):
+        """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
+        BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
+        materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
+        if not h.is_cuda:                     # reference formulation (registry of non-HIP test operators)
+            total = 0
+            for w, (op, bn, act) in zip(weights, self._ops):
+                total = total + w * act(bn(op(g, h, h_in).float()))
+            return total
+        ys = [None if isinstance(op, OPS.f_zero_op) else op(g, h, h_in) for op, _, _ in self._ops]
+        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
 
 
 class _Stage(nn.Module):

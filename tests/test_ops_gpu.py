@@ -174,3 +174,41 @@ def test_linear_mfma_shapes():
             close(xd.grad, xr.grad, "linear gx", rtol=2e-5, atol=2e-5)
             close(Wd.grad, Wr.grad, "linear gW", rtol=5e-5, atol=5e-5)
             close(bd.grad, br.grad, "linear gb", rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("rows,D,present", [(3000, 200, [0, 1, 1, 1, 1]), (777, 64, [1, 1, 1]), (100, 10, [1, 0, 1, 1]),
+                                            (5000, 256, [1, 1, 1, 1, 1, 1, 1, 1]), (64, 512, [1, 1])])
+def test_mixed_epilogue_matches_bn_relu_sum(rows, D, present):
+    """Fused MixedOp epilogue vs the reference formulation sum_k w_k relu(BatchNorm1d_k(y_k))
+    (reference models/cell_lp.py:25-33) evaluated by torch in float64 on the CPU."""
+    gen = torch.Generator().manual_seed(rows + D)
+    Kb = len(present)
+    ys = [torch.randn(rows, D, generator=gen) * (1 + k) + 0.5 * k if p else None for k, p in enumerate(present)]
+    gam = [torch.rand(D, generator=gen) + 0.5 for _ in range(Kb)]
+    bet = [torch.randn(D, generator=gen) * 0.3 for _ in range(Kb)]
+    w = torch.softmax(torch.randn(Kb, generator=gen), 0)
+    gout = torch.randn(rows, D, generator=gen)
+    # reference (float64, torch BN in training mode)
+    yr = [(y if y is not None else torch.zeros(rows, D)).double().requires_grad_(True) for y in ys]
+    gr_, br_, wr = [t.double().requires_grad_(True) for t in gam], [t.double().requires_grad_(True) for t in bet], w.double().requires_grad_(True)
+    ref = sum(wr[k] * torch.relu(torch.nn.functional.batch_norm(yr[k], None, None, gr_[k], br_[k], training=True)) for k in range(Kb))
+    ref.backward(gout.double())
+    # HIP
+    bns = [torch.nn.BatchNorm1d(D).to(DEV) for _ in range(Kb)]
+    for k, b in enumerate(bns):
+        b.weight.data.copy_(gam[k]); b.bias.data.copy_(bet[k]); b.train()
+    yd = [y.to(DEV).requires_grad_(True) if y is not None else None for y in ys]
+    wd = w.to(DEV).requires_grad_(True)
+    out = K.mixed_epilogue(yd, bns, wd)
+    out.backward(gout.to(DEV))
+    close(out, ref.float().detach(), "mixed out", rtol=2e-5, atol=2e-5)
+    close(wd.grad, wr.grad.float(), "mixed dw", rtol=1e-4, atol=1e-3)
+    for k in range(Kb):
+        close(bns[k].weight.grad, gr_[k].grad.float(), f"dgamma {k}", rtol=1e-4, atol=2e-4)
+        close(bns[k].bias.grad, br_[k].grad.float(), f"dbeta {k}", rtol=1e-4, atol=2e-4)
+        if ys[k] is not None:
+            close(yd[k].grad, yr[k].grad.float(), f"dy {k}", rtol=1e-4, atol=2e-6)
+            ref_bn = torch.nn.BatchNorm1d(D).double()
+            ref_bn.train(); ref_bn(ys[k].double())
+            close(bns[k].running_mean, ref_bn.running_mean.float(), f"running_mean {k}", rtol=1e-5, atol=1e-6)
+            close(bns[k].running_var, ref_bn.running_var.float(), f"running_var {k}", rtol=1e-5, atol=1e-6)
