@@ -107,6 +107,32 @@ inline RowGeom row_geom(int D, bool all_aligned) {
     else if ((L) == 64) { CALL(V, 64, 4); }                                    \
   } while (0)
 
+// Deterministic second stage of the two-stage reductions: out[t] = sum_b ws[(b0 + b) * ld + t],
+// b < nb.  A 64 x 16 thread block owns 64 consecutive t; thread row ty sums the partials
+// b = ty, ty + 16, ... (coalesced along t), then the 16 row sums are added in order.
+template <typename T>
+__global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, int b0, int nb, int ld, int len) {
+  __shared__ T part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  T acc = 0;
+  if (t < len)
+    for (int b = ty; b < nb; b += 16) acc += ws[(int64_t)(b0 + b) * ld + t];
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && t < len) {
+    T tot = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tot += part[i][tx];
+    out[t] = tot;
+  }
+}
+
+template <typename T>
+inline void launch_ordered_reduce(const T* ws, T* out, int b0, int nb, int ld, int len, hipStream_t st) {
+  hipLaunchKernelGGL((ordered_reduce_k<T>), dim3((len + 63) / 64), dim3(1024), 0, st, ws, out, b0, nb, ld, len);
+}
+
 inline int grid_for(int64_t work_items, int items_per_block) {
   int64_t b = (work_items + items_per_block - 1) / items_per_block;
   if (b < 1) b = 1;

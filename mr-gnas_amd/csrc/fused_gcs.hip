@@ -201,7 +201,7 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
       default: LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCONV); break;                                                      \
     }                                                                                                                  \
     if (n_hubs > 0) {                                                                                                  \
-      int gh = grid_for(n_hubs, MRG_BLOCK / L);                                                                        \
+      int gh = n_hubs < 4096 ? (int)n_hubs : 4096;                                                                        \
       hipLaunchKernelGGL((seg_hub_k<V, L, K, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, (const float*)nullptr, hub_node, \
                          hub_first, hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0); \
     }                                                                                                                  \

@@ -196,18 +196,27 @@ __global__ void gate_reduce_k(const float* __restrict__ ws, float* __restrict__ 
   d_uvc[seg * ld + t] = acc;
 }
 
-// uvc[k] = sum_j W[j,k] a[j]  (k < in_dim);  uvc[in_dim] = sum_j a[j] b[j]
+// uvc[k] = sum_j W[j,k] a[j]  (k < in_dim);  uvc[in_dim] = sum_j a[j] b[j].
+// 64 x 16 threads per 64 columns: thread row ty sums j = ty, ty+16, ... (coalesced along k).
 __global__ void gate_collapse_k(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ a,
                                 float* __restrict__ uvc, int D, int in_dim) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > in_dim) return;
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + tx;
   float acc = 0.f;
   if (k < in_dim) {
-    for (int j = 0; j < D; ++j) acc += W[(int64_t)j * in_dim + k] * a[j];
-  } else if (b) {
-    for (int j = 0; j < D; ++j) acc += a[j] * b[j];
+    for (int j = ty; j < D; j += 16) acc += W[(int64_t)j * in_dim + k] * a[j];
+  } else if (k == in_dim && b) {
+    for (int j = ty; j < D; j += 16) acc += a[j] * b[j];
   }
-  uvc[k] = acc;
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && k <= in_dim) {
+    float tot = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tot += part[i][tx];
+    uvc[k] = tot;
+  }
 }
 
 // one block per output row j of W
@@ -242,7 +251,7 @@ using namespace mrg;
 extern "C" int mrg_gate_collapse(const float* W, const float* b, const float* a, float* uvc, int D, int in_dim, void* stream) {
   if (!W || !a || !uvc) return MRG_E_NULLPTR;
   if (D <= 0 || in_dim <= 0) return MRG_E_SHAPE;
-  hipLaunchKernelGGL(gate_collapse_k, dim3((in_dim + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, b, a, uvc, D, in_dim);
+  hipLaunchKernelGGL(gate_collapse_k, dim3((in_dim + 1 + 63) / 64), dim3(1024), 0, (hipStream_t)stream, W, b, a, uvc, D, in_dim);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -310,7 +319,8 @@ extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gate_reduce_k, dim3((ld + 255) / 256, 3), dim3(256), 0, st, (const float*)ws, d_uvc, p, ld);
+  for (int seg = 0; seg < 3; ++seg)
+    launch_ordered_reduce<float>((const float*)ws, d_uvc + seg * ld, p.blk[seg], p.blk[seg + 1] - p.blk[seg], ld, ld, st);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

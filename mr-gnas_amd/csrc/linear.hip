@@ -191,16 +191,26 @@ __global__ __launch_bounds__(MRG_BLOCK) void linear_wgrad_k(const float* __restr
   }
 }
 
-// gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order
+// gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
+// thread row ty sums the partial tiles g = ty, ty+16, ..., the 16 row sums are added in order.
 __global__ void linear_wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
                                       int G, int K, int Nout, int ldg, int ldx) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = blockIdx.y;
-  if (c > K || n >= Nout) return;
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int n = blockIdx.y;
   float acc = 0.f;
-  for (int g = 0; g < G; ++g) acc += ws[((int64_t)g * ldg + n) * ldx + c];
-  if (c < K) gW[(int64_t)n * K + c] = acc;
-  else if (gbias) gbias[n] = acc;
+  if (c <= K)
+    for (int g = ty; g < G; g += 16) acc += ws[((int64_t)g * ldg + n) * ldx + c];
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c <= K) {
+    float tot = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tot += part[i][tx];
+    if (c < K) gW[(int64_t)n * K + c] = tot;
+    else if (gbias) gbias[n] = tot;
+  }
 }
 
 static int pick_nt(int ncols) {
@@ -319,7 +329,7 @@ extern "C" int mrg_linear_bwd_weight(const float* gY, const float* X, float* gW,
   }
 #undef GO
   MRG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(linear_wgrad_reduce_k, dim3((K + 1 + 255) / 256, Nout), dim3(256), 0, st, (const float*)ws, gW, gbias,
+  hipLaunchKernelGGL(linear_wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias,
                      p.G, K, Nout, p.TM * 32, p.TN * 32);
   MRG_LAUNCH_CHECK();
   return MRG_OK;

@@ -327,7 +327,7 @@ extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows,
 #undef CALL
   MRG_LAUNCH_CHECK();
   int len = K * 2 * D;
-  hipLaunchKernelGGL((mix_reduce_k<double>), dim3((len + 255) / 256), dim3(256), 0, st, (const double*)ws, sums, grid, len);
+  launch_ordered_reduce<double>((const double*)ws, sums, 0, grid, len, len, st);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -398,7 +398,7 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
 #undef CALL
   MRG_LAUNCH_CHECK();
   int len = K * 3 * D;
-  hipLaunchKernelGGL((mix_reduce_k<float>), dim3((len + 255) / 256), dim3(256), 0, st, (const float*)ws, red, grid, len);
+  launch_ordered_reduce<float>((const float*)ws, red, 0, grid, len, len, st);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

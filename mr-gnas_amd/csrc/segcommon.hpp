@@ -68,6 +68,9 @@ __device__ __forceinline__ void finalize_row(Acc<VEC, LPR, KMAX, IS_MAX>& acc, i
   }
 }
 
+// Combine of the partial results of a split (hub) list: one workgroup per hub.  The RPB lane
+// groups take contiguous ranges of the hub's partial slots (8 loads in flight each) and their
+// sums are combined in range order through LDS -- a fixed association, bitwise reproducible.
 template <int VEC, int LPR, int KMAX, bool IS_MAX>
 __global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__ self_rows, const int32_t* __restrict__ hub_node,
                                                        const int32_t* __restrict__ hub_first, const int32_t* __restrict__ hub_count,
@@ -76,27 +79,72 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__
                                                        const float* __restrict__ ws_val, const int32_t* __restrict__ ws_arg,
                                                        int D, int is_mean) {
   constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  constexpr int U = 8;
+  __shared__ float sval[RPB * WIDTH];
+  __shared__ int32_t sarg[IS_MAX ? RPB * WIDTH : 1];
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
-  for (int64_t h = (int64_t)blockIdx.x * RPB + rw; h < n_hubs; h += (int64_t)gridDim.x * RPB) {
+  for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
     const int v = hub_node[h], s0 = hub_first[h], cnt = hub_count[h];
+    const int per = (cnt + RPB - 1) / RPB;
+    const int q0 = rw * per < cnt ? rw * per : cnt, q1 = q0 + per < cnt ? q0 + per : cnt;
     Acc<VEC, LPR, KMAX, IS_MAX> acc;
     acc.init();
-    for (int q = 0; q < cnt; ++q) {
+    for (int q = q0; q < q1; q += U) {
+      Vec<VEC> x[U][KMAX];
+      IVec<VEC> a[U][KMAX];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        int c = sl + k * LPR;
-        if (c < dv) {
-          Vec<VEC> x = Vec<VEC>::load(ws_val + (int64_t)(s0 + q) * D + c * VEC);
-          IVec<VEC> a = IVec<VEC>::fill(-1);
-          if (IS_MAX) a = IVec<VEC>::load(ws_arg + (int64_t)(s0 + q) * D + c * VEC);
-          acc.take_partial(k, x, a);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (q + u < q1 && c < dv) {
+            x[u][k] = Vec<VEC>::load(ws_val + (int64_t)(s0 + q + u) * D + c * VEC);
+            a[u][k] = IS_MAX ? IVec<VEC>::load(ws_arg + (int64_t)(s0 + q + u) * D + c * VEC) : IVec<VEC>::fill(-1);
+          }
         }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (q + u < q1) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (sl + k * LPR < dv) acc.take_partial(k, x[u][k], a[u][k]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        sval[rw * WIDTH + c * VEC + j] = acc.val[k][j];
+        if (IS_MAX) sarg[rw * WIDTH + c * VEC + j] = acc.arg[k][j];
       }
     }
-    finalize_row<VEC, LPR, KMAX, IS_MAX>(acc, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
+    __syncthreads();
+    if (rw == 0) {
+      Acc<VEC, LPR, KMAX, IS_MAX> tot;
+      tot.init();
+      for (int g = 0; g < RPB; ++g) {
+        if (g * per < cnt) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            int c = sl + k * LPR;
+            Vec<VEC> xv;
+            IVec<VEC> av = IVec<VEC>::fill(-1);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              xv[j] = sval[g * WIDTH + c * VEC + j];
+              if (IS_MAX) av[j] = sarg[g * WIDTH + c * VEC + j];
+            }
+            tot.take_partial(k, xv, av);
+          }
+        }
+      }
+      finalize_row<VEC, LPR, KMAX, IS_MAX>(tot, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
+    }
   }
 }
-
 
 }  // namespace mrg

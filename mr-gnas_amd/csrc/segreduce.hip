@@ -139,7 +139,7 @@ extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_
     else                                                                                                               \
       hipLaunchKernelGGL((seg_chunk_k<V, L, K, false>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
     if (n_hubs > 0) {                                                                                                  \
-      int gh = grid_for(n_hubs, MRG_BLOCK / L);                                                                        \
+      int gh = n_hubs < 4096 ? (int)n_hubs : 4096;                                                                        \
       if (mode == MRG_REDUCE_MAX)                                                                                      \
         hipLaunchKernelGGL((seg_hub_k<V, L, K, true>), dim3(gh), dim3(MRG_BLOCK), 0, st, self_rows, hub_node, hub_first, hub_count, n_hubs, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
       else                                                                                                             \
