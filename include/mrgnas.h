@@ -201,8 +201,10 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  * Y[rows, Nout] = act(X[rows, K] W[Nout, K]^T + bias) */
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y,
                    int64_t rows, int K, int Nout, int act, void *stream);
-/* gX[rows, K] = gY[rows, Nout] W[Nout, K]   (gY already masked by the activation) */
-int mrg_linear_bwd_input(const float *gY, const float *W, float *gX,
+/* gX[rows, K] = gY[rows, Nout] W[Nout, K]   (gY already masked by the activation);
+ * ws holds W^T (mrg_linear_bwd_input_workspace_bytes). */
+int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout);
+int mrg_linear_bwd_input(const float *gY, const float *W, float *gX, void *ws,
                          int64_t rows, int K, int Nout, void *stream);
 /* gW[Nout, K] = gY^T X,  gbias[Nout] = column sums of gY (NULL ok). */
 int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout);

@@ -1,0 +1,293 @@
+// Software-pipelined tall-skinny GEMM core on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   C[rows, N] = epilogue( [A1 | A2][rows, K1+K2] * B[N, K1+K2]^T )
+//
+// rows ~ 5e5, N and K ~ 2e2..4e2: 2*rows*K*N flop over 4*rows*(K+N) bytes is ~100 flop/B, far above
+// the f32-MFMA ridge (157 TF/s / 8 TB/s ~ 20 flop/B), so the matrix pipe is the roofline.
+//
+// Geometry (wave = 64 lanes): a 256-thread workgroup owns 128 rows x NT*32 columns; wave w owns
+// rows [32w, 32w+32) and all NT column tiles of 32x32 (NT*16 accumulator registers), so A is read
+// from HBM exactly once.  Registers are held to <= 256 per lane so that TWO workgroups share a CU:
+// one workgroup's prologue / epilogue overlaps the other's MFMA phase.
+// K is walked in tiles of 16: while the 8*NT MFMAs (64 cycles each) of tile t run, the global
+// loads of tile t+1 are already in flight into registers (issued branch-free from clamped
+// addresses; masking happens when they are written to the other LDS buffer after the MFMAs),
+// one barrier per tile.  LDS tiles are k-contiguous with a 4-float pad (row stride 20 floats):
+// the ds_read_b128 fragment reads are bank-conflict free; one ds_read_b128 (4 consecutive k)
+// feeds 4 MFMAs; the fragments of step t+1 are read while the MFMAs of step t issue.
+// Measured (MI355X, rows 544k, K = N = 200): 66-68 TF/s (rocBLAS sgemm via torch: 38.6 TF/s);
+// with 13 barriers per workgroup and lock-stepped partners the matrix pipe is ~55 % busy.
+// "Dual source": the reduction dimension may be the concatenation of two row-major tensors
+// (the reference's torch.cat([s, s_in], dim=1) is never materialised).
+#pragma once
+#include "common.hpp"
+
+namespace mrg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GBM_MAX = 256;      // rows per workgroup = 128 * MT (MT row tiles of 32 per wave)
+
+enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3 };
+
+struct GemmArgs {
+  const float* A1; const float* A2;   // [rows][K1], [rows][K2] row-major; A2 may be NULL (K2 = 0)
+  int K1, K2;
+  const float* B; int ldb;            // [N][ldb] row-major, columns [0, K1+K2) are used
+  const float* bias;                  // [N] or NULL
+  float* C; int ldc; int N;           // output [rows][ldc], N valid columns
+  int64_t rows;
+  int act;                            // EPI_BIAS_ACT: MRG_ACT_*
+  const float* S; int ld_s;           // EPI_GATE: C = sigmoid(acc + bias) * S[row][col] * c_row
+  const float* rowscale; float scale; // c_row = scale * (rowscale ? rowscale[row] : 1)     (EPI_GATE, EPI_SCALE)
+  float* aux;                         // EPI_GATE: optional store of sigmoid(acc + bias), [rows][N]
+  const float* Cin; int ld_cin;       // EPI_ACCUM: C = acc + Cin
+};
+
+// Branch-free guarded loads, split in two halves so the data is not needed until the tile is
+// written to LDS (after the MFMAs of the previous tile):
+//   gemm_raw4   issues the load from a clamped, always valid address -- no branch, no use of the data
+//               (hipcc turns a load inside a data-dependent branch into branch + load + vmcnt(0));
+//   gemm_mask4  zeroes the lanes that were out of range, at stash time.
+//   VEC4: K % 4 == 0 and 16-byte aligned rows -> one global_load_dwordx4 per call.
+template <bool VEC4>
+__device__ __forceinline__ float4 gemm_raw4(const float* __restrict__ base, int64_t row, int64_t nrows, int k, int K, int ld) {
+  const int64_t rc = row < nrows ? row : nrows - 1;
+  const float* p = base + rc * ld;
+  if (VEC4) {
+    const int kc = k + 4 <= K ? k : (K >= 4 ? K - 4 : 0);
+    return *reinterpret_cast<const float4*>(p + kc);
+  }
+  const int km = K - 1;
+  return make_float4(p[k < K ? k : km], p[k + 1 < K ? k + 1 : km], p[k + 2 < K ? k + 2 : km], p[k + 3 < K ? k + 3 : km]);
+}
+
+template <bool VEC4>
+__device__ __forceinline__ float4 gemm_mask4(float4 v, int64_t row, int64_t nrows, int k, int K) {
+  const bool rv = row < nrows;
+  if (VEC4) {
+    const bool ok = rv && k + 4 <= K;
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+  } else {
+    v.x = (rv && k < K) ? v.x : 0.f; v.y = (rv && k + 1 < K) ? v.y : 0.f;
+    v.z = (rv && k + 2 < K) ? v.z : 0.f; v.w = (rv && k + 3 < K) ? v.w : 0.f;
+  }
+  return v;
+}
+
+// the concatenated operand [A1 | A2] (K1 % 4 == 0 whenever K2 > 0; the host passes A2 = A1 when
+// there is no second source): which tensor / local column a global column k maps to
+struct ASel { const float* base; int ld, kk; };
+__device__ __forceinline__ ASel gemm_sel_a(const GemmArgs& a, int k) {
+  const bool first = k < a.K1 || a.K2 == 0;
+  ASel s;
+  s.base = first ? a.A1 : a.A2;
+  s.ld = first ? a.K1 : a.K2;
+  s.kk = first ? k : k - a.K1;
+  return s;
+}
+
+template <int NT, int MT, int GBK, int EPI, bool VEC4>
+__global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmArgs a) {
+  constexpr int GBM = 128 * MT;
+  constexpr int GLD = GBK + 4;                 // padded LDS row stride (floats)
+  constexpr int F4R = GBK / 4;                 // float4 per tile row
+  constexpr int NA = GBM * F4R / MRG_BLOCK;    // A float4 per thread per tile
+  constexpr int NBT = NT * 32 * F4R;           // B float4 per tile
+  constexpr int NB = (NBT + MRG_BLOCK - 1) / MRG_BLOCK;
+  extern __shared__ __align__(16) float smem[];
+  constexpr int A_TILE = GBM * GLD, B_TILE = NT * 32 * GLD, STAGE = A_TILE + B_TILE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * GBM;
+  const int col0 = blockIdx.y * (NT * 32);
+  const int K = a.K1 + a.K2;
+  const int nkt = (K + GBK - 1) / GBK;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  float4 pa[NA];
+  float4 pb[NB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      const ASel sa = gemm_sel_a(a, k0 + (f % F4R) * 4);
+      pa[i] = gemm_raw4<VEC4>(sa.base, row0 + f / F4R, a.rows, sa.kk, sa.ld, sa.ld);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      f = f < NBT ? f : NBT - 1;
+      pb[i] = gemm_raw4<VEC4>(a.B, col0 + f / F4R, a.N, k0 + (f % F4R) * 4, K, a.ldb);
+    }
+  };
+  auto stash = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      const ASel sa = gemm_sel_a(a, k0 + (f % F4R) * 4);
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + (f / F4R) * GLD + (f % F4R) * 4]) =
+          gemm_mask4<VEC4>(pa[i], row0 + f / F4R, a.rows, sa.kk, sa.ld);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      if (f < NBT)
+        *reinterpret_cast<float4*>(&smem[buf * STAGE + A_TILE + (f / F4R) * GLD + (f % F4R) * 4]) =
+            gemm_mask4<VEC4>(pb[i], col0 + f / F4R, a.N, k0 + (f % F4R) * 4, K);
+    }
+  };
+
+  fetch(0);
+  stash(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * GBK;
+    if (kt + 1 < nkt) fetch(k0 + GBK);                 // in flight during the MFMAs below
+    const int kv = K - k0 < GBK ? K - k0 : GBK;
+    const int nt8 = (kv + 7) >> 3;
+    const float* At = smem + cur * STAGE + (wave * 32 * MT + li) * GLD + lh * 4;
+    const float* Bt = smem + cur * STAGE + A_TILE + li * GLD + lh * 4;
+    // fragment reads of step t+1 are issued before the MFMAs of step t (register double buffer)
+    float4 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[0][m] = *reinterpret_cast<const float4*>(At + m * 32 * GLD);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const float4*>(Bt + n * 32 * GLD);
+#pragma unroll
+    for (int t = 0; t < GBK / 8; ++t) {
+      if (t < nt8) {
+        const int c = t & 1, nx = c ^ 1;
+        if (t + 1 < GBK / 8) {               // harmless over-read of zero-filled columns when t + 1 >= nt8
+#pragma unroll
+          for (int m = 0; m < MT; ++m) af[nx][m] = *reinterpret_cast<const float4*>(At + m * 32 * GLD + (t + 1) * 8);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[nx][n] = *reinterpret_cast<const float4*>(Bt + n * 32 * GLD + (t + 1) * 8);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][m].x, bf[c][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][m].y, bf[c][n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][m].z, bf[c][n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][m].w, bf[c][n].w, acc[m][n], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) {
+      stash(cur ^ 1, k0 + GBK);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue.  C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  const bool full = row0 + GBM <= a.rows;          // every row of this workgroup exists: no per-element bound check
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 32 + li;
+    if (col < a.N) {
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + wave * 32 * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (full || row < a.rows) {
+            float v = acc[m][n][r] + bv;
+            if (EPI == EPI_BIAS_ACT) {
+              if (a.act == MRG_ACT_RELU) v = v > 0.f ? v : 0.f;
+            } else if (EPI == EPI_GATE) {
+              const float gate = sigmoidf_fast(v);
+              if (a.aux) a.aux[row * a.N + col] = gate;
+              const float c = a.scale * (a.rowscale ? a.rowscale[row] : 1.0f);
+              v = gate * a.S[row * a.ld_s + col] * c;
+            } else if (EPI == EPI_SCALE) {
+              v = v * (a.scale * (a.rowscale ? a.rowscale[row] : 1.0f));
+            } else {
+              v = v + a.Cin[row * a.ld_cin + col];
+            }
+            a.C[row * a.ldc + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+inline int gemm_pick_nt(int ncols) {
+  int t = (ncols + 31) / 32;
+  if (t <= 1) return 1;
+  if (t <= 2) return 2;
+  if (t <= 4) return 4;
+  return 7;                          // wider outputs use several column blocks of 224
+}
+
+inline size_t gemm_lds_bytes(int nt, int mt, int bk) { return (size_t)2 * (128 * mt + nt * 32) * (bk + 4) * sizeof(float); }
+
+template <int EPI>
+inline int launch_rowgemm(GemmArgs a, hipStream_t st) {
+  if (a.rows <= 0) return MRG_OK;
+  if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
+  if (a.K2 > 0 && (a.K1 % 4 != 0)) return MRG_E_SHAPE;
+  const bool vec = (a.K1 % 4 == 0) && (a.K2 % 4 == 0) && (a.ldb % 4 == 0) && ((a.K1 + a.K2) % 4 == 0) && aligned16(a.A1) &&
+                   aligned16(a.A2) && aligned16(a.B) && a.K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
+  const int nt = gemm_pick_nt(a.N);
+  const int mt = 1;
+  const int gbm = 128 * mt;
+  dim3 grid((unsigned)((a.rows + gbm - 1) / gbm), (unsigned)((a.N + nt * 32 - 1) / (nt * 32)));
+  const size_t lds = gemm_lds_bytes(nt, mt, mt == 2 ? 32 : 16);
+#define MRG_GO1(NTV, MTV, BKV, VV)                                                                                         \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_k<NTV, MTV, BKV, EPI, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((rowgemm_k<NTV, MTV, BKV, EPI, VV>), grid, dim3(MRG_BLOCK), lds, st, a);                             \
+  } while (0)
+#define MRG_GO(NTV)                                                                                                   \
+  do {                                                                                                                \
+    if (vec) MRG_GO1(NTV, 1, 16, true);                                                                               \
+    else MRG_GO1(NTV, 1, 16, false);                                                                                  \
+  } while (0)
+  switch (nt) {
+    case 1: MRG_GO(1); break;
+    case 2: MRG_GO(2); break;
+    case 4: MRG_GO(4); break;
+    default: MRG_GO(7); break;
+  }
+#undef MRG_GO
+#undef MRG_GO1
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MRG_OK : (int)e;
+}
+
+// Bt[c][r] = B[r][c]  (small weight matrices; used to present W^T row-major to the core)
+__global__ void transpose_k(const float* __restrict__ B, float* __restrict__ Bt, int rows, int cols, int ldb) {
+  __shared__ float tile[32][33];
+  int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y)
+    if (r0 + i < rows && c < cols) tile[i][threadIdx.x] = B[(int64_t)(r0 + i) * ldb + c];
+  __syncthreads();
+  int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y)
+    if (c0 + i < cols && r < rows) Bt[(int64_t)(c0 + i) * rows + r] = tile[threadIdx.x][i];
+}
+
+inline void launch_transpose(const float* B, float* Bt, int rows, int cols, int ldb, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_k, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, B, Bt, rows, cols, ldb);
+}
+
+}  // namespace mrg

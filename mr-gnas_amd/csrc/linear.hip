@@ -1,166 +1,106 @@
-// Dense linears on edge / node rows with exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+// Dense linears on edge / node rows with exact-f32 MFMA (core: gemm.hpp).
 //   nn.Linear inside a_max_op / a_mean_op: reference models/operations_lp.py:228,231,243,246
 //   W_O / W_I / W_S / W_R of CompGraphConv:  reference models/compgcn.py:36-41,77-78,100,103
-// These are tall-skinny GEMMs (rows ~ 5e5, K and Nout ~ 2e2): 2*rows*K*Nout flop against
-// 4*rows*(K+Nout) bytes is ~100 flop/B at D = 200, above the f32-MFMA ridge (157 TF/s over
-// 8 TB/s ~ 20 flop/B), so the roofline here is the matrix pipe, not HBM.
-//
-// Tiling (wave = 64 lanes): a workgroup of 4 waves owns 128 rows x (NT*32) columns; wave w
-// owns rows [32w, 32w+32) and all NT column tiles, so X is read from HBM exactly once.
-// LDS tiles are k-contiguous with a 4-float pad (stride 36): the ds_read_b128 fragment reads
-// (4 consecutive k per lane -> 4 MFMAs) and the staging ds_write_b128 are bank-conflict-free.
-#include "common.hpp"
+// forward / input-gradient use the pipelined row GEMM; the weight gradient is a split-over-rows
+// GEMM (each workgroup reduces a chunk of rows into register-resident output tiles, partial
+// tiles are combined in a fixed order), also software-pipelined, and optionally dual-source.
+#include "gemm.hpp"
 
 namespace mrg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Weight gradient: partial[g][n][c] = sum over the workgroup's rows r of gY[r][n] * X'[r][c],
+// X' = [X1 | X2 | 1] (the appended column of ones yields the bias gradient for free).
+constexpr int WBR = 16;    // rows per LDS tile
 
-constexpr int LBM = 128;   // rows per workgroup
-constexpr int LBK = 32;    // k per LDS tile
-constexpr int LLD = LBK + 4;
+struct WgradArgs {
+  const float* gY; int Nout;                 // [rows][Nout]
+  const float* X1; const float* X2; int K1, K2;
+  float* ws;
+  int64_t rows, rows_per_block;
+  int TM, TN, TNB;
+};
 
-__device__ __forceinline__ float4 ld4_guard(const float* __restrict__ base, int64_t row, int64_t nrows, int k, int K, int64_t ld,
-                                            bool vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < nrows) {
-    const float* p = base + row * ld + k;
-    if (vec_ok && k + 3 < K) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (k < K) v.x = p[0];
-      if (k + 1 < K) v.y = p[1];
-      if (k + 2 < K) v.z = p[2];
-      if (k + 3 < K) v.w = p[3];
-    }
-  }
-  return v;
+// X' = [X1 | X2 | 1 | 0...]: which tensor / local column a global column c maps to
+struct XSel { const float* base; int ld, kk; };
+__device__ __forceinline__ XSel wgrad_sel_x(const WgradArgs& a, int c) {
+  const bool first = c < a.K1 || a.K2 == 0;
+  XSel s;
+  s.base = first ? a.X1 : a.X2;
+  s.ld = first ? a.K1 : a.K2;
+  s.kk = first ? c : c - a.K1;
+  return s;
 }
 
-// C[rows, N] = act(A[rows, K] * B^T + bias),  B given as [N, K] (BT = false, nn.Linear weight)
-// or as [K, N] (BT = true: the same weight used for the input gradient).
-template <int NT, bool BT>
-__global__ __launch_bounds__(MRG_BLOCK) void linear_k(const float* __restrict__ A, const float* __restrict__ B,
-                                                      const float* __restrict__ bias, float* __restrict__ C, int64_t rows,
-                                                      int K, int N, int act, int vecA, int vecB) {
-  __shared__ float As[LBM * LLD];
-  __shared__ float Bs[NT * 32 * LLD];
+template <int TPW, int NPF, bool VEC4>      // TPW accumulator tiles per wave, NPF prefetch float4 per thread
+__global__ __launch_bounds__(MRG_BLOCK) void wgrad_k(WgradArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  const int tn0 = blockIdx.y * a.TNB;
+  const int tnb = a.TN - tn0 < a.TNB ? a.TN - tn0 : a.TNB;
+  const int ldg = a.TM * 32, ldx = a.TNB * 32, stage = WBR * (ldg + ldx);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * LBM;
-  const int col0 = blockIdx.y * (NT * 32);
-  f32x16 acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += LBK) {
-    // ---- stage A: 128 x 32 floats = 1024 float4, 4 per thread
-#pragma unroll
-    for (int i = 0; i < (LBM * LBK / 4) / MRG_BLOCK; ++i) {
-      int idx = tid + i * MRG_BLOCK;
-      int r = idx >> 3, k4 = idx & 7;
-      float4 v = ld4_guard(A, row0 + r, rows, k0 + k4 * 4, K, K, vecA != 0);
-      *reinterpret_cast<float4*>(&As[r * LLD + k4 * 4]) = v;
-    }
-    // ---- stage B
-    if (!BT) {
-#pragma unroll
-      for (int i = 0; i < (NT * 32 * LBK / 4 + MRG_BLOCK - 1) / MRG_BLOCK; ++i) {
-        int idx = tid + i * MRG_BLOCK;
-        if (idx < NT * 32 * LBK / 4) {
-          int j = idx >> 3, k4 = idx & 7;
-          float4 v = ld4_guard(B, col0 + j, N, k0 + k4 * 4, K, K, vecB != 0);
-          *reinterpret_cast<float4*>(&Bs[j * LLD + k4 * 4]) = v;
-        }
-      }
-    } else {
-      // B[k][n] row-major: lanes run along n (coalesced), scatter into the k-contiguous tile
-      for (int e = tid; e < NT * 32 * LBK; e += MRG_BLOCK) {
-        int j = e % (NT * 32), kk = e / (NT * 32);
-        float v = 0.f;
-        if (k0 + kk < K && col0 + j < N) v = B[(int64_t)(k0 + kk) * N + col0 + j];
-        Bs[j * LLD + kk] = v;
-      }
-    }
-    __syncthreads();
-    const int kt = K - k0 < LBK ? K - k0 : LBK;
-    const int nt8 = (kt + 7) >> 3;
-    for (int t = 0; t < nt8; ++t) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + li) * LLD + t * 8 + lh * 4]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float4 b = *reinterpret_cast<const float4*>(&Bs[(n * 32 + li) * LLD + t * 8 + lh * 4]);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[n], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = col0 + n * 32 + li;
-    if (col < N) {
-      const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < rows) {
-          float v = acc[n][r] + bv;
-          if (act == MRG_ACT_RELU) v = v > 0.f ? v : 0.f;
-          C[row * N + col] = v;
-        }
-      }
-    }
-  }
-}
-
-// Weight gradient: partial[g][n][c] = sum over the block's rows r of gY[r][n] * X'[r][c],
-// X' = [X | 1] (the extra column of ones yields the bias gradient for free).
-constexpr int WBR = 32;    // rows per LDS tile
-
-template <int TPW>
-__global__ __launch_bounds__(MRG_BLOCK) void linear_wgrad_k(const float* __restrict__ gY, const float* __restrict__ X,
-                                                            float* __restrict__ ws, int64_t rows, int K, int Nout, int TM,
-                                                            int TN, int TNB, int64_t rows_per_block, int vecG, int vecX) {
-  extern __shared__ float smem[];
-  const int tn0 = blockIdx.y * TNB;                       // first X' column tile of this workgroup
-  const int tnb = TN - tn0 < TNB ? TN - tn0 : TNB;        // column tiles it owns
-  const int ldg = TM * 32, ldx = TNB * 32;
-  float* Gs = smem;                 // [WBR][ldg]
-  float* Xs = smem + WBR * ldg;     // [WBR][ldx]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int ntiles = TM * tnb;
+  const int ntiles = a.TM * tnb;
+  const int g4 = ldg / 4, x4 = ldx / 4, nf4 = WBR * (g4 + x4);      // float4 per staged tile
   f32x16 acc[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR) {
-    // stage gY tile (zero beyond Nout / beyond r_end)
-    for (int idx = tid; idx < WBR * (ldg / 4); idx += MRG_BLOCK) {
-      int r = idx / (ldg / 4), c4 = idx % (ldg / 4);
-      float4 v = ld4_guard(gY, r0 + r, r_end, c4 * 4, Nout, Nout, vecG != 0);
-      *reinterpret_cast<float4*>(&Gs[r * ldg + c4 * 4]) = v;
+  const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r_end = r_begin + a.rows_per_block;
+  if (r_end > a.rows) r_end = a.rows;
+
+  float4 pf[NPF];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      // every lane issues ONE load from a clamped address; which operand it is, is a select
+      const bool isg = f < WBR * g4;
+      const int f2 = isg ? f : (f < nf4 ? f - WBR * g4 : 0);
+      const int per = isg ? g4 : x4;
+      const int r = f2 / per, c4 = f2 - r * per;
+      const XSel sx = wgrad_sel_x(a, tn0 * 32 + c4 * 4);
+      const float* base = isg ? a.gY : sx.base;
+      const int ld = isg ? a.Nout : sx.ld;
+      const int kk = isg ? c4 * 4 : sx.kk;
+      pf[i] = gemm_raw4<VEC4>(base, r0 + r, r_end, kk, ld, ld);
     }
-    // stage the X' tile: columns [tn0*32, tn0*32 + ldx) of [X | 1]
-    for (int idx = tid; idx < WBR * (ldx / 4); idx += MRG_BLOCK) {
-      int r = idx / (ldx / 4), c4 = idx % (ldx / 4);
-      int c = tn0 * 32 + c4 * 4;
-      float4 v = ld4_guard(X, r0 + r, r_end, c, K, K, vecX != 0);
-      if (r0 + r < r_end) {
-        if (c == K) v.x = 1.f; else if (c + 1 == K) v.y = 1.f; else if (c + 2 == K) v.z = 1.f; else if (c + 3 == K) v.w = 1.f;
+  };
+  auto stash = [&](int buf, int64_t r0) {
+    const int K = a.K1 + a.K2;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      int f = tid + i * MRG_BLOCK;
+      if (f < nf4) {
+        const bool isg = f < WBR * g4;
+        const int f2 = isg ? f : f - WBR * g4;
+        const int per = isg ? g4 : x4;
+        const int r = f2 / per, c4 = f2 - r * per;
+        const int c = tn0 * 32 + c4 * 4;
+        const XSel sx = wgrad_sel_x(a, c);
+        float4 v = gemm_mask4<VEC4>(pf[i], r0 + r, r_end, isg ? c4 * 4 : sx.kk, isg ? a.Nout : sx.ld);
+        if (!isg && r0 + r < r_end) {            // the appended column of ones
+          if (c == K) v.x = 1.0f;
+          if (!VEC4) { if (c + 1 == K) v.y = 1.0f; if (c + 2 == K) v.z = 1.0f; if (c + 3 == K) v.w = 1.0f; }
+        }
+        *reinterpret_cast<float4*>(&smem[buf * stage + f * 4]) = v;                    // Gs then Xs, both dense row-major
       }
-      *reinterpret_cast<float4*>(&Xs[r * ldx + c4 * 4]) = v;
     }
-    __syncthreads();
-#pragma unroll 2
+  };
+
+  if (r_begin < r_end) {
+    fetch(r_begin);
+    stash(0, r_begin);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR) {
+    const bool more = r0 + WBR < r_end;
+    if (more) fetch(r0 + WBR);
+    const float* Gs = smem + cur * stage;
+    const float* Xs = Gs + WBR * ldg;
+#pragma unroll 1
     for (int t = 0; t < WBR / 2; ++t) {
       const float* grow = Gs + (2 * t + lh) * ldg + li;
       const float* xrow = Xs + (2 * t + lh) * ldx + li;
@@ -173,10 +113,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void linear_wgrad_k(const float* __restr
         }
       }
     }
-    __syncthreads();
+    if (more) {
+      stash(cur ^ 1, r0 + WBR);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
-  const int ldw = TN * 32;
-  float* out = ws + (int64_t)blockIdx.x * ldg * ldw;
+  const int ldw = a.TN * 32;
+  float* out = a.ws + (int64_t)blockIdx.x * ldg * ldw;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int id = wave + 4 * i;
@@ -193,8 +137,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void linear_wgrad_k(const float* __restr
 
 // gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
 // thread row ty sums the partial tiles g = ty, ty+16, ..., the 16 row sums are added in order.
-__global__ void linear_wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
-                                      int G, int K, int Nout, int ldg, int ldx) {
+__global__ void wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
+                               int G, int K, int Nout, int ldg, int ldx) {
   __shared__ float part[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -213,37 +157,8 @@ __global__ void linear_wgrad_reduce_k(const float* __restrict__ ws, float* __res
   }
 }
 
-static int pick_nt(int ncols) {
-  int t = (ncols + 31) / 32;
-  if (t <= 1) return 1;
-  if (t <= 2) return 2;
-  if (t <= 4) return 4;
-  if (t <= 7) return 7;
-  return 8;
-}
-
-template <bool BT>
-static int launch_linear(const float* A, const float* B, const float* bias, float* C, int64_t rows, int K, int N, int act,
-                         hipStream_t st) {
-  const int nt = pick_nt(N);
-  dim3 grid((unsigned)((rows + LBM - 1) / LBM), (unsigned)((N + nt * 32 - 1) / (nt * 32)));
-  const int vecA = (K % 4 == 0) && aligned16(A);
-  const int vecB = (K % 4 == 0) && aligned16(B);
-#define GO(NTV) hipLaunchKernelGGL((linear_k<NTV, BT>), grid, dim3(MRG_BLOCK), 0, st, A, B, bias, C, rows, K, N, act, vecA, vecB)
-  switch (nt) {
-    case 1: GO(1); break;
-    case 2: GO(2); break;
-    case 4: GO(4); break;
-    case 7: GO(7); break;
-    default: GO(8); break;
-  }
-#undef GO
-  MRG_LAUNCH_CHECK();
-  return MRG_OK;
-}
-
 struct WgradPlan {
-  int TM, TN, TNB, tpw, G;
+  int TM, TN, TNB, tpw, npf, G;
   int64_t rows_per_block;
   size_t lds;
   bool ok;
@@ -259,8 +174,10 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout) {
   const int opts[] = {1, 2, 4, 7, 13};
   p.tpw = 0;
   for (int o : opts) if (per_wave <= o) { p.tpw = o; break; }
-  p.lds = (size_t)WBR * (p.TM + p.TNB) * 32 * sizeof(float);
-  p.ok = p.tpw > 0 && p.lds <= 160 * 1024;
+  int nf4 = WBR * (p.TM + p.TNB) * 8;                    // float4 per staged tile
+  p.npf = (nf4 + MRG_BLOCK - 1) / MRG_BLOCK;
+  p.lds = (size_t)2 * WBR * (p.TM + p.TNB) * 32 * sizeof(float);
+  p.ok = p.tpw > 0 && p.lds <= 160 * 1024 && p.npf <= 16;
   int64_t tiles = (rows + WBR - 1) / WBR;
   int64_t G = tiles < 512 ? tiles : 512;
   if (G < 1) G = 1;
@@ -270,6 +187,59 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout) {
   p.G = (int)((rows + p.rows_per_block - 1) / p.rows_per_block);
   if (p.G < 1) p.G = 1;
   return p;
+}
+
+int64_t wgrad_workspace_bytes(int64_t rows, int K, int Nout) {
+  WgradPlan p = wgrad_plan(rows, K, Nout);
+  return (int64_t)p.G * p.TM * 32 * p.TN * 32 * sizeof(float);
+}
+
+// gW[Nout][K1+K2] = gY^T [X1 | X2], gbias = column sums of gY
+int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int K2, float* gW, float* gbias, void* ws,
+                 int64_t rows, int Nout, hipStream_t st) {
+  const int K = K1 + K2;
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)Nout * K, st);
+    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Nout, st);
+    return (int)e;
+  }
+  WgradPlan p = wgrad_plan(rows, K, Nout);
+  if (!p.ok) return MRG_E_SHAPE;
+  WgradArgs a{};
+  a.gY = gY; a.Nout = Nout; a.X1 = X1; a.X2 = X2; a.K1 = K1; a.K2 = K2; a.ws = (float*)ws;
+  a.rows = rows; a.rows_per_block = p.rows_per_block; a.TM = p.TM; a.TN = p.TN; a.TNB = p.TNB;
+  if (!X2 || K2 == 0) { a.X2 = X1; a.K2 = 0; }
+  const bool vec = (Nout % 4 == 0) && (K1 % 4 == 0) && (a.K2 % 4 == 0) && aligned16(gY) && aligned16(X1) && aligned16(a.X2) &&
+                   Nout >= 4 && K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
+  dim3 grid(p.G, (p.TN + p.TNB - 1) / p.TNB);
+#define GO(T, F)                                                                                                       \
+  do {                                                                                                                 \
+    if (vec) {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k<T, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+      hipLaunchKernelGGL((wgrad_k<T, F, true>), grid, dim3(MRG_BLOCK), p.lds, st, a);                                  \
+    } else {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k<T, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+      hipLaunchKernelGGL((wgrad_k<T, F, false>), grid, dim3(MRG_BLOCK), p.lds, st, a);                                 \
+    }                                                                                                                  \
+  } while (0)
+#define GOF(T)                                                                                                         \
+  do {                                                                                                                 \
+    if (p.npf <= 2) GO(T, 2); else if (p.npf <= 4) GO(T, 4); else if (p.npf <= 8) GO(T, 8); else GO(T, 16);            \
+  } while (0)
+  switch (p.tpw) {
+    case 1: GOF(1); break;
+    case 2: GOF(2); break;
+    case 4: GOF(4); break;
+    case 7: GOF(7); break;
+    default: GOF(13); break;
+  }
+#undef GOF
+#undef GO
+  MRG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias, p.G, K, Nout,
+                     p.TM * 32, p.TN * 32);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
 }
 
 }  // namespace mrg
@@ -282,55 +252,40 @@ extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias,
   if (act != MRG_ACT_NONE && act != MRG_ACT_RELU) return MRG_E_ENUM;
   if (rows == 0) return MRG_OK;
   if (!X || !W || !Y) return MRG_E_NULLPTR;
-  return launch_linear<false>(X, W, bias, Y, rows, K, Nout, act, (hipStream_t)stream);
+  GemmArgs a{};
+  a.A1 = X; a.K1 = K; a.B = W; a.ldb = K; a.bias = bias; a.C = Y; a.ldc = Nout; a.N = Nout; a.rows = rows; a.act = act;
+  return launch_rowgemm<EPI_BIAS_ACT>(a, (hipStream_t)stream);
 }
 
-extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, int64_t rows, int K, int Nout, void* stream) {
+extern "C" int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout) {
+  if (K <= 0 || Nout <= 0) return 0;
+  return (int64_t)K * Nout * sizeof(float);
+}
+
+extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, void* ws, int64_t rows, int K, int Nout,
+                                    void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!gY || !W || !gX) return MRG_E_NULLPTR;
-  // gX[rows, K] = gY[rows, Nout] * W[Nout, K]: reduction over Nout, W read as [k = Nout][n = K]
-  return launch_linear<true>(gY, W, nullptr, gX, rows, Nout, K, MRG_ACT_NONE, (hipStream_t)stream);
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  // gX[rows, K] = gY[rows, Nout] * W[Nout, K]: present W^T [K][Nout] row-major to the core
+  launch_transpose(W, (float*)ws, Nout, K, K, st);
+  GemmArgs a{};
+  a.A1 = gY; a.K1 = Nout; a.B = (const float*)ws; a.ldb = Nout; a.C = gX; a.ldc = K; a.N = K; a.rows = rows; a.act = MRG_ACT_NONE;
+  return launch_rowgemm<EPI_BIAS_ACT>(a, st);
 }
 
 extern "C" int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout) {
   if (rows < 0 || K <= 0 || Nout <= 0) return 0;
-  WgradPlan p = wgrad_plan(rows, K, Nout);
-  return (int64_t)p.G * p.TM * 32 * p.TN * 32 * sizeof(float);
+  return wgrad_workspace_bytes(rows, K, Nout);
 }
 
 extern "C" int mrg_linear_bwd_weight(const float* gY, const float* X, float* gW, float* gbias, void* ws, int64_t rows, int K,
                                      int Nout, void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
   if (!gW) return MRG_E_NULLPTR;
-  hipStream_t st = (hipStream_t)stream;
-  if (rows == 0) {                       // no rows: the gradients are exactly zero
-    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)Nout * K, st);
-    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Nout, st);
-    return (int)e;
-  }
-  if (!gY || !X) return MRG_E_NULLPTR;
-  if (!ws) return MRG_E_WORKSPACE;
-  WgradPlan p = wgrad_plan(rows, K, Nout);
-  if (!p.ok) return MRG_E_SHAPE;
-  const int vecG = (Nout % 4 == 0) && aligned16(gY);
-  const int vecX = (K % 4 == 0) && aligned16(X);
-#define GO(T)                                                                                                          \
-  do {                                                                                                                 \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-    hipLaunchKernelGGL((linear_wgrad_k<T>), dim3(p.G, (p.TN + p.TNB - 1) / p.TNB), dim3(MRG_BLOCK), p.lds, st, gY, X, (float*)ws, rows, K, Nout, p.TM, p.TN, p.TNB, p.rows_per_block, vecG, vecX); \
-  } while (0)
-  switch (p.tpw) {
-    case 1: GO(1); break;
-    case 2: GO(2); break;
-    case 4: GO(4); break;
-    case 7: GO(7); break;
-    default: GO(13); break;
-  }
-#undef GO
-  MRG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(linear_wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias,
-                     p.G, K, Nout, p.TM * 32, p.TN * 32);
-  MRG_LAUNCH_CHECK();
-  return MRG_OK;
+  if (rows > 0 && (!gY || !X)) return MRG_E_NULLPTR;
+  if (rows > 0 && !ws) return MRG_E_WORKSPACE;
+  return launch_wgrad(gY, X, nullptr, K, 0, gW, gbias, ws, rows, Nout, (hipStream_t)stream);
 }

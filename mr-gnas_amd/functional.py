@@ -258,7 +258,8 @@ class _Linear(torch.autograd.Function):
         work = dict(nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), rows, K, Nout, st), **work)
+            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", K, Nout), x)
+            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), ptr(wt), rows, K, Nout, st), **work)
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             gW = torch.empty_like(W)
             gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None

@@ -126,3 +126,12 @@ def test_harness_state_dict_keys_match_reference():
     net = S.FixedNetwork("cpu", geno, z["N"], z["R"], z["D"], z["D0"], z["nbase"])
     ref = {**sub(z, "param/"), **sub(z, "buffer/")}
     assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.items()}
+
+
+def test_library_is_not_older_than_its_sources():
+    """Guards against testing a stale .so: rebuild with __graft_entry__.build() after editing csrc/."""
+    import glob
+    import os
+    src = glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "csrc", "*.h*")) + [_lib.HEADER_PATH]
+    newest = max(os.path.getmtime(p) for p in src)
+    assert os.path.getmtime(_lib.LIB_PATH) >= newest, "libmrgnas_hip.so is older than its sources: run __graft_entry__.build()"
