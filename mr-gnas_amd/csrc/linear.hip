@@ -32,7 +32,7 @@ __device__ __forceinline__ XSel wgrad_sel_x(const WgradArgs& a, int c) {
 }
 
 template <int TPW, int NPF, bool VEC4>      // TPW accumulator tiles per wave, NPF prefetch float4 per thread
-__global__ __launch_bounds__(MRG_BLOCK) void wgrad_k(WgradArgs a) {
+__global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_k(WgradArgs a) {
   extern __shared__ __align__(16) float smem[];
   const int tn0 = blockIdx.y * a.TNB;
   const int tnb = a.TN - tn0 < a.TNB ? a.TN - tn0 : a.TNB;
@@ -168,8 +168,9 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout) {
   WgradPlan p{};
   p.TM = (Nout + 31) / 32;
   p.TN = (K + 1 + 31) / 32;
-  // at most 52 accumulator tiles (13 per wave) per workgroup; wider outputs split X' columns over grid.y
-  p.TNB = p.TM * p.TN <= 52 ? p.TN : (52 / p.TM > 0 ? 52 / p.TM : 0);
+  // at most 28 accumulator tiles (7 per wave, 112 registers) per workgroup so that two workgroups
+  // share a CU; wider outputs split the X' column tiles over grid.y (gY is then re-read per split)
+  p.TNB = p.TM * p.TN <= 28 ? p.TN : (28 / p.TM > 0 ? 28 / p.TM : 0);
   int per_wave = p.TNB > 0 ? (p.TM * p.TNB + 3) / 4 : 99;
   const int opts[] = {1, 2, 4, 7, 13};
   p.tpw = 0;
