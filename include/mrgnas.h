@@ -164,6 +164,18 @@ int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, c
                   int64_t n_slots, const int32_t *seg_len,
                   float *out, void *ws, int64_t nseg, int D, void *stream);
 
+/* Span form of the elementwise modes (SUB, MUL, COPY, NEGS) of mrg_fused_gcs: the elements are
+ * pre-sorted by segment and packed as int32x4 {seg, xi, yi, float-bits of scal} in `meta` [E];
+ * every lane group reduces `span` consecutive sorted elements (perfect load balance, 8 gathered
+ * rows in flight).  span_slot [n_spans][2] = workspace slot of the first / last run of a span
+ * when that run does not cover its whole segment (-1 otherwise); hub_* list the segments made
+ * of partial runs (consecutive slots, list order).  `out` [nseg, D] must be zero-filled. */
+int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, int64_t E, int span,
+                 const int32_t *span_slot, int64_t n_spans,
+                 const int32_t *hub_seg, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,
+                 int64_t n_slots, const int32_t *seg_len,
+                 float *out, void *ws, int64_t nseg, int D, void *stream);
+
 /* ---- X: MixedOp epilogue  out = sum_k w_k * ReLU(BatchNorm_k(y_k)) -----------------
  * MixedOp.forward / op_forward, reference models/cell_lp.py:25-33, with nn.BatchNorm1d in
  * training mode (:21).  K <= 8 operator outputs y_k [rows, D]; a NULL y_k is an all-zero

@@ -212,3 +212,135 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
+
+// ======================================================================================
+// Span formulation of the elementwise modes (SUB / MUL / COPY / NEGS): perfectly balanced.
+// The elements are pre-sorted by segment and packed as {seg, xi, yi, scal} (16 bytes, one
+// broadcast load per element).  Every LPR-lane group owns SPAN consecutive sorted elements,
+// keeps 8 gathered rows in flight, and sums runs of equal segment id in registers.  A run that
+// covers its whole segment is stored straight to out[seg]; only the first and the last run of
+// a span can be partial -- they go to consecutive workspace slots that seg_hub_k adds up in
+// list order (bitwise reproducible, no atomics).  `out` must be zero-filled by the caller
+// (segments without elements are never written).
+// ======================================================================================
+namespace mrg {
+
+template <int VEC, int LPR, int KMAX, int MODE>
+__global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict__ X, const float* __restrict__ Y,
+                                                        const int4* __restrict__ meta, int64_t E, int span,
+                                                        const int32_t* __restrict__ span_slot, int64_t n_spans,
+                                                        float* __restrict__ out, float* __restrict__ ws_val, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int U = 8;
+  constexpr bool NY = NeedsY<MODE>::value;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t sp = (int64_t)blockIdx.x * RPB + rw; sp < n_spans; sp += (int64_t)gridDim.x * RPB) {
+    const int64_t start = sp * span;
+    const int64_t end = start + span < E ? start + span : E;
+    const int slot_first = span_slot[2 * sp], slot_last = span_slot[2 * sp + 1];
+    Vec<VEC> acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = Vec<VEC>::fill(0.f);
+    int cur_seg = meta[start].x;
+    bool first_run = true;
+    for (int64_t j = start; j < end; j += U) {
+      int4 m[U];
+      Vec<VEC> x[U][KMAX], y[U][KMAX];
+#pragma unroll
+      for (int q = 0; q < U; ++q) m[q] = meta[j + q < end ? j + q : end - 1];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (c < dv) {
+            x[q][k] = Vec<VEC>::load(X + (int64_t)m[q].y * D + c * VEC);
+            if (NY) y[q][k] = Vec<VEC>::load(Y + (int64_t)m[q].z * D + c * VEC);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (j + q < end) {
+          if (m[q].x != cur_seg) {             // uniform within the lane group: a run ends
+            float* dst = (first_run && slot_first >= 0) ? ws_val + (int64_t)slot_first * D : out + (int64_t)cur_seg * D;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              int c = sl + k * LPR;
+              if (c < dv) acc[k].store(dst + c * VEC);
+              acc[k] = Vec<VEC>::fill(0.f);
+            }
+            cur_seg = m[q].x;
+            first_run = false;
+          }
+          const float s = __int_as_float(m[q].w);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            if (sl + k * LPR < dv) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                const float xv = x[q][k][i];
+                float val;
+                if (MODE == MRG_GCS_SUB) val = xv - y[q][k][i] * s;
+                else if (MODE == MRG_GCS_MUL) val = xv * (y[q][k][i] * s);
+                else if (MODE == MRG_GCS_COPY) val = xv * s;
+                else val = -(xv * s);
+                acc[k][i] += val;
+              }
+            }
+          }
+        }
+      }
+    }
+    const int slot = first_run ? slot_first : slot_last;
+    float* dst = slot >= 0 ? ws_val + (int64_t)slot * D : out + (int64_t)cur_seg * D;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) acc[k].store(dst + c * VEC);
+    }
+  }
+}
+
+}  // namespace mrg
+
+extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void* meta, int64_t E, int span,
+                            const int32_t* span_slot, int64_t n_spans, const int32_t* hub_seg, const int32_t* hub_first,
+                            const int32_t* hub_count, int64_t n_hubs, int64_t n_slots, const int32_t* seg_len, float* out,
+                            void* ws, int64_t nseg, int D, void* stream) {
+  if (mode != MRG_GCS_SUB && mode != MRG_GCS_MUL && mode != MRG_GCS_COPY && mode != MRG_GCS_NEGS) return MRG_E_ENUM;
+  if (nseg < 0 || D <= 0 || E < 0 || span < 1 || n_spans < 0 || n_hubs < 0 || n_slots < 0) return MRG_E_SHAPE;
+  if (E == 0 || nseg == 0) return MRG_OK;
+  if (!X || !meta || !span_slot || !out || !seg_len) return MRG_E_NULLPTR;
+  if ((mode == MRG_GCS_SUB || mode == MRG_GCS_MUL) && !Y) return MRG_E_NULLPTR;
+  if (n_hubs > 0 && (!hub_seg || !hub_first || !hub_count)) return MRG_E_NULLPTR;
+  if (n_slots > 0 && !ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws_val = (float*)ws;
+  RowGeom g = row_geom(D, aligned16(X) && aligned16(Y) && aligned16(out) && aligned16(ws));
+  if (!g.ok) return MRG_E_SHAPE;
+  const int4* m4 = (const int4*)meta;
+#define LAUNCH(V, L, K, M)                                                                                              \
+  hipLaunchKernelGGL((span_gcs_k<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, E, span, span_slot, n_spans, out, ws_val, D)
+#define CALL(V, L, K)                                                                                                  \
+  do {                                                                                                                 \
+    int grid = grid_for(n_spans, MRG_BLOCK / L);                                                                       \
+    switch (mode) {                                                                                                    \
+      case MRG_GCS_SUB: LAUNCH(V, L, K, MRG_GCS_SUB); break;                                                           \
+      case MRG_GCS_MUL: LAUNCH(V, L, K, MRG_GCS_MUL); break;                                                           \
+      case MRG_GCS_COPY: LAUNCH(V, L, K, MRG_GCS_COPY); break;                                                         \
+      default: LAUNCH(V, L, K, MRG_GCS_NEGS); break;                                                                   \
+    }                                                                                                                  \
+    if (n_hubs > 0) {                                                                                                  \
+      int gh = n_hubs < 4096 ? (int)n_hubs : 4096;                                                                     \
+      hipLaunchKernelGGL((seg_hub_k<V, L, K, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, (const float*)nullptr, hub_seg, \
+                         hub_first, hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0); \
+    }                                                                                                                  \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+#undef LAUNCH
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

@@ -283,9 +283,12 @@ class GatherPlan:
 
     def __init__(self, idx, num_table_rows):
         from .graph import dst_csr_plan
+        from .graph import span_meta, span_plan
         self.idx32 = idx.to(torch.int32).contiguous()
         self.rows = int(num_table_rows)
         self.plan = dst_csr_plan(idx, self.rows)
+        self.sp = span_plan(idx, self.rows)
+        self.meta = span_meta(self.sp, torch.arange(idx.numel(), device=idx.device))
 
 
 class _Gather(torch.autograd.Function):
@@ -297,6 +300,8 @@ class _Gather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = f32c(g)
+        if g.is_cuda:
+            return span_gcs("copy", g, None, ctx.gp.meta, ctx.gp.sp), None
         out, _ = _seg_fwd(0, g, None, ctx.gp.plan, ctx.gp.rows, g.shape[1])
         return out, None
 
@@ -331,6 +336,21 @@ def fused_gcs(mode, X, xi, Y, yi, scal, plan, nseg):
     return out
 
 
+def span_gcs(mode, X, Y, meta, plan):
+    """mrg_span_gcs: balanced span form of fused_gcs for the elementwise modes."""
+    X, Y = f32c(X), f32c(Y)
+    require_hip(X, Y, meta)
+    D, nseg, E = X.shape[1], plan["nseg"], plan["E"]
+    out = torch.zeros(nseg, D, dtype=torch.float32, device=X.device)
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
+    rows_y = Y.shape[0] if Y is not None else 0
+    nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)          # SURVEY section 8d
+    call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), E, plan["span"], ptr(plan["span_slot"]), plan["n_spans"],
+                          ptr(plan["hub_seg"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), plan["n_hubs"], plan["n_slots"],
+                          ptr(plan["seg_len"]), ptr(out), ptr(ws), nseg, D, stream_of(X)), nbytes=nb)
+    return out
+
+
 class ComposePlan:
     """Index structure of one compose-and-aggregate: element e reads node row xi[e] and relation
     row yi[e], is scaled by scal[e] and summed into segment seg[e].  Holds the three chunk plans
@@ -345,6 +365,23 @@ class ComposePlan:
         self.by_seg = dst_csr_plan(seg, n_seg)
         self.by_x = dst_csr_plan(xi, n_x)
         self.by_y = dst_csr_plan(yi, n_y)
+        # balanced span plans + packed per-element metadata for the elementwise modes
+        from .graph import span_meta, span_plan
+        self.sp_seg = span_plan(seg, n_seg)
+        self.sp_x = span_plan(xi, n_x)
+        self.sp_y = span_plan(yi, n_y)
+        self.m_fwd = span_meta(self.sp_seg, xi, yi, scal)             # out[seg] <- X[xi] (op) Y[yi]*s
+        self.m_bx = span_meta(self.sp_x, seg, yi, scal)               # gX[xi]   <- G[seg] (op) Y[yi]*s
+        self.m_by_g = span_meta(self.sp_y, seg, xi, scal)             # gY[yi]   <- G[seg] (op) X[xi]*s
+        self._m_bx_unit = None
+        self._raw = (seg, xi)
+
+    def m_bx_unit(self):
+        """metadata of gX[xi] <- G[seg] with unit scale (d/dx of x - y*s)."""
+        if self._m_bx_unit is None:
+            from .graph import span_meta
+            self._m_bx_unit = span_meta(self.sp_x, self._raw[0], None, None)
+        return self._m_bx_unit
 
 
 class _ComposeAggregate(torch.autograd.Function):
@@ -356,6 +393,8 @@ class _ComposeAggregate(torch.autograd.Function):
         X, Y = f32c(X), f32c(Y)
         ctx.kind, ctx.cp = kind, cp
         ctx.save_for_backward(X, Y)
+        if kind in ("sub", "mul"):
+            return span_gcs(kind, X, Y, cp.m_fwd, cp.sp_seg)
         return fused_gcs(kind, X, cp.xi, Y, cp.yi, cp.scal, cp.by_seg, cp.n_seg)
 
     @staticmethod
@@ -366,14 +405,14 @@ class _ComposeAggregate(torch.autograd.Function):
         gX = gY = None
         if kind == "sub":       # x - y s
             if ctx.needs_input_grad[1]:
-                gX = fused_gcs("copy", G, cp.seg, None, None, None, cp.by_x, cp.n_x)
+                gX = span_gcs("copy", G, None, cp.m_bx_unit(), cp.sp_x)
             if ctx.needs_input_grad[2]:
-                gY = fused_gcs("negs", G, cp.seg, None, None, cp.scal, cp.by_y, cp.n_y)
+                gY = span_gcs("negs", G, None, cp.m_by_g, cp.sp_y)
         elif kind == "mul":     # x * y s
             if ctx.needs_input_grad[1]:
-                gX = fused_gcs("mul", G, cp.seg, Y, cp.yi, cp.scal, cp.by_x, cp.n_x)
+                gX = span_gcs("mul", G, Y, cp.m_bx, cp.sp_x)
             if ctx.needs_input_grad[2]:
-                gY = fused_gcs("mul", G, cp.seg, X, cp.xi, cp.scal, cp.by_y, cp.n_y)
+                gY = span_gcs("mul", G, X, cp.m_by_g, cp.sp_y)
         else:                   # ccorr(x, y s)
             if ctx.needs_input_grad[1]:
                 gX = fused_gcs("ccorr", G, cp.seg, Y, cp.yi, cp.scal, cp.by_x, cp.n_x)

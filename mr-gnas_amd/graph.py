@@ -59,6 +59,59 @@ def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
     }
 
 
+import os as _os
+
+SPAN_ELEMS = int(_os.environ.get("MRG_SPAN", "64"))      # sorted elements reduced by one lane group in the span kernels
+
+
+def span_plan(seg, nseg, span=None):
+    """Plan for mrg_span_gcs (include/mrgnas.h): elements sorted by segment, cut into spans of
+    `span` consecutive sorted elements.  Only the first / last run of a span can be a partial
+    segment; those get consecutive workspace slots (numbered in span order, so the slots of one
+    segment are consecutive and in list order) that the hub pass adds up.  Pure tensor code."""
+    dev = seg.device
+    seg = seg.long()
+    span = SPAN_ELEMS if span is None else span
+    E, nseg = int(seg.numel()), int(nseg)
+    perm = torch.argsort(seg, stable=True)
+    seg_s = seg[perm]
+    seg_len = torch.bincount(seg, minlength=nseg)
+    segptr = torch.zeros(nseg + 1, dtype=torch.long, device=dev)
+    segptr[1:] = torch.cumsum(seg_len, 0)
+    n_spans = (E + span - 1) // span
+    start = torch.arange(n_spans, device=dev) * span
+    end = torch.clamp(start + span, max=E)
+    if n_spans:
+        f, l = seg_s[start], seg_s[end - 1]
+        f_part = (segptr[f] < start) | (segptr[f + 1] > end)
+        l_part = (l != f) & (segptr[l + 1] > end)
+    else:
+        f = l = torch.zeros(0, dtype=torch.long, device=dev)
+        f_part = l_part = torch.zeros(0, dtype=torch.bool, device=dev)
+    flags = torch.stack((f_part, l_part), dim=1).reshape(-1)
+    slot_ids = torch.cumsum(flags.long(), 0) - 1
+    span_slot = torch.where(flags, slot_ids, torch.full_like(slot_ids, -1))
+    slot_seg = torch.stack((f, l), dim=1).reshape(-1)[flags]
+    if slot_seg.numel():
+        hub_seg, hub_count = torch.unique_consecutive(slot_seg, return_counts=True)
+    else:
+        hub_seg = hub_count = torch.zeros(0, dtype=torch.long, device=dev)
+    hub_first = torch.cumsum(hub_count, 0) - hub_count
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return {"perm": perm, "seg_sorted": i32(seg_s), "seg_len": i32(seg_len), "span": int(span), "n_spans": int(n_spans),
+            "span_slot": i32(span_slot), "hub_seg": i32(hub_seg), "hub_first": i32(hub_first), "hub_count": i32(hub_count),
+            "n_hubs": int(hub_seg.numel()), "n_slots": int(slot_seg.numel()), "E": E, "nseg": nseg}
+
+
+def span_meta(plan, xi, yi=None, scal=None):
+    """int32x4 {seg, xi, yi, float bits of scal} per sorted element (one 16-byte load each)."""
+    perm = plan["perm"]
+    xi_s = xi.long()[perm]
+    yi_s = yi.long()[perm] if yi is not None else torch.zeros_like(xi_s)
+    sc = scal.float().reshape(-1)[perm] if scal is not None else torch.ones(perm.numel(), dtype=torch.float32, device=perm.device)
+    return torch.stack((plan["seg_sorted"].long(), xi_s, yi_s, sc.contiguous().view(torch.int32).long()), dim=1).to(torch.int32).contiguous()
+
+
 class RelGraph:
     """Multi-relational edge-list graph resident in HBM (see module docstring)."""
 

@@ -135,3 +135,46 @@ def test_library_is_not_older_than_its_sources():
     src = glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "csrc", "*.h*")) + [_lib.HEADER_PATH]
     newest = max(os.path.getmtime(p) for p in src)
     assert os.path.getmtime(_lib.LIB_PATH) >= newest, "libmrgnas_hip.so is older than its sources: run __graft_entry__.build()"
+
+
+@pytest.mark.parametrize("span", [1, 4, 64])
+def test_span_plan_emulation(span):
+    """Emulate mrg_span_gcs on the CPU from the plan alone and compare with index_add."""
+    rng = np.random.default_rng(span)
+    nseg, E, D = 19, 500, 3
+    seg = torch.from_numpy(rng.integers(0, nseg - 4, size=E))          # last segments stay empty
+    seg[:200] = 3                                                        # a hub spanning many spans
+    x = torch.randn(E, D, dtype=torch.float64)
+    p = G.span_plan(seg, nseg, span=span)
+    meta = G.span_meta(p, torch.arange(E), None, None)
+    assert meta.shape == (E, 4) and meta.dtype == torch.int32
+    assert torch.equal(meta[:, 0], p["seg_sorted"]) and torch.all(meta[1:, 0] >= meta[:-1, 0])
+    assert meta[:, 3].view(torch.float32).eq(1.0).all()
+    out = torch.zeros(nseg, D, dtype=torch.float64)
+    ws = torch.zeros(max(p["n_slots"], 1), D, dtype=torch.float64)
+    written = torch.zeros(nseg, dtype=torch.long)
+    for sp in range(p["n_spans"]):
+        a, b = sp * span, min((sp + 1) * span, E)
+        sf, sl_ = int(p["span_slot"][2 * sp]), int(p["span_slot"][2 * sp + 1])
+        acc, cur, first = torch.zeros(D, dtype=torch.float64), int(meta[a, 0]), True
+
+        def flush(slot):
+            if slot >= 0:
+                ws[slot] = acc
+            else:
+                out[cur] = acc
+                written[cur] += 1
+        for j in range(a, b):
+            if int(meta[j, 0]) != cur:
+                flush(sf if first else -1)
+                acc, cur, first = torch.zeros(D, dtype=torch.float64), int(meta[j, 0]), False
+            acc = acc + x[int(meta[j, 1])]
+        flush(sf if first else sl_)
+    for h in range(p["n_hubs"]):
+        s0, cnt, v = int(p["hub_first"][h]), int(p["hub_count"][h]), int(p["hub_seg"][h])
+        assert written[v] == 0
+        out[v] = ws[s0:s0 + cnt].sum(0)
+        written[v] += 1
+    ref = torch.zeros(nseg, D, dtype=torch.float64).index_add(0, seg, x)
+    torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
+    assert torch.all(written[p["seg_len"].long() > 0] == 1) and torch.all(written[p["seg_len"].long() == 0] == 0)

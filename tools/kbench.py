@@ -97,10 +97,11 @@ def main():
         nb = E * (8 + 4 * D) + 4 * (2 * N + 1) + 4 * D * (Rp + 2 * N)
         with torch.no_grad():
             for kind in ("sub", "mul"):
-                rec(f"fused_gcs_{kind}", timeit(lambda: K.fused_gcs(kind, ent, cp.xi, rel, cp.yi, cp.scal, cp.by_seg, 2 * N), args.reps), nb)
+                rec(f"chunk_gcs_{kind}", timeit(lambda: K.fused_gcs(kind, ent, cp.xi, rel, cp.yi, cp.scal, cp.by_seg, 2 * N), args.reps), nb)
+                rec(f"span_gcs_{kind}", timeit(lambda: K.span_gcs(kind, ent, rel, cp.m_fwd, cp.sp_seg), args.reps), nb)
             G2 = rnd(2 * N, D)
-            rec("fused_gcs_bwd_node(copy)", timeit(lambda: K.fused_gcs("copy", G2, cp.seg, None, None, None, cp.by_x, N), args.reps), E * (8 + 4 * D) + 4 * D * N)
-            rec("fused_gcs_bwd_rel(negs)", timeit(lambda: K.fused_gcs("negs", G2, cp.seg, None, None, cp.scal, cp.by_y, Rp), args.reps), E * (8 + 4 * D) + 4 * D * Rp)
+            rec("span_gcs_bwd_node(copy)", timeit(lambda: K.span_gcs("copy", G2, None, cp.m_bx_unit(), cp.sp_x), args.reps), E * (8 + 4 * D) + 4 * D * N)
+            rec("span_gcs_bwd_rel(negs)", timeit(lambda: K.span_gcs("negs", G2, None, cp.m_by_g, cp.sp_y), args.reps), E * (8 + 4 * D) + 4 * D * Rp)
             if args.shape == "fb":
                 rec("fused_gcs_ccorr", timeit(lambda: K.fused_gcs("ccorr", ent, cp.xi, rel, cp.yi, cp.scal, cp.by_seg, 2 * N), 3, 1), 0, 2 * E * D * D)
     if want("linear"):
