@@ -169,7 +169,8 @@ int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, c
  * every lane group reduces `span` consecutive sorted elements (perfect load balance, 8 gathered
  * rows in flight).  span_slot [n_spans][2] = workspace slot of the first / last run of a span
  * when that run does not cover its whole segment (-1 otherwise); hub_* list the segments made
- * of partial runs (consecutive slots, list order).  `out` [nseg, D] must be zero-filled. */
+ * of partial runs (consecutive slots, list order) AND, with hub_count 0, the segments that have
+ * no element at all, so that every row of `out` [nseg, D] is written. */
 int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, int64_t E, int span,
                  const int32_t *span_slot, int64_t n_spans,
                  const int32_t *hub_seg, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,

@@ -220,8 +220,8 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
 // keeps 8 gathered rows in flight, and sums runs of equal segment id in registers.  A run that
 // covers its whole segment is stored straight to out[seg]; only the first and the last run of
 // a span can be partial -- they go to consecutive workspace slots that seg_hub_k adds up in
-// list order (bitwise reproducible, no atomics).  `out` must be zero-filled by the caller
-// (segments without elements are never written).
+// list order (bitwise reproducible, no atomics).  Segments without elements are listed as hubs
+// with zero partials, so every output row is written and no zero-fill pass is needed.
 // ======================================================================================
 namespace mrg {
 
@@ -311,9 +311,10 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
                             void* ws, int64_t nseg, int D, void* stream) {
   if (mode != MRG_GCS_SUB && mode != MRG_GCS_MUL && mode != MRG_GCS_COPY && mode != MRG_GCS_NEGS) return MRG_E_ENUM;
   if (nseg < 0 || D <= 0 || E < 0 || span < 1 || n_spans < 0 || n_hubs < 0 || n_slots < 0) return MRG_E_SHAPE;
-  if (E == 0 || nseg == 0) return MRG_OK;
-  if (!X || !meta || !span_slot || !out || !seg_len) return MRG_E_NULLPTR;
-  if ((mode == MRG_GCS_SUB || mode == MRG_GCS_MUL) && !Y) return MRG_E_NULLPTR;
+  if (nseg == 0) return MRG_OK;
+  if (!out || !seg_len) return MRG_E_NULLPTR;
+  if (E > 0 && (!X || !meta || !span_slot)) return MRG_E_NULLPTR;
+  if (E > 0 && (mode == MRG_GCS_SUB || mode == MRG_GCS_MUL) && !Y) return MRG_E_NULLPTR;
   if (n_hubs > 0 && (!hub_seg || !hub_first || !hub_count)) return MRG_E_NULLPTR;
   if (n_slots > 0 && !ws) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -326,7 +327,7 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
     int grid = grid_for(n_spans, MRG_BLOCK / L);                                                                       \
-    switch (mode) {                                                                                                    \
+    if (E > 0 && n_spans > 0) switch (mode) {                                                                          \
       case MRG_GCS_SUB: LAUNCH(V, L, K, MRG_GCS_SUB); break;                                                           \
       case MRG_GCS_MUL: LAUNCH(V, L, K, MRG_GCS_MUL); break;                                                           \
       case MRG_GCS_COPY: LAUNCH(V, L, K, MRG_GCS_COPY); break;                                                         \

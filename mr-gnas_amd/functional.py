@@ -174,7 +174,13 @@ class _SegReduce(torch.autograd.Function):
         require_hip(msg, self_rows)
         if msg.shape[0] != graph.num_edges():
             raise _lib.MrgnasError(f"message rows {msg.shape[0]} != number of edges {graph.num_edges()}")
-        out, arg = _seg_fwd(mode, msg, self_rows, graph.plan(), graph.number_of_nodes(), msg.shape[1])
+        if mode != 2 and hasattr(graph, "agg_plan"):          # sum / mean: balanced span kernel
+            sp, meta = graph.agg_plan("mean" if mode == 1 else "sum")
+            out, arg = span_gcs("copy", msg, None, meta, sp), None
+            if self_rows is not None:
+                out += self_rows
+        else:
+            out, arg = _seg_fwd(mode, msg, self_rows, graph.plan(), graph.number_of_nodes(), msg.shape[1])
         ctx.mode, ctx.graph, ctx.has_self = mode, graph, self_rows is not None
         ctx.save_for_backward(*((arg,) if arg is not None else ()))
         return out
@@ -204,7 +210,13 @@ class _AggRows(torch.autograd.Function):
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         if x.shape[0] != E + N:
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
-        out, arg = _seg_fwd(mode, x, x[E:] if add_self else None, graph.plan(), N, D)
+        if mode != 2 and hasattr(graph, "agg_plan"):
+            sp, meta = graph.agg_plan("mean" if mode == 1 else "sum")
+            out, arg = span_gcs("copy", x, None, meta, sp), None      # xi < E: only the edge rows of x are gathered
+            if add_self:
+                out += x[E:]
+        else:
+            out, arg = _seg_fwd(mode, x, x[E:] if add_self else None, graph.plan(), N, D)
         ctx.mode, ctx.graph, ctx.add_self = mode, graph, add_self
         ctx.save_for_backward(*((arg,) if arg is not None else ()))
         return out
@@ -341,7 +353,7 @@ def span_gcs(mode, X, Y, meta, plan):
     X, Y = f32c(X), f32c(Y)
     require_hip(X, Y, meta)
     D, nseg, E = X.shape[1], plan["nseg"], plan["E"]
-    out = torch.zeros(nseg, D, dtype=torch.float32, device=X.device)
+    out = torch.empty(nseg, D, dtype=torch.float32, device=X.device)     # every row is written: runs, hubs, empty segments
     ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
     rows_y = Y.shape[0] if Y is not None else 0
     nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)

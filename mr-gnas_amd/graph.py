@@ -97,6 +97,12 @@ def span_plan(seg, nseg, span=None):
     else:
         hub_seg = hub_count = torch.zeros(0, dtype=torch.long, device=dev)
     hub_first = torch.cumsum(hub_count, 0) - hub_count
+    # segments without elements are appended as hubs with zero partials: the hub pass writes
+    # their zero rows, so the output needs no separate zero-fill
+    empty = torch.nonzero(seg_len == 0).view(-1)
+    hub_seg = torch.cat((hub_seg, empty))
+    hub_count = torch.cat((hub_count, torch.zeros_like(empty)))
+    hub_first = torch.cat((hub_first, torch.zeros_like(empty)))
     i32 = lambda t: t.to(torch.int32).contiguous()
     return {"perm": perm, "seg_sorted": i32(seg_s), "seg_len": i32(seg_len), "span": int(span), "n_spans": int(n_spans),
             "span_slot": i32(span_slot), "hub_seg": i32(hub_seg), "hub_first": i32(hub_first), "hub_count": i32(hub_count),
@@ -190,6 +196,19 @@ class RelGraph:
         if self._plan is None:
             self._plan = dst_csr_plan(self._dst, self._n)
         return self._plan
+
+    def agg_plan(self, kind):
+        """Span plan + packed metadata of the destination-segmented SUM / MEAN over the edge rows
+        (mean = per-element scale 1 / in-degree); cached."""
+        key = "_agg_" + kind
+        if key not in self._i32:
+            sp = span_plan(self._dst, self._n)
+            scal = None
+            if kind == "mean":
+                scal = (1.0 / self.in_degrees().clamp(min=1).float())[self._dst]
+            meta = span_meta(sp, torch.arange(self.num_edges(), device=self.device), None, scal)
+            self._i32[key] = (sp, meta)
+        return self._i32[key]
 
     def i32(self, name):
         """int32 copy of 'src' / 'dst' / an integer edata field, cached."""
