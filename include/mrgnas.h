@@ -224,6 +224,25 @@ int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout);
 int mrg_linear_bwd_weight(const float *gY, const float *X, float *gW, float *gbias, void *ws,
                           int64_t rows, int K, int Nout, void *stream);
 
+/* ---- dense (per-feature) filters, one direction segment per call ------------------
+ * f_dense_op_comp / f_comp_op / f_dense_op_last / f_dense_op .forward,
+ * reference models/operations_lp.py:356-390, 266-288, 392-401, 345-354.
+ *   z = [s | s_in] W^T + bias        (s_in NULL: z = s W^T + bias; W is [D, 2D] or [D, D])
+ *   kind 0:  out = sigmoid(z) * s * c      (gate [rows, D] receives sigmoid(z) for the backward)
+ *   kind 1:  out = z * c
+ *   c = scale * (rowscale ? rowscale[row] : 1)     (the reference's 1/3 and edge norm)
+ * torch.cat([s, s_in], 1) is never materialised: the GEMM reads both sources; gate, scale and
+ * norm are applied in its epilogue.  Backward: gs, gs_in [rows, D] (fully written), gW [D, K],
+ * gbias [D] (NULL ok). */
+int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const float *W, const float *bias,
+                         const float *rowscale, float scale, float *out, float *gate,
+                         int64_t rows, int D, void *stream);
+int64_t mrg_dense_filter_bwd_workspace_bytes(int64_t rows, int D, int has_in);
+int mrg_dense_filter_bwd(int kind, const float *g, const float *s, const float *s_in, const float *W,
+                         const float *gate, const float *rowscale, float scale,
+                         float *gs, float *gs_in, float *gW, float *gbias, void *ws,
+                         int64_t rows, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

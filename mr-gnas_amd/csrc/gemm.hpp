@@ -87,6 +87,38 @@ __device__ __forceinline__ ASel gemm_sel_a(const GemmArgs& a, int k) {
   return s;
 }
 
+// raw / mask of a float4 of the concatenated operand [A1 | A2] at global column k.  The scalar
+// path selects the source per element (K1 need not be a multiple of 4 there).
+template <bool VEC4>
+__device__ __forceinline__ float4 gemm_raw_a(const GemmArgs& a, int64_t row, int k) {
+  if (VEC4) {
+    const ASel sa = gemm_sel_a(a, k);
+    return gemm_raw4<true>(sa.base, row, a.rows, sa.kk, sa.ld, sa.ld);
+  }
+  const int64_t rc = row < a.rows ? row : a.rows - 1;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const ASel sa = gemm_sel_a(a, k + j);
+    const int kc = sa.kk < sa.ld ? sa.kk : sa.ld - 1;
+    v[j] = sa.base[rc * sa.ld + kc];
+  }
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <bool VEC4>
+__device__ __forceinline__ float4 gemm_mask_a(float4 v, const GemmArgs& a, int64_t row, int k) {
+  if (VEC4) {
+    const ASel sa = gemm_sel_a(a, k);
+    return gemm_mask4<true>(v, row, a.rows, sa.kk, sa.ld);
+  }
+  const int K = a.K1 + a.K2;
+  const bool rv = row < a.rows;
+  v.x = (rv && k < K) ? v.x : 0.f; v.y = (rv && k + 1 < K) ? v.y : 0.f;
+  v.z = (rv && k + 2 < K) ? v.z : 0.f; v.w = (rv && k + 3 < K) ? v.w : 0.f;
+  return v;
+}
+
 template <int NT, int MT, int GBK, int EPI, bool VEC4>
 __global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmArgs a) {
   constexpr int GBM = 128 * MT;
@@ -117,8 +149,7 @@ __global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmAr
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int f = tid + i * MRG_BLOCK;
-      const ASel sa = gemm_sel_a(a, k0 + (f % F4R) * 4);
-      pa[i] = gemm_raw4<VEC4>(sa.base, row0 + f / F4R, a.rows, sa.kk, sa.ld, sa.ld);
+      pa[i] = gemm_raw_a<VEC4>(a, row0 + f / F4R, k0 + (f % F4R) * 4);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -131,9 +162,8 @@ __global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmAr
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int f = tid + i * MRG_BLOCK;
-      const ASel sa = gemm_sel_a(a, k0 + (f % F4R) * 4);
       *reinterpret_cast<float4*>(&smem[buf * STAGE + (f / F4R) * GLD + (f % F4R) * 4]) =
-          gemm_mask4<VEC4>(pa[i], row0 + f / F4R, a.rows, sa.kk, sa.ld);
+          gemm_mask_a<VEC4>(pa[i], a, row0 + f / F4R, k0 + (f % F4R) * 4);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -244,7 +274,6 @@ template <int EPI>
 inline int launch_rowgemm(GemmArgs a, hipStream_t st) {
   if (a.rows <= 0) return MRG_OK;
   if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
-  if (a.K2 > 0 && (a.K1 % 4 != 0)) return MRG_E_SHAPE;
   const bool vec = (a.K1 % 4 == 0) && (a.K2 % 4 == 0) && (a.ldb % 4 == 0) && ((a.K1 + a.K2) % 4 == 0) && aligned16(a.A1) &&
                    aligned16(a.A2) && aligned16(a.B) && a.K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
   const int nt = gemm_pick_nt(a.N);
@@ -275,7 +304,7 @@ inline int launch_rowgemm(GemmArgs a, hipStream_t st) {
 }
 
 // Bt[c][r] = B[r][c]  (small weight matrices; used to present W^T row-major to the core)
-__global__ void transpose_k(const float* __restrict__ B, float* __restrict__ Bt, int rows, int cols, int ldb) {
+static __global__ void transpose_k(const float* __restrict__ B, float* __restrict__ Bt, int rows, int cols, int ldb) {
   __shared__ float tile[32][33];
   int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y)

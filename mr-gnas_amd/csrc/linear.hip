@@ -60,11 +60,25 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_k(WgradAr
       const int f2 = isg ? f : (f < nf4 ? f - WBR * g4 : 0);
       const int per = isg ? g4 : x4;
       const int r = f2 / per, c4 = f2 - r * per;
-      const XSel sx = wgrad_sel_x(a, tn0 * 32 + c4 * 4);
-      const float* base = isg ? a.gY : sx.base;
-      const int ld = isg ? a.Nout : sx.ld;
-      const int kk = isg ? c4 * 4 : sx.kk;
-      pf[i] = gemm_raw4<VEC4>(base, r0 + r, r_end, kk, ld, ld);
+      if (VEC4) {
+        const XSel sx = wgrad_sel_x(a, tn0 * 32 + c4 * 4);
+        const float* base = isg ? a.gY : sx.base;
+        const int ld = isg ? a.Nout : sx.ld;
+        const int kk = isg ? c4 * 4 : sx.kk;
+        pf[i] = gemm_raw4<true>(base, r0 + r, r_end, kk, ld, ld);
+      } else {                                  // scalar path: per-element source selection
+        const int64_t rc = r0 + r < r_end ? r0 + r : r_end - 1;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const XSel sx = wgrad_sel_x(a, tn0 * 32 + c4 * 4 + j);
+          const float* base = isg ? a.gY : sx.base;
+          const int ld = isg ? a.Nout : sx.ld;
+          const int kk = isg ? c4 * 4 + j : sx.kk;
+          v[j] = base[rc * ld + (kk < ld ? kk : ld - 1)];
+        }
+        pf[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   };
   auto stash = [&](int buf, int64_t r0) {
@@ -79,7 +93,12 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_k(WgradAr
         const int r = f2 / per, c4 = f2 - r * per;
         const int c = tn0 * 32 + c4 * 4;
         const XSel sx = wgrad_sel_x(a, c);
-        float4 v = gemm_mask4<VEC4>(pf[i], r0 + r, r_end, isg ? c4 * 4 : sx.kk, isg ? a.Nout : sx.ld);
+        float4 v;
+        if (VEC4) {
+          v = gemm_mask4<true>(pf[i], r0 + r, r_end, isg ? c4 * 4 : sx.kk, isg ? a.Nout : sx.ld);
+        } else {                                // columns are valid up to Nout (gY) or K (X'); the ones column is set below
+          v = gemm_mask4<false>(pf[i], r0 + r, r_end, isg ? c4 * 4 : c, isg ? a.Nout : K);
+        }
         if (!isg && r0 + r < r_end) {            // the appended column of ones
           if (c == K) v.x = 1.0f;
           if (!VEC4) { if (c + 1 == K) v.y = 1.0f; if (c + 2 == K) v.z = 1.0f; if (c + 3 == K) v.w = 1.0f; }

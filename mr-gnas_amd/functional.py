@@ -545,3 +545,77 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
     cfg = _MixCfg(list(bns), present, group, total_rows)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns]
     return _MixedEpilogue.apply(cfg, w, *tensors)
+
+
+# ---------------------------------------------------------------------------
+# dense (per-feature) filters on the MFMA row GEMM
+# ---------------------------------------------------------------------------
+class _DenseFilter(torch.autograd.Function):
+    """Three direction segments [0,b0) [b0,b1) [b1,M), each with its own nn.Linear (W, b);
+    params flat: W_in, b_in, W_out, b_out, W_self, b_self (None for an absent segment / bias).
+    kind 0: sigmoid(W[s;s_in]+b) * s * c   kind 1: (W[s;s_in]) * c,  c = scale * norm on edge rows."""
+
+    @staticmethod
+    def forward(ctx, kind, s, s_in, norm, b0, b1, scale_edge, scale_self, *params):
+        s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
+        params = tuple(f32c(p) for p in params)
+        require_hip(s, s_in, norm, *params)
+        M, D = s.shape
+        st = stream_of(s)
+        out = torch.empty_like(s)
+        gate = torch.empty_like(s) if kind == 0 else None
+        K_ = 2 * D if s_in is not None else D
+        segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
+        for i, (lo, hi, scale, edge) in enumerate(segs):
+            W, b = params[2 * i], params[2 * i + 1]
+            if hi <= lo:
+                continue
+            rs = norm[lo:hi] if (edge and norm is not None) else None
+            call("mrg_dense_filter_fwd", (kind, ptr(s[lo:hi]), ptr(s_in[lo:hi]) if s_in is not None else None, ptr(W), ptr(b),
+                                          ptr(rs), scale, ptr(out[lo:hi]), ptr(gate[lo:hi]) if gate is not None else None,
+                                          hi - lo, D, st),
+                 nbytes=4 * (hi - lo) * (K_ + D * (2 if kind == 0 else 1)), flops=2 * (hi - lo) * K_ * D)
+        ctx.cfg = (kind, b0, b1, scale_edge, scale_self)
+        ctx.save_for_backward(s, s_in, norm, gate, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, s_in, norm, gate, *params = ctx.saved_tensors
+        kind, b0, b1, scale_edge, scale_self = ctx.cfg
+        g = f32c(g)
+        M, D = s.shape
+        st = stream_of(s)
+        gs = torch.empty_like(s)
+        gs_in = torch.empty_like(s) if s_in is not None else None
+        K_ = 2 * D if s_in is not None else D
+        grads = []
+        segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
+        for i, (lo, hi, scale, edge) in enumerate(segs):
+            W, b = params[2 * i], params[2 * i + 1]
+            if W is None:
+                grads += [None, None]
+                continue
+            gW = torch.empty_like(W)
+            gb = torch.empty_like(b) if b is not None else None
+            rows = max(hi - lo, 0)
+            ws = _ws(_ws_bytes("mrg_dense_filter_bwd_workspace_bytes", rows, D, int(s_in is not None)), s)
+            rs = norm[lo:hi] if (edge and norm is not None and rows > 0) else None
+            sl = slice(lo, hi)
+            call("mrg_dense_filter_bwd", (kind, ptr(g[sl]), ptr(s[sl]), ptr(s_in[sl]) if s_in is not None else None, ptr(W),
+                                          ptr(gate[sl]) if gate is not None else None, ptr(rs), scale, ptr(gs[sl]),
+                                          ptr(gs_in[sl]) if gs_in is not None else None, ptr(gW), ptr(gb), ptr(ws), rows, D, st),
+                 nbytes=4 * rows * (K_ + 4 * D), flops=4 * rows * K_ * D)
+            grads += [gW, gb]
+        return (None, gs, gs_in, None, None, None, None, None, *grads)
+
+
+def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_self, b_self, self_scale):
+    """f_dense_comp (kind 0, self_scale 1/3) / f_comp (kind 1, self_scale 1)."""
+    return _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
+                              W_in, b_in, W_out, b_out, W_self, b_self)
+
+
+def dense_filter_single(s, s_in, W, b):
+    """f_dense_last (s_in None) / f_dense: sigmoid(W [s ; s_in] + b) * s on all rows."""
+    return _DenseFilter.apply(0, s, s_in, None, 0, 0, 1.0, 1.0, None, None, None, None, W, b)

@@ -113,12 +113,7 @@ class f_sparse_op(nn.Module):
         return K._Gate.apply(src_emb, src_emb_in, None, 0, 0, 1.0, *none3, *none3, self.W.weight, self.W.bias, self.a.weight)
 
 
-# ---- dense filters (GEMM + elementwise gate) ---------------------------------------
-def _thirds(g, e_in, e_out, x_self, self_scale):
-    e = torch.cat((e_in, e_out), dim=0) * (g.norm_flat().view(-1, 1) * (1.0 / 3.0))
-    return torch.cat((e, x_self * self_scale if self_scale != 1.0 else x_self), dim=0)
-
-
+# ---- dense (per-feature) filters: MFMA row GEMM with the gate / scale fused in its epilogue -----
 class f_dense_op_comp(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -128,12 +123,9 @@ class f_dense_op_comp(nn.Module):
         self.W_self = nn.Linear(2 * D, D, bias=True)
 
     def forward(self, g, src_emb, src_emb_in):
-        h, E = _bounds(g)
-        outs = []
-        for lin, sl in ((self.W_in, slice(0, h)), (self.W_out, slice(h, E)), (self.W_self, slice(E, None))):
-            s = src_emb[sl]
-            outs.append(torch.sigmoid(lin(torch.cat([s, src_emb_in[sl]], dim=1))) * s)
-        return _thirds(g, outs[0], outs[1], outs[2], 1.0 / 3.0)
+        b0, b1 = _bounds(g)
+        return K.dense_filter_comp(0, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, self.W_in.bias,
+                                   self.W_out.weight, self.W_out.bias, self.W_self.weight, self.W_self.bias, 1.0 / 3.0)
 
 
 class f_comp_op(nn.Module):
@@ -145,10 +137,9 @@ class f_comp_op(nn.Module):
         self.W_self = nn.Linear(2 * D, D, bias=False)
 
     def forward(self, g, src_emb, src_emb_in):
-        h, E = _bounds(g)
-        outs = [lin(torch.cat([src_emb[sl], src_emb_in[sl]], dim=1))
-                for lin, sl in ((self.W_in, slice(0, h)), (self.W_out, slice(h, E)), (self.W_self, slice(E, None)))]
-        return _thirds(g, outs[0], outs[1], outs[2], 1.0)       # self rows are NOT scaled (reference :285-287)
+        b0, b1 = _bounds(g)       # self rows are NOT scaled (reference :285-287)
+        return K.dense_filter_comp(1, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, None,
+                                   self.W_out.weight, None, self.W_self.weight, None, 1.0)
 
 
 class f_dense_op(nn.Module):
@@ -158,7 +149,7 @@ class f_dense_op(nn.Module):
         self.W = nn.Linear(2 * D, D, bias=True)
 
     def forward(self, g, src_emb, src_emb_in):
-        return torch.sigmoid(self.W(torch.cat([src_emb, src_emb_in], dim=1))) * src_emb
+        return K.dense_filter_single(src_emb, src_emb_in, self.W.weight, self.W.bias)
 
 
 class f_dense_op_last(nn.Module):
@@ -168,7 +159,7 @@ class f_dense_op_last(nn.Module):
         self.W = nn.Linear(D, D, bias=True)
 
     def forward(self, g, src_emb, src_emb_in):
-        return torch.sigmoid(self.W(src_emb)) * src_emb
+        return K.dense_filter_single(src_emb, None, self.W.weight, self.W.bias)
 
 
 # ---- a4 / a5 / a6: aggregators ---------------------------------------------------------

@@ -102,7 +102,7 @@ def test_star_ops_against_oracle(N, T, R, D, order):
     gen = torch.Generator().manual_seed(D)
     x, x_in = torch.randn(E + N, D, generator=gen), torch.randn(E + N, D, generator=gen)
     gM, gN = torch.randn(E + N, D, generator=gen), torch.randn(N, D, generator=gen)
-    for name in ("pre_mult", "pre_sub", "pre_add", "f_sparse_comp", "a_sum", "a_mean", "a_max"):
+    for name in ("pre_mult", "pre_sub", "pre_add", "f_sparse_comp", "f_dense_comp", "f_comp", "a_sum", "a_mean", "a_max"):
         P = OO.init_params(name, D, gen)
         for k in P:
             if k.endswith("bias"):
