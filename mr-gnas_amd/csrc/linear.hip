@@ -34,9 +34,9 @@ __device__ __forceinline__ XSel wgrad_sel_x(const WgradArgs& a, int c) {
 template <int TPW, int NPF, bool VEC4>      // TPW accumulator tiles per wave, NPF prefetch float4 per thread
 __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_k(WgradArgs a) {
   extern __shared__ __align__(16) float smem[];
-  const int tn0 = blockIdx.y * a.TNB;
-  const int tnb = a.TN - tn0 < a.TNB ? a.TN - tn0 : a.TNB;
-  const int ldg = a.TM * 32, ldx = a.TNB * 32, stage = WBR * (ldg + ldx);
+  const int tn0 = (int)(((int64_t)blockIdx.y * a.TN) / gridDim.y);                 // balanced split of the column tiles
+  const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
+  const int ldg = a.TM * 32, ldx = tnb * 32, stage = WBR * (ldg + a.TNB * 32);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int ntiles = a.TM * tnb;
   const int g4 = ldg / 4, x4 = ldx / 4, nf4 = WBR * (g4 + x4);      // float4 per staged tile
@@ -231,7 +231,7 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
   if (!X2 || K2 == 0) { a.X2 = X1; a.K2 = 0; }
   const bool vec = (Nout % 4 == 0) && (K1 % 4 == 0) && (a.K2 % 4 == 0) && aligned16(gY) && aligned16(X1) && aligned16(a.X2) &&
                    Nout >= 4 && K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
-  dim3 grid(p.G, (p.TN + p.TNB - 1) / p.TNB);
+  dim3 grid(p.G, (p.TN + p.TNB - 1) / p.TNB);      // y-blocks own ~TN/grid.y column tiles each (<= TNB)
 #define GO(T, F)                                                                                                       \
   do {                                                                                                                 \
     if (vec) {                                                                                                         \
