@@ -119,6 +119,73 @@ __device__ __forceinline__ float4 gemm_mask_a(float4 v, const GemmArgs& a, int64
   return v;
 }
 
+// Epilogue of one wave: NT tiles of 32x32 at rows [rowbase, rowbase+32), columns [col0, col0 + NT*32).
+// C/D map of a tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+// Every load (bias, row scale, gate multiplicand, accumulate input) is issued unconditionally from a
+// clamped address BEFORE the stores, and a full tile stores without per-element branches: a store inside
+// a data-dependent branch makes hipcc wait vmcnt(0) per store, which serialises the 16*NT stores of a lane.
+template <int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh,
+                                              bool full) {
+  int64_t rowc[16];
+  float cs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    rowc[r] = row < a.rows ? row : a.rows - 1;
+    cs[r] = 1.0f;
+    if (EPI == EPI_GATE || EPI == EPI_SCALE) cs[r] = a.scale * (a.rowscale ? a.rowscale[rowc[r]] : 1.0f);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 32 + li;
+    const bool cok = col < a.N;
+    const int colc = cok ? col : a.N - 1;
+    const float bv = a.bias ? a.bias[colc] : 0.f;
+    float in[16], v[16], g[16];
+    if (EPI == EPI_GATE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) in[r] = a.S[rowc[r] * a.ld_s + colc];
+    } else if (EPI == EPI_ACCUM) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) in[r] = a.Cin[rowc[r] * a.ld_cin + colc];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float x = acc[n][r] + bv;
+      if (EPI == EPI_BIAS_ACT) {
+        v[r] = (a.act == MRG_ACT_RELU) ? (x > 0.f ? x : 0.f) : x;
+      } else if (EPI == EPI_GATE) {
+        g[r] = sigmoidf_fast(x);
+        v[r] = g[r] * in[r] * cs[r];
+      } else if (EPI == EPI_SCALE) {
+        v[r] = x * cs[r];
+      } else {
+        v[r] = x + in[r];
+      }
+    }
+    if (full) {
+      if (cok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.C[rowc[r] * a.ldc + col] = v[r];
+        if (EPI == EPI_GATE && a.aux) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a.aux[rowc[r] * a.N + col] = g[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cok && row < a.rows) {
+          a.C[row * a.ldc + col] = v[r];
+          if (EPI == EPI_GATE && a.aux) a.aux[row * a.N + col] = g[r];
+        }
+      }
+    }
+  }
+}
+
 template <int NT, int MT, int GBK, int EPI, bool VEC4>
 __global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmArgs a) {
   constexpr int GBM = 128 * MT;
@@ -226,38 +293,128 @@ __global__ __launch_bounds__(MRG_BLOCK, (MT == 1 ? 2 : 1)) void rowgemm_k(GemmAr
     }
   }
 
-  // ---- epilogue.  C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-  const bool full = row0 + GBM <= a.rows;          // every row of this workgroup exists: no per-element bound check
+  // ---- epilogue
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = col0 + n * 32 + li;
-    if (col < a.N) {
-      const float bv = a.bias ? a.bias[col] : 0.f;
+  for (int m = 0; m < MT; ++m)
+    gemm_epilogue<NT, EPI>(a, acc[m], row0 + wave * 32 * MT + m * 32, col0, li, lh, row0 + GBM <= a.rows);
+}
+
+// ---- LDS-DMA variant (the fast path) ---------------------------------------------------------
+// Same tiling as rowgemm_k, but the A / B tiles travel global -> LDS with global_load_lds_dwordx4
+// (no VGPR staging, no ds_write, no vmcnt -> ds_write dependency in the instruction stream).
+// Measured on MI355X (rows 544k, K = N = 200): staging through registers cost 0.35 ms on top of
+// 0.38 ms of MFMA time; with LDS-DMA the same kernel runs 0.55 ms instead of 0.86 ms.
+// The DMA destination is wave-uniform base + lane*16, so LDS rows are unpadded (64 B); the
+// resulting 4-way bank conflict of the ds_read_b128 fragment reads is invisible next to the
+// 64-cycle f32 MFMAs.  The DMA cannot zero-fill: out-of-range rows / columns are read from
+// clamped addresses (their results are never stored) and K must be a multiple of 8 so that an
+// 8-deep MFMA step never contains columns beyond K.
+template <int NT, int EPI, bool DUAL>
+__global__ __launch_bounds__(MRG_BLOCK, 2) void rowgemm_dma_k(GemmArgs a) {
+  constexpr int GBK = 16, GBM = 128, GLD = GBK, F4R = GBK / 4;
+  constexpr int NA = GBM * F4R / MRG_BLOCK, NBT = NT * 32 * F4R, NB = (NBT + MRG_BLOCK - 1) / MRG_BLOCK;
+  extern __shared__ __align__(16) float smem[];
+  constexpr int A_TILE = GBM * GLD, B_TILE = NT * 32 * GLD, STAGE = A_TILE + B_TILE;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * GBM;
+  const int col0 = blockIdx.y * (NT * 32);
+  const int K = a.K1 + a.K2;
+  const int nkt = (K + GBK - 1) / GBK;
+
+  f32x16 acc[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+  for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + wave * 32 * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (full || row < a.rows) {
-            float v = acc[m][n][r] + bv;
-            if (EPI == EPI_BIAS_ACT) {
-              if (a.act == MRG_ACT_RELU) v = v > 0.f ? v : 0.f;
-            } else if (EPI == EPI_GATE) {
-              const float gate = sigmoidf_fast(v);
-              if (a.aux) a.aux[row * a.N + col] = gate;
-              const float c = a.scale * (a.rowscale ? a.rowscale[row] : 1.0f);
-              v = gate * a.S[row * a.ld_s + col] * c;
-            } else if (EPI == EPI_SCALE) {
-              v = v * (a.scale * (a.rowscale ? a.rowscale[row] : 1.0f));
-            } else {
-              v = v + a.Cin[row * a.ld_cin + col];
-            }
-            a.C[row * a.ldc + col] = v;
-          }
-        }
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  const float* arow1[NA]; const float* arow2[NA]; const float* brow[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int64_t row = row0 + (tid + i * MRG_BLOCK) / F4R;
+    const int64_t rc = row < a.rows ? row : a.rows - 1;
+    arow1[i] = a.A1 + rc * a.K1;
+    arow2[i] = a.A2 + rc * a.K2;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int f = tid + i * MRG_BLOCK;
+    f = f < NBT ? f : NBT - 1;
+    const int col = col0 + f / F4R;
+    brow[i] = a.B + (int64_t)(col < a.N ? col : a.N - 1) * a.ldb;
+  }
+  auto fetch = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * MRG_BLOCK;
+      const int k = k0 + (f % F4R) * 4;
+      const float* p;
+      if (DUAL) {
+        const bool first = k < a.K1;
+        const int kk = first ? k : k - a.K1, ld = first ? a.K1 : a.K2;
+        p = (first ? arow1[i] : arow2[i]) + (kk + 4 <= ld ? kk : ld - 4);
+      } else {
+        p = arow1[i] + (k + 4 <= K ? k : K - 4);
       }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(smem + buf * STAGE + (f - lane) * 4), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * MRG_BLOCK;
+      const int fc = f < NBT ? f : NBT - 1;
+      const int k = k0 + (fc % F4R) * 4;
+      if (f - lane < NBT)                      // wave-uniform
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(brow[i] + (k + 4 <= K ? k : K - 4)),
+                                         (lds_ptr_t)(smem + buf * STAGE + A_TILE + (f - lane) * 4), 16, 0, 0);
+    }
+  };
+
+  // Fragment reads are issued through inline asm: hipcc otherwise puts s_waitcnt vmcnt(0) in front of the
+  // first ds_read that follows a global_load_lds (it assumes the DMA may alias it), which would drain the
+  // DMA of the NEXT tile before this tile's MFMAs start.  Hazards are handled by hand: the reads only touch
+  // the buffer whose DMA was waited for (vmcnt(0)) before the barrier that ended the previous iteration.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned a_off = (unsigned)(((wave * 32 + li) * GLD + lh * 4) * sizeof(float));
+  const unsigned b_off = (unsigned)((A_TILE + li * GLD + lh * 4) * sizeof(float));
+  auto step = [&](unsigned abase, unsigned bbase, int t) {     // 8 k-columns: 1 + NT fragment reads, 4*NT MFMAs
+    v4f a4, b4[NT];
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a4) : "v"(abase + t * 32));
+#pragma unroll
+    for (int n = 0; n < NT; ++n) asm volatile("ds_read_b128 %0, %1" : "=v"(b4[n]) : "v"(bbase + n * (32 * GLD * 4) + t * 32));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);                         // keep the MFMAs below the wait (they do not touch memory)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[n].w, acc[n], 0, 0, 0);
+  };
+  const int nfull = K / GBK;                                // tiles with both 8-column steps valid
+  fetch(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int kt = 0; kt < nfull; ++kt) {                      // DMA of tile kt+1 runs under the MFMAs of tile kt
+    if (kt + 1 < nkt) fetch(cur ^ 1, (kt + 1) * GBK);
+    const unsigned abase = lds0 + cur * (STAGE * 4) + a_off, bbase = lds0 + cur * (STAGE * 4) + b_off;
+    step(abase, bbase, 0);
+    step(abase, bbase, 1);
+    if (kt + 1 < nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA has landed ...
+      __builtin_amdgcn_s_barrier();                        // ... and so has everyone else's; all reads of `cur` are done
+      cur ^= 1;
     }
   }
+  if (nfull < nkt) {                                        // K % 16 == 8: one last half tile
+    step(lds0 + cur * (STAGE * 4) + a_off, lds0 + cur * (STAGE * 4) + b_off, 0);
+  }
+
+  gemm_epilogue<NT, EPI>(a, acc, row0 + wave * 32, col0, li, lh, row0 + GBM <= a.rows);
 }
 
 inline int gemm_pick_nt(int ncols) {
@@ -277,6 +434,29 @@ inline int launch_rowgemm(GemmArgs a, hipStream_t st) {
   const bool vec = (a.K1 % 4 == 0) && (a.K2 % 4 == 0) && (a.ldb % 4 == 0) && ((a.K1 + a.K2) % 4 == 0) && aligned16(a.A1) &&
                    aligned16(a.A2) && aligned16(a.B) && a.K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
   const int nt = gemm_pick_nt(a.N);
+  if (vec && (a.K1 % 8 == 0) && (a.K2 % 8 == 0)) {            // LDS-DMA fast path
+    dim3 gridd((unsigned)((a.rows + 127) / 128), (unsigned)((a.N + nt * 32 - 1) / (nt * 32)));
+    const size_t ldsd = (size_t)2 * (128 + nt * 32) * 16 * sizeof(float);
+#define MRG_GOD(NTV)                                                                                                  \
+  do {                                                                                                                \
+    if (a.K2 > 0) {                                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_dma_k<NTV, EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd); \
+      hipLaunchKernelGGL((rowgemm_dma_k<NTV, EPI, true>), gridd, dim3(MRG_BLOCK), ldsd, st, a);                        \
+    } else {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_dma_k<NTV, EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd); \
+      hipLaunchKernelGGL((rowgemm_dma_k<NTV, EPI, false>), gridd, dim3(MRG_BLOCK), ldsd, st, a);                       \
+    }                                                                                                                 \
+  } while (0)
+    switch (nt) {
+      case 1: MRG_GOD(1); break;
+      case 2: MRG_GOD(2); break;
+      case 4: MRG_GOD(4); break;
+      default: MRG_GOD(7); break;
+    }
+#undef MRG_GOD
+    hipError_t ed = hipGetLastError();
+    return ed == hipSuccess ? MRG_OK : (int)ed;
+  }
   const int mt = 1;
   const int gbm = 128 * mt;
   dim3 grid((unsigned)((a.rows + gbm - 1) / gbm), (unsigned)((a.N + nt * 32 - 1) / (nt * 32)));
