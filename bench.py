@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 MFMA_F32_PEAK_TFS = 157.3  # dense f32-input MFMA peak (same guide)
-MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_linrelu_segmax_fwd"}
+MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_dense_filter_fwd", "mrg_dense_filter_bwd"}
 
 
 def parse():

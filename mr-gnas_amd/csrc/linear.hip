@@ -154,6 +154,124 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_k(WgradAr
   }
 }
 
+// ---- LDS-DMA variant of the weight gradient (vector path) -------------------------------------
+// Tiles go global -> LDS with global_load_lds_dwordx4 (no register staging, no ds_write); the DMA
+// cannot synthesise values, so rows beyond the chunk and padding columns are sourced from a block
+// of zeros and the appended bias column from a {1,0,0,0} constant.  MFMA operands are read with
+// inline-asm ds_read_b32 so that hipcc does not drain the in-flight DMA before every LDS read.
+static __device__ float mrg_zeros16[4] = {0.f, 0.f, 0.f, 0.f};
+static __device__ float mrg_ones16[4] = {1.f, 0.f, 0.f, 0.f};
+
+template <int TPW, int NPF>
+__global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_dma_k(WgradArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int tn0 = (int)(((int64_t)blockIdx.y * a.TN) / gridDim.y);
+  const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
+  const int ldg = a.TM * 32, ldx = tnb * 32, stage = WBR * (ldg + a.TNB * 32);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int ntiles = a.TM * tnb;
+  const int g4 = ldg / 4, x4 = ldx / 4, nf4 = WBR * (g4 + x4);
+  const int K = a.K1 + a.K2;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r_end = r_begin + a.rows_per_block;
+  if (r_end > a.rows) r_end = a.rows;
+
+  // loop-invariant DMA metadata of this thread's float4 slots
+  const float* src[NPF]; int64_t stride[NPF]; int rr[NPF]; int kind[NPF];     // kind: 0 data, 1 ones, 2 zeros
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int f = tid + i * MRG_BLOCK;
+    const bool isg = f < WBR * g4;
+    const int f2 = isg ? f : (f < nf4 ? f - WBR * g4 : 0);
+    const int per = isg ? g4 : x4;
+    const int r = f2 / per, c = (f2 - r * per) * 4 + (isg ? 0 : tn0 * 32);
+    rr[i] = r;
+    if (isg) {
+      kind[i] = c < a.Nout ? 0 : 2;
+      src[i] = a.gY + (r_begin + r) * a.Nout + (c < a.Nout ? c : 0);
+      stride[i] = (int64_t)WBR * a.Nout;
+    } else {
+      const XSel sx = wgrad_sel_x(a, c < K ? c : 0);
+      kind[i] = c < K ? 0 : (c == K ? 1 : 2);
+      src[i] = sx.base + (r_begin + r) * sx.ld + sx.kk;
+      stride[i] = (int64_t)WBR * sx.ld;
+    }
+  }
+  auto fetch = [&](int buf, int64_t r0, int64_t tile) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int f = tid + i * MRG_BLOCK;
+      if (f - lane < nf4) {                                 // wave-uniform: this wave-instruction has work
+        const bool rv = r0 + rr[i] < r_end;
+        const float* p = (rv && kind[i] == 0) ? src[i] + tile * stride[i] : ((rv && kind[i] == 1) ? mrg_ones16 : mrg_zeros16);
+        if (f < nf4)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(smem + buf * stage + (f - lane) * 4), 16, 0, 0);
+      }
+    }
+  };
+  // per-tile LDS byte offsets of this lane's operands
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned goff[TPW], xoff[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int id = wave + 4 * i;
+    const int m = id < ntiles ? id / tnb : 0, n = id < ntiles ? id - m * tnb : 0;
+    goff[i] = (unsigned)((lh * ldg + m * 32 + li) * 4);
+    xoff[i] = (unsigned)((WBR * ldg + lh * ldx + n * 32 + li) * 4);
+  }
+  if (r_begin < r_end) fetch(0, r_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  int64_t tile = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR, ++tile) {
+    const bool more = r0 + WBR < r_end;
+    if (more) fetch(cur ^ 1, r0 + WBR, tile + 1);
+    const unsigned base = lds0 + cur * stage * 4;
+#pragma unroll 1
+    for (int t = 0; t < WBR / 2; ++t) {
+      float gv[TPW], xv[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        asm volatile("ds_read_b32 %0, %1" : "=v"(gv[i]) : "v"(base + goff[i] + t * 2 * ldg * 4));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(xv[i]) : "v"(base + xoff[i] + t * 2 * ldx * 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        if (wave + 4 * i < ntiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[i], xv[i], acc[i], 0, 0, 0);
+    }
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur ^= 1;
+    }
+  }
+  const int ldw = a.TN * 32;
+  float* out = a.ws + (int64_t)blockIdx.x * ldg * ldw;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int id = wave + 4 * i;
+    if (id < ntiles) {
+      const int m = id / tnb, n = id - m * tnb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(int64_t)row * ldw + (tn0 + n) * 32 + li] = acc[i][r];
+      }
+    }
+  }
+}
+
 // gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
 // thread row ty sums the partial tiles g = ty, ty+16, ..., the 16 row sums are added in order.
 __global__ void wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
@@ -235,8 +353,8 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
 #define GO(T, F)                                                                                                       \
   do {                                                                                                                 \
     if (vec) {                                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k<T, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-      hipLaunchKernelGGL((wgrad_k<T, F, true>), grid, dim3(MRG_BLOCK), p.lds, st, a);                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_k<T, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+      hipLaunchKernelGGL((wgrad_dma_k<T, F>), grid, dim3(MRG_BLOCK), p.lds, st, a);                                    \
     } else {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k<T, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
       hipLaunchKernelGGL((wgrad_k<T, F, false>), grid, dim3(MRG_BLOCK), p.lds, st, a);                                 \
