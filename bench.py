@@ -23,12 +23,14 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+_lib = None
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 MFMA_F32_PEAK_TFS = 157.3  # dense f32-input MFMA peak (same guide)
-MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_dense_filter_fwd", "mrg_dense_filter_bwd"}
+MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_dense_filter_fwd"}
 
 
 def parse():
@@ -131,6 +133,52 @@ def host_cores():
     return cores
 
 
+def north_star_kernel(step, dim, reps=20):
+    """The fused per-relation gather -> compose -> segmented-sum kernel (CompGCN aggregation, reference
+    models/compgcn.py:58-87) on the benchmark graph: segments = (destination, direction), 'sub' compose.
+    bytes_alg per SURVEY section 8d: E*(8 + 4D) + 4*(nseg+1) + 4D*(R' + nseg)."""
+    from mr_gnas_amd import functional as K
+    g = step.g
+    src, dst, _ = g.edges(form="all")
+    E, N, dev = g.num_edges(), g.number_of_nodes(), src.device
+    if E == 0:
+        return None
+    Rp = int(g.edata["e_type"].max().item()) + 2
+    b0, _ = g.bounds()
+    direction = (torch.arange(E, device=dev) >= b0).long()
+    cp = K.ComposePlan(src, g.edata["e_type"], dst * 2 + direction, g.norm_flat(), N, Rp, 2 * N)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    ent = torch.randn(N, dim, device=dev, generator=gen)
+    rel = torch.randn(Rp, dim, device=dev, generator=gen)
+    for _ in range(3):
+        K.span_gcs("sub", ent, rel, cp.m_fwd, cp.sp_seg)
+    _lib.meter.start(["mrg_span_gcs"])
+    for _ in range(reps):
+        K.span_gcs("sub", ent, rel, cp.m_fwd, cp.sp_seg)
+    st = _lib.meter.stop()["mrg_span_gcs"]
+    sec = st["ms"] / 1e3 / st["launches"]
+    nbytes = st["bytes"] / st["launches"]
+    return {"kernel": "mrg_span_gcs (CompGCN aggregation, compose=sub)", "bound": "hbm", "edges": E, "segments": 2 * N, "dim": dim,
+            "bytes_alg": int(nbytes), "us_per_launch": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "g_edges_per_s": round(E / sec / 1e9, 3)}
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if kernel in t.get("per_launch_bytes", {}):
+                best = t["per_launch_bytes"][kernel]
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(args, state, alphas):
     """The CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores
     on a bounded sample: one supernet step on a `--cpu-sample`-triple sampled step graph."""
@@ -190,6 +238,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    global _lib
     from mr_gnas_amd import _lib
     _lib.load()
 
@@ -257,10 +306,13 @@ def main():
     if dominant and dominant in dom_stats:
         d = dom_stats[dominant]
         out["roofline"] = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                           "unit": d["unit"], "frac": d["frac"], "traffic": None, "launches": d["launches"],
+                           "unit": d["unit"], "frac": d["frac"], "traffic": load_traffic(dominant), "launches": d["launches"],
                            "us_per_launch": d["us_per_launch"],
                            "share_of_step": round(d["ms_total"] / (ms_per_step * args.steps), 4)}
     out["kernels"] = table
+    if world == 1 and not sharded:
+        log("timing the fused compose+scatter kernel (north-star kernel) on the benchmark graph")
+        out["north_star_kernel"] = north_star_kernel(step, args.dim)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         state = step.model.state_dict()
         log("timing the CPU oracle on the bounded sample")

@@ -214,15 +214,17 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  * Y[rows, Nout] = act(X[rows, K] W[Nout, K]^T + bias) */
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y,
                    int64_t rows, int K, int Nout, int act, void *stream);
-/* gX[rows, K] = gY[rows, Nout] W[Nout, K]   (gY already masked by the activation);
- * ws holds W^T (mrg_linear_bwd_input_workspace_bytes). */
+/* gX[rows, K] (+)= gY[rows, Nout] W[:, 0:K]   (gY already masked by the activation).  W is
+ * [Nout][ldw] row-major, ldw >= K (a column block of a wider weight, e.g. one half of an
+ * nn.Linear(2D, D)); accumulate != 0 adds into gX.  ws holds the transposed block. */
 int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout);
 int mrg_linear_bwd_input(const float *gY, const float *W, float *gX, void *ws,
-                         int64_t rows, int K, int Nout, void *stream);
-/* gW[Nout, K] = gY^T X,  gbias[Nout] = column sums of gY (NULL ok). */
+                         int64_t rows, int K, int Nout, int ldw, int accumulate, void *stream);
+/* gW[Nout, K1+K2] = gY^T [X1 | X2]  (X2 NULL / K2 = 0: single source; the reference's
+ * torch.cat([s, s_in], 1) is never materialised),  gbias[Nout] = column sums of gY (NULL ok). */
 int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout);
-int mrg_linear_bwd_weight(const float *gY, const float *X, float *gW, float *gbias, void *ws,
-                          int64_t rows, int K, int Nout, void *stream);
+int mrg_linear_bwd_weight(const float *gY, const float *X1, const float *X2, float *gW, float *gbias, void *ws,
+                          int64_t rows, int K1, int K2, int Nout, void *stream);
 
 /* ---- dense (per-feature) filters, one direction segment per call ------------------
  * f_dense_op_comp / f_comp_op / f_dense_op_last / f_dense_op .forward,
@@ -232,16 +234,15 @@ int mrg_linear_bwd_weight(const float *gY, const float *X, float *gW, float *gbi
  *   kind 1:  out = z * c
  *   c = scale * (rowscale ? rowscale[row] : 1)     (the reference's 1/3 and edge norm)
  * torch.cat([s, s_in], 1) is never materialised: the GEMM reads both sources; gate, scale and
- * norm are applied in its epilogue.  Backward: gs, gs_in [rows, D] (fully written), gW [D, K],
- * gbias [D] (NULL ok). */
+ * norm are applied in its epilogue. */
 int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const float *W, const float *bias,
                          const float *rowscale, float scale, float *out, float *gate,
                          int64_t rows, int D, void *stream);
-int64_t mrg_dense_filter_bwd_workspace_bytes(int64_t rows, int D, int has_in);
-int mrg_dense_filter_bwd(int kind, const float *g, const float *s, const float *s_in, const float *W,
-                         const float *gate, const float *rowscale, float scale,
-                         float *gs, float *gs_in, float *gW, float *gbias, void *ws,
-                         int64_t rows, int D, void *stream);
+/* backward, step 1:  kind 0: dz = g*s*c*gate*(1-gate), gs = g*c*gate (direct term);  kind 1: dz = g*c.
+ * Steps 2-3 are mrg_linear_bwd_input (gs += dz W[:, :D]; gs_in = dz W[:, D:]) and
+ * mrg_linear_bwd_weight (gW = dz^T [s | s_in], gbias = column sums of dz). */
+int mrg_dense_filter_dz(int kind, const float *g, const float *s, const float *gate, const float *rowscale,
+                        float scale, float *dz, float *gs, int64_t rows, int D, void *stream);
 
 #ifdef __cplusplus
 }

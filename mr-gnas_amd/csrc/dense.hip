@@ -9,9 +9,6 @@
 #include "gemm.hpp"
 
 namespace mrg {
-int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int K2, float* gW, float* gbias, void* ws,
-                 int64_t rows, int Nout, hipStream_t st);
-int64_t wgrad_workspace_bytes(int64_t rows, int K, int Nout);
 
 // kind 0 (gate):   dz = g * s * c * gate * (1 - gate);  gs = g * c * gate     (c = scale * rowscale[row])
 // kind 1 (linear): dz = g * c
@@ -49,8 +46,6 @@ __global__ __launch_bounds__(MRG_BLOCK) void dense_dz_k(const float* __restrict_
   }
 }
 
-static int64_t round16(int64_t b) { return (b + 15) & ~(int64_t)15; }
-
 }  // namespace mrg
 
 using namespace mrg;
@@ -75,35 +70,19 @@ extern "C" int mrg_dense_filter_fwd(int kind, const float* s, const float* s_in,
   return launch_rowgemm<EPI_SCALE>(a, (hipStream_t)stream);
 }
 
-extern "C" int64_t mrg_dense_filter_bwd_workspace_bytes(int64_t rows, int D, int has_in) {
-  if (rows < 0 || D <= 0) return 0;
-  const int K = has_in ? 2 * D : D;
-  return round16((int64_t)rows * D * 4) + round16((int64_t)K * D * 4) + wgrad_workspace_bytes(rows, K, D) + 64;
-}
-
-extern "C" int mrg_dense_filter_bwd(int kind, const float* g, const float* s, const float* s_in, const float* W,
-                                    const float* gate, const float* rowscale, float scale, float* gs, float* gs_in,
-                                    float* gW, float* gbias, void* ws, int64_t rows, int D, void* stream) {
+// dz (and, for the gated kinds, the direct term of the gradient w.r.t. s):
+//   kind 0:  dz = g * s * c * gate * (1 - gate),  gs = g * c * gate
+//   kind 1:  dz = g * c                            (gs untouched)
+// The caller then runs mrg_linear_bwd_input (dz W[:, :D] accumulated into gs, dz W[:, D:] into gs_in) and
+// mrg_linear_bwd_weight (dz^T [s | s_in]).
+extern "C" int mrg_dense_filter_dz(int kind, const float* g, const float* s, const float* gate, const float* rowscale,
+                                   float scale, float* dz, float* gs, int64_t rows, int D, void* stream) {
   if (kind != 0 && kind != 1) return MRG_E_ENUM;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
-  if (!gW) return MRG_E_NULLPTR;
+  if (rows == 0) return MRG_OK;
+  if (!g || !dz) return MRG_E_NULLPTR;
+  if (kind == 0 && (!s || !gate || !gs)) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
-  const int K = s_in ? 2 * D : D;
-  if (rows == 0) {
-    hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)D * K, st);
-    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)D, st);
-    return (int)e;
-  }
-  if (!g || !s || !W || !gs) return MRG_E_NULLPTR;
-  if (kind == 0 && !gate) return MRG_E_NULLPTR;
-  if (s_in && !gs_in) return MRG_E_NULLPTR;
-  if (!ws) return MRG_E_WORKSPACE;
-  char* wsb = (char*)ws;
-  float* dz = (float*)wsb;
-  float* Wt = (float*)(wsb + round16(rows * (int64_t)D * 4));
-  void* ws_w = wsb + round16(rows * (int64_t)D * 4) + round16((int64_t)K * D * 4);
-
-  // 1. dz (and the direct term of gs for the gated kinds)
   RowGeom gm = row_geom(D, aligned16(g) && aligned16(s) && aligned16(gate) && aligned16(gs) && aligned16(dz));
   if (!gm.ok) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                                \
@@ -115,29 +94,5 @@ extern "C" int mrg_dense_filter_bwd(int kind, const float* g, const float* s, co
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();
-
-  // 2. W^T halves, row-major [D(k-col)][D(out)] each
-  launch_transpose(W, Wt, D, D, K, st);                                   // (W[:, :D])^T
-  if (s_in) launch_transpose(W + D, Wt + (int64_t)D * D, D, D, K, st);    // (W[:, D:])^T
-  MRG_LAUNCH_CHECK();
-
-  // 3. gs (+)= dz * W[:, :D]      4. gs_in = dz * W[:, D:]
-  GemmArgs a{};
-  a.A1 = dz; a.K1 = D; a.B = Wt; a.ldb = D; a.C = gs; a.ldc = D; a.N = D; a.rows = rows; a.act = MRG_ACT_NONE;
-  int rc;
-  if (kind == 0) {
-    a.Cin = gs; a.ld_cin = D;
-    rc = launch_rowgemm<EPI_ACCUM>(a, st);
-  } else {
-    rc = launch_rowgemm<EPI_BIAS_ACT>(a, st);
-  }
-  if (rc != MRG_OK) return rc;
-  if (s_in) {
-    GemmArgs b{};
-    b.A1 = dz; b.K1 = D; b.B = Wt + (int64_t)D * D; b.ldb = D; b.C = gs_in; b.ldc = D; b.N = D; b.rows = rows; b.act = MRG_ACT_NONE;
-    rc = launch_rowgemm<EPI_BIAS_ACT>(b, st);
-    if (rc != MRG_OK) return rc;
-  }
-  // 5. gW = dz^T [s | s_in], gbias = column sums of dz
-  return launch_wgrad(dz, s, s_in, D, s_in ? D : 0, gW, gbias, ws_w, rows, D, st);
+  return MRG_OK;
 }

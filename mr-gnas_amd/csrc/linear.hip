@@ -400,17 +400,23 @@ extern "C" int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout) {
   return (int64_t)K * Nout * sizeof(float);
 }
 
+// gX[rows, K] (+)= gY[rows, Nout] * W[:, 0:K]   where W is [Nout][ldw] row-major (ldw >= K: a column block
+// of a wider weight, e.g. one half of an nn.Linear(2D, D)); accumulate != 0 adds into the existing gX.
 extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, void* ws, int64_t rows, int K, int Nout,
-                                    void* stream) {
-  if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
+                                    int ldw, int accumulate, void* stream) {
+  if (rows < 0 || K <= 0 || Nout <= 0 || ldw < K) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!gY || !W || !gX) return MRG_E_NULLPTR;
   if (!ws) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  // gX[rows, K] = gY[rows, Nout] * W[Nout, K]: present W^T [K][Nout] row-major to the core
-  launch_transpose(W, (float*)ws, Nout, K, K, st);
+  // present (W[:, 0:K])^T = [K][Nout] row-major to the core
+  launch_transpose(W, (float*)ws, Nout, K, ldw, st);
   GemmArgs a{};
   a.A1 = gY; a.K1 = Nout; a.B = (const float*)ws; a.ldb = Nout; a.C = gX; a.ldc = K; a.N = K; a.rows = rows; a.act = MRG_ACT_NONE;
+  if (accumulate) {
+    a.Cin = gX; a.ld_cin = K;
+    return launch_rowgemm<EPI_ACCUM>(a, st);
+  }
   return launch_rowgemm<EPI_BIAS_ACT>(a, st);
 }
 
@@ -419,11 +425,12 @@ extern "C" int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, in
   return wgrad_workspace_bytes(rows, K, Nout);
 }
 
-extern "C" int mrg_linear_bwd_weight(const float* gY, const float* X, float* gW, float* gbias, void* ws, int64_t rows, int K,
-                                     int Nout, void* stream) {
-  if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
+// gW[Nout][K1+K2] = gY^T [X1 | X2] (X2 NULL / K2 = 0: single source), gbias[Nout] = column sums of gY (NULL ok)
+extern "C" int mrg_linear_bwd_weight(const float* gY, const float* X1, const float* X2, float* gW, float* gbias, void* ws,
+                                     int64_t rows, int K1, int K2, int Nout, void* stream) {
+  if (rows < 0 || K1 <= 0 || K2 < 0 || Nout <= 0) return MRG_E_SHAPE;
   if (!gW) return MRG_E_NULLPTR;
-  if (rows > 0 && (!gY || !X)) return MRG_E_NULLPTR;
+  if (rows > 0 && (!gY || !X1 || (K2 > 0 && !X2))) return MRG_E_NULLPTR;
   if (rows > 0 && !ws) return MRG_E_WORKSPACE;
-  return launch_wgrad(gY, X, nullptr, K, 0, gW, gbias, ws, rows, Nout, (hipStream_t)stream);
+  return launch_wgrad(gY, X1, K2 > 0 ? X2 : nullptr, K1, K2, gW, gbias, ws, rows, Nout, (hipStream_t)stream);
 }

@@ -271,12 +271,12 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", K, Nout), x)
-            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), ptr(wt), rows, K, Nout, st), **work)
+            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), ptr(wt), rows, K, Nout, K, 0, st), **work)
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             gW = torch.empty_like(W)
             gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None
             ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K, Nout), x)
-            call("mrg_linear_bwd_weight", (ptr(g), ptr(x), ptr(gW), ptr(gb), ptr(ws), rows, K, Nout, st), **work)
+            call("mrg_linear_bwd_weight", (ptr(g), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), rows, K, 0, Nout, st), **work)
         return gx, gW, gb, None
 
 
@@ -599,13 +599,24 @@ class _DenseFilter(torch.autograd.Function):
             gW = torch.empty_like(W)
             gb = torch.empty_like(b) if b is not None else None
             rows = max(hi - lo, 0)
-            ws = _ws(_ws_bytes("mrg_dense_filter_bwd_workspace_bytes", rows, D, int(s_in is not None)), s)
             rs = norm[lo:hi] if (edge and norm is not None and rows > 0) else None
             sl = slice(lo, hi)
-            call("mrg_dense_filter_bwd", (kind, ptr(g[sl]), ptr(s[sl]), ptr(s_in[sl]) if s_in is not None else None, ptr(W),
-                                          ptr(gate[sl]) if gate is not None else None, ptr(rs), scale, ptr(gs[sl]),
-                                          ptr(gs_in[sl]) if gs_in is not None else None, ptr(gW), ptr(gb), ptr(ws), rows, D, st),
-                 nbytes=4 * rows * (K_ + 4 * D), flops=4 * rows * K_ * D)
+            dz = torch.empty(rows, D, dtype=torch.float32, device=s.device)
+            # 1. dz (+ direct term of gs for the gated kinds)
+            call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(rs), scale,
+                                         ptr(dz), ptr(gs[sl]), rows, D, st), nbytes=4 * rows * D * (5 if kind == 0 else 2))
+            # 2. gs (+)= dz W[:, :D];  gs_in = dz W[:, D:]
+            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s)
+            gwork = dict(nbytes=4 * rows * 2 * D + 4 * D * D, flops=2 * rows * D * D)
+            call("mrg_linear_bwd_input", (ptr(dz), ptr(W), ptr(gs[sl]), ptr(wt), rows, D, D, K_, int(kind == 0), st), **gwork)
+            if s_in is not None:
+                wt2 = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s)
+                call("mrg_linear_bwd_input", (ptr(dz), ptr(W[:, D:]), ptr(gs_in[sl]), ptr(wt2), rows, D, D, K_, 0, st), **gwork)
+            # 3. gW = dz^T [s | s_in], gb = column sums of dz
+            ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)
+            call("mrg_linear_bwd_weight", (ptr(dz), ptr(s[sl]), ptr(s_in[sl]) if s_in is not None else None, ptr(gW), ptr(gb), ptr(ws),
+                                           rows, D, D if s_in is not None else 0, D, st),
+                 nbytes=4 * rows * (D + K_), flops=2 * rows * K_ * D)
             grads += [gW, gb]
         return (None, gs, gs_in, None, None, None, None, None, *grads)
 

@@ -77,8 +77,12 @@ def test_fused_gcs_large_with_hubs():
     X, Y = torch.randn(N, D, generator=gen), torch.randn(R, D, generator=gen)
     cp = K.ComposePlan(src.to(DEV), et.to(DEV), dst.to(DEV), s.to(DEV), N, R, N)
     idx = (torch.arange(D).view(-1, 1) + torch.arange(D).view(1, -1)) % D
-    for kind in ("sub", "mul", "ccorr"):
-        out = K.fused_gcs(kind, X.to(DEV), cp.xi, Y.to(DEV), cp.yi, cp.scal, cp.by_seg, N).cpu()
+    for kind in ("sub", "mul", "ccorr", "span_sub", "span_mul"):
+        if kind.startswith("span_"):          # balanced span kernel (what CompGraphConv uses for sub / mul)
+            kind = kind[5:]
+            out = K.span_gcs(kind, X.to(DEV), Y.to(DEV), cp.m_fwd, cp.sp_seg).cpu()
+        else:                                 # chunk kernel
+            out = K.fused_gcs(kind, X.to(DEV), cp.xi, Y.to(DEV), cp.yi, cp.scal, cp.by_seg, N).cpu()
         x, y = X[src].double(), (Y[et] * s.view(-1, 1)).double()
         if kind == "sub":
             msg = x - y
