@@ -142,9 +142,10 @@ int mrg_seg_reduce_fwd(int mode, const float *msg, const float *self_rows,
                        int64_t N, int D, void *stream);
 /* gmsg [E, D]: sum  gmsg[e] = gout[dst[e]];  mean  gout[dst[e]] / max(deg,1);
  * max  gmsg[e,c] = (arg[dst[e],c] == e) ? gout[dst[e],c] : 0.
- * gself [N, D] = gout (skipped when NULL). */
+ * gself [N, D] = gout (skipped when NULL).  relu_src [E, D] (NULL ok): the messages were ReLU
+ * outputs (a_max / a_mean), gmsg is additionally zeroed where relu_src <= 0. */
 int mrg_seg_reduce_bwd(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree,
-                       const int32_t *arg, float *gmsg, float *gself,
+                       const int32_t *arg, float *gmsg, float *gself, const float *relu_src,
                        int64_t E, int64_t N, int D, void *stream);
 
 /* ---- a9: fused gather -> compose -> segmented sum ------------------------------

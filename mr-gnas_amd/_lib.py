@@ -42,7 +42,7 @@ SIGNATURES = {
     "mrg_gate_param_grad": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mrg_seg_reduce_workspace_bytes": (_L, [_L, _I]),
     "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
-    "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_span_gcs": (_I, [_I, _P, _P, _P, _L, _I, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict
 template <int VEC, int LPR, int KMAX, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__ gout, const int32_t* __restrict__ dst,
                                                        const int32_t* __restrict__ in_degree, const int32_t* __restrict__ arg,
-                                                       float* __restrict__ gmsg, float* __restrict__ gself, int64_t E,
-                                                       int64_t rows, int D) {
+                                                       float* __restrict__ gmsg, float* __restrict__ gself,
+                                                       const float* __restrict__ relu_src, int64_t E, int64_t rows, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
@@ -94,6 +94,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__
             IVec<VEC> a = IVec<VEC>::load(arg + v * D + c * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) g[j] = (a[j] == (int)r) ? g[j] : 0.f;
+          }
+          if (relu_src) {            // the messages were ReLU outputs: mask the gradient where they are 0
+            Vec<VEC> y = Vec<VEC>::load(relu_src + r * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] = y[j] > 0.f ? g[j] : 0.f;
           }
         }
         g.store(o + c * VEC);
@@ -153,7 +158,8 @@ extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_
 }
 
 extern "C" int mrg_seg_reduce_bwd(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree,
-                                  const int32_t* arg, float* gmsg, float* gself, int64_t E, int64_t N, int D, void* stream) {
+                                  const int32_t* arg, float* gmsg, float* gself, const float* relu_src, int64_t E, int64_t N,
+                                  int D, void* stream) {
   if (mode < 0 || mode > 2) return MRG_E_ENUM;
   if (E < 0 || N < 0 || D <= 0) return MRG_E_SHAPE;
   if (!gout || (E > 0 && (!dst || !gmsg))) return MRG_E_NULLPTR;
@@ -162,14 +168,14 @@ extern "C" int mrg_seg_reduce_bwd(int mode, const float* gout, const int32_t* ds
   const int64_t rows = E + (gself ? N : 0);
   if (rows == 0) return MRG_OK;
   hipStream_t st = (hipStream_t)stream;
-  RowGeom g = row_geom(D, aligned16(gout) && aligned16(gmsg) && aligned16(gself) && aligned16(arg));
+  RowGeom g = row_geom(D, aligned16(gout) && aligned16(gmsg) && aligned16(gself) && aligned16(arg) && aligned16(relu_src));
   if (!g.ok) return MRG_E_SHAPE;
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
     int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                    \
-    if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
-    else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
-    else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, E, rows, D); \
+    if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
+    else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
+    else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL

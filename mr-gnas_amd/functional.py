@@ -159,12 +159,12 @@ def _seg_fwd(mode, msg, self_rows, p, N, D, want_arg=True):
     return out, arg
 
 
-def _seg_bwd(mode, g, graph, arg, gmsg, gself):
+def _seg_bwd(mode, g, graph, arg, gmsg, gself, relu_src=None):
     p = graph.plan()
     E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
-    nb = 4 * D * E + 4 * E + 4 * D * N * (1 + (gself is not None) + (mode == 2))
+    nb = 4 * D * E * (1 + (relu_src is not None)) + 4 * E + 4 * D * N * (1 + (gself is not None) + (mode == 2))
     call("mrg_seg_reduce_bwd", (mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), ptr(gself),
-                                E, N, D, stream_of(g)), nbytes=nb)
+                                ptr(relu_src), E, N, D, stream_of(g)), nbytes=nb)
 
 
 class _SegReduce(torch.autograd.Function):
@@ -236,6 +236,60 @@ class _AggRows(torch.autograd.Function):
 
 def aggregate_rows(kind, x, graph, add_self=True):
     return _AggRows.apply(REDUCE[kind], x, graph, add_self)
+
+
+class _LinReluAgg(torch.autograd.Function):
+    """a_max / a_mean as ONE autograd node on the reference's [M, D] layout
+    (reference models/operations_lp.py:230-235, 245-250):
+        m = ReLU(Linear(x[:E]));  h = reduce_{e -> v} m[e];  out = h + x[E:]
+    The backward writes the gradient of x once (rows [0,E) from the input-gradient GEMM, rows [E,M) a copy of
+    the incoming gradient) instead of two zero-padded slice gradients that autograd would add, and the ReLU
+    mask is applied inside the reducer's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, mode, x, W, b, graph):
+        x, W, b = f32c(x), f32c(W), f32c(b)
+        require_hip(x, W, b)
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
+        if x.shape[0] != E + N:
+            raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
+        st = stream_of(x)
+        y = torch.empty(E, D, dtype=torch.float32, device=x.device)
+        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), E, D, D, 1, st),
+             nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
+        if mode == 2:
+            out, arg = _seg_fwd(2, y, x[E:], graph.plan(), N, D)
+        else:
+            sp, meta = graph.agg_plan("mean" if mode == 1 else "sum")
+            out, arg = span_gcs("copy", y, None, meta, sp), None
+            out += x[E:]
+        ctx.mode, ctx.graph = mode, graph
+        ctx.save_for_backward(x, W, y, *((arg,) if arg is not None else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, *rest = ctx.saved_tensors
+        arg = rest[0] if rest else None
+        graph, mode = ctx.graph, ctx.mode
+        g = f32c(g)
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
+        st = stream_of(x)
+        gx = torch.empty_like(x)
+        gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
+        _seg_bwd(mode, g, graph, arg, gy, gx[E:], relu_src=y)          # gy masked by ReLU; gx[E:] = g
+        work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
+        wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
+        call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
+        gW = torch.empty_like(W)
+        gb = torch.empty(D, dtype=torch.float32, device=x.device)
+        ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", E, D, D), x)
+        call("mrg_linear_bwd_weight", (ptr(gy), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), E, D, 0, D, st), **work)
+        return None, gx, gW, gb, None
+
+
+def linear_relu_aggregate(kind, x, W, b, graph):
+    return _LinReluAgg.apply(REDUCE[kind], x, W, b, graph)
 
 
 # ---------------------------------------------------------------------------

@@ -172,9 +172,7 @@ class _LinReluAgg(nn.Module):
         self.linear = nn.Linear(D, D)
 
     def forward(self, block, src_emb, src_emb_in):
-        E = block.num_edges()
-        m = K.linear(src_emb[:E], self.linear.weight, self.linear.bias, act="relu")
-        return K.seg_reduce(self.kind, m, src_emb[E:], block)
+        return K.linear_relu_aggregate(self.kind, src_emb, self.linear.weight, self.linear.bias, block)
 
 
 class a_max_op(_LinReluAgg):

@@ -154,8 +154,9 @@ class SearchNetwork(nn.Module):
             src_in_f = torch.cat((src_in.long(), torch.arange(n, device=dev)))
             ent_idx = node_id.view(-1).long()[src_in_f]
             rel_idx = torch.cat((edge_type.long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
+            # layer >= 2 reads cat(ent[src_in], ent): one gather with the index cat(src_in, arange(n)), no torch.cat
             setattr(g, key, (K.GatherPlan(ent_idx, self._num_ent), K.GatherPlan(rel_idx, self._num_rel),
-                             K.GatherPlan(src_in.long(), n)))
+                             K.GatherPlan(src_in_f, n)))
         return getattr(g, key)
 
     def forward(self, g_train, node_id, src_in, edge_type):
@@ -165,7 +166,7 @@ class SearchNetwork(nn.Module):
         ent = None
         for l, cell in enumerate(self.cells):
             wz, wf, wm, wl = self.layer_weights(l)
-            x = K.gather(ent_all, p_ent) if l == 0 else torch.cat((K.gather(ent, p_in), ent), dim=0)
+            x = K.gather(ent_all, p_ent) if l == 0 else K.gather(ent, p_in)
             ent = self.batchnorm_h(cell(g_train, x, K.gather(rel, p_rel), wz, wf, wm, wl))
             if l > 0 or self._layers == 1:
                 ent = F.relu(ent)
