@@ -200,42 +200,56 @@ def seg_reduce(kind, msg, self_rows, graph):
 
 
 class _AggRows(torch.autograd.Function):
-    """Aggregator on the reference's [M, D] layout: rows [0, E) are messages,
-    rows [E, M) the residual self rows; the gradient comes back as one [M, D]."""
+    """a_sum on the reference's [M, D] layout (reference models/operations_lp.py:260-264): rows [0, E) are
+    messages, rows [E, M) the residual self rows; out = Dropout(h) + x[E:].  The dropout keep-mask
+    (already scaled by 1/(1-p), [N, D]) is passed in, so the whole operator is one autograd node whose
+    backward writes the [M, D] gradient once."""
 
     @staticmethod
-    def forward(ctx, mode, x, graph, add_self):
+    def forward(ctx, mode, x, graph, add_self, keep):
         x = f32c(x)
-        require_hip(x)
+        require_hip(x, keep)
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         if x.shape[0] != E + N:
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
         if mode != 2 and hasattr(graph, "agg_plan"):
             sp, meta = graph.agg_plan("mean" if mode == 1 else "sum")
             out, arg = span_gcs("copy", x, None, meta, sp), None      # xi < E: only the edge rows of x are gathered
+            if keep is not None:
+                out *= keep
             if add_self:
                 out += x[E:]
         else:
-            out, arg = _seg_fwd(mode, x, x[E:] if add_self else None, graph.plan(), N, D)
+            out, arg = _seg_fwd(mode, x, x[E:] if (add_self and keep is None) else None, graph.plan(), N, D)
+            if keep is not None:
+                out *= keep
+                if add_self:
+                    out += x[E:]
         ctx.mode, ctx.graph, ctx.add_self = mode, graph, add_self
-        ctx.save_for_backward(*((arg,) if arg is not None else ()))
+        ctx.save_for_backward(*[t for t in (arg, keep) if t is not None])
+        ctx.has = (arg is not None, keep is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = f32c(g)
         graph = ctx.graph
-        arg = ctx.saved_tensors[0] if ctx.mode == 2 else None
+        saved = list(ctx.saved_tensors)
+        arg = saved.pop(0) if ctx.has[0] else None
+        keep = saved.pop(0) if ctx.has[1] else None
         E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
         gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
-        if not ctx.add_self:
+        gh = g * keep if keep is not None else g
+        if ctx.add_self:
+            gx[E:] = g
+        else:
             gx[E:].zero_()
-        _seg_bwd(ctx.mode, g, graph, arg, gx, gx[E:] if ctx.add_self else None)
-        return None, gx, None, None
+        _seg_bwd(ctx.mode, gh, graph, arg, gx, None)
+        return None, gx, None, None, None
 
 
-def aggregate_rows(kind, x, graph, add_self=True):
-    return _AggRows.apply(REDUCE[kind], x, graph, add_self)
+def aggregate_rows(kind, x, graph, add_self=True, keep=None):
+    return _AggRows.apply(REDUCE[kind], x, graph, add_self, keep)
 
 
 class _LinReluAgg(torch.autograd.Function):

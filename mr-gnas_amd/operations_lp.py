@@ -190,10 +190,11 @@ class a_sum_op(nn.Module):
         self.drop_sum = nn.Dropout(self.drop_aggr)
 
     def forward(self, block, src_emb, src_emb_in):
-        if self.training and self.drop_aggr > 0:
-            E = block.num_edges()
-            return self.drop_sum(K.aggregate_rows("sum", src_emb, block, add_self=False)) + src_emb[E:]
-        return K.aggregate_rows("sum", src_emb, block, add_self=True)
+        keep = None
+        if self.training and self.drop_aggr > 0:      # nn.Dropout semantics: keep-mask scaled by 1 / (1 - p), on the [N, D] sums
+            N, D = block.number_of_nodes(), src_emb.shape[1]
+            keep = self.drop_sum(torch.ones(N, D, dtype=torch.float32, device=src_emb.device))
+        return K.aggregate_rows("sum", src_emb, block, add_self=True, keep=keep)
 
 
 # ---- score functions (the step after the path; dense) ---------------------------------------
