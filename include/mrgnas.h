@@ -171,12 +171,21 @@ int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, c
  * rows in flight).  span_slot [n_spans][2] = workspace slot of the first / last run of a span
  * when that run does not cover its whole segment (-1 otherwise); hub_* list the segments made
  * of partial runs (consecutive slots, list order) AND, with hub_count 0, the segments that have
- * no element at all, so that every row of `out` [nseg, D] is written. */
-int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, int64_t E, int span,
+ * no element at all, so that every row of `out` [nseg, D] is written.
+ * ext_scal (NULL ok): when given, meta.w is an element index and the scale is ext_scal[meta.w]
+ * (per-call scales, e.g. upstream gradients, without rebuilding the packed metadata). */
+int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, const float *ext_scal, int64_t E, int span,
                  const int32_t *span_slot, int64_t n_spans,
                  const int32_t *hub_seg, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,
                  int64_t n_slots, const int32_t *seg_len,
                  float *out, void *ws, int64_t nseg, int D, void *stream);
+
+/* ---- DistMult scores (the step after the path) ---------------------------------------
+ * Network.calc_score, reference models/model_search_lp.py:169-176:
+ *   score[t] = sum_c ent[s_t, c] * rel[r_t, c] * ent[o_t, c]
+ * without materialising the three [T, D] gathers; backward = three mrg_span_gcs (mode MUL, ext_scal = dscore). */
+int mrg_distmult_score(const float *ent, const float *rel, const int32_t *s_idx, const int32_t *r_idx,
+                       const int32_t *o_idx, float *score, int64_t T, int D, void *stream);
 
 /* ---- X: MixedOp epilogue  out = sum_k w_k * ReLU(BatchNorm_k(y_k)) -----------------
  * MixedOp.forward / op_forward, reference models/cell_lp.py:25-33, with nn.BatchNorm1d in

@@ -44,7 +44,8 @@ SIGNATURES = {
     "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
-    "mrg_span_gcs": (_I, [_I, _P, _P, _P, _L, _I, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),

@@ -227,9 +227,9 @@ namespace mrg {
 
 template <int VEC, int LPR, int KMAX, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict__ X, const float* __restrict__ Y,
-                                                        const int4* __restrict__ meta, int64_t E, int span,
-                                                        const int32_t* __restrict__ span_slot, int64_t n_spans,
-                                                        float* __restrict__ out, float* __restrict__ ws_val, int D) {
+                                                        const int4* __restrict__ meta, const float* __restrict__ ext_scal,
+                                                        int64_t E, int span, const int32_t* __restrict__ span_slot,
+                                                        int64_t n_spans, float* __restrict__ out, float* __restrict__ ws_val, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int U = 8;
   constexpr bool NY = NeedsY<MODE>::value;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict_
             cur_seg = m[q].x;
             first_run = false;
           }
-          const float s = __int_as_float(m[q].w);
+          const float s = ext_scal ? ext_scal[m[q].w] : __int_as_float(m[q].w);
 #pragma unroll
           for (int k = 0; k < KMAX; ++k) {
             if (sl + k * LPR < dv) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict_
 
 }  // namespace mrg
 
-extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void* meta, int64_t E, int span,
+extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void* meta, const float* ext_scal, int64_t E, int span,
                             const int32_t* span_slot, int64_t n_spans, const int32_t* hub_seg, const int32_t* hub_first,
                             const int32_t* hub_count, int64_t n_hubs, int64_t n_slots, const int32_t* seg_len, float* out,
                             void* ws, int64_t nseg, int D, void* stream) {
@@ -323,7 +323,7 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
   if (!g.ok) return MRG_E_SHAPE;
   const int4* m4 = (const int4*)meta;
 #define LAUNCH(V, L, K, M)                                                                                              \
-  hipLaunchKernelGGL((span_gcs_k<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, E, span, span_slot, n_spans, out, ws_val, D)
+  hipLaunchKernelGGL((span_gcs_k<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, n_spans, out, ws_val, D)
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
     int grid = grid_for(n_spans, MRG_BLOCK / L);                                                                       \
@@ -342,6 +342,57 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
 #undef LAUNCH
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+
+// ======================================================================================
+// DistMult scores  score[t] = sum_c ent[s_t, c] * rel[r_t, c] * ent[o_t, c]
+//   Network.calc_score, reference models/model_search_lp.py:169-176 (three [T, D] gathers, two
+//   products and a row sum in the reference).  One lane group per triple; nothing of size [T, D]
+//   is written.  Its backward is three mrg_span_gcs launches (mode MUL, ext_scal = dscore).
+// ======================================================================================
+namespace mrg {
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void distmult_k(const float* __restrict__ ent, const float* __restrict__ rel,
+                                                        const int32_t* __restrict__ si, const int32_t* __restrict__ ri,
+                                                        const int32_t* __restrict__ oi, float* __restrict__ score, int64_t T, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  for (int64_t t = (int64_t)blockIdx.x * RPB + rw; t < T; t += (int64_t)gridDim.x * RPB) {
+    const float* a = ent + (int64_t)si[t] * D;
+    const float* b = rel + (int64_t)ri[t] * D;
+    const float* c = ent + (int64_t)oi[t] * D;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int col = sl + k * LPR;
+      if (col < dv) {
+        Vec<VEC> x = Vec<VEC>::load(a + col * VEC), y = Vec<VEC>::load(b + col * VEC), z = Vec<VEC>::load(c + col * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc += x[j] * y[j] * z[j];
+      }
+    }
+    acc = group_sum<LPR>(acc);
+    if (sl == 0) score[t] = acc;
+  }
+}
+}  // namespace mrg
+
+extern "C" int mrg_distmult_score(const float* ent, const float* rel, const int32_t* s_idx, const int32_t* r_idx,
+                                  const int32_t* o_idx, float* score, int64_t T, int D, void* stream) {
+  if (T < 0 || D <= 0) return MRG_E_SHAPE;
+  if (T == 0) return MRG_OK;
+  if (!ent || !rel || !s_idx || !r_idx || !o_idx || !score) return MRG_E_NULLPTR;
+  RowGeom g = row_geom(D, aligned16(ent) && aligned16(rel));
+  if (!g.ok) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V, L, K) \
+  hipLaunchKernelGGL((distmult_k<V, L, K>), dim3(grid_for(T, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), 0, st, ent, rel, s_idx, r_idx, o_idx, score, T, D)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

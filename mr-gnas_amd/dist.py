@@ -289,15 +289,15 @@ class ShardedSupernet:
     def loss(self, ent, rel, samples_local, labels_local, total_samples):
         """This rank's share of the mean BCE (reference models/model_search_lp.py:181-188):
         the ranks' values add up to the reference loss."""
-        key = (samples_local.data_ptr(), tuple(samples_local.shape), samples_local._version)
-        if getattr(self, "_score_key", None) != key:
+        if ent.is_cuda:
+            key = (samples_local.data_ptr(), tuple(samples_local.shape), samples_local._version)
+            if getattr(self, "_score_key", None) != key:
+                self._score_plan = K.ScorePlan(samples_local, ent.shape[0], rel.shape[0])
+                self._score_key = key
+            score = K.distmult_score(ent, rel, self._score_plan)
+        else:
             t = samples_local.long()
-            self._score_plans = (self.k.GatherPlan(t[:, 0].contiguous(), ent.shape[0]),
-                                 self.k.GatherPlan(t[:, 1].contiguous(), rel.shape[0]),
-                                 self.k.GatherPlan(t[:, 2].contiguous(), ent.shape[0]))
-            self._score_key = key
-        ps, pr, po = self._score_plans
-        score = torch.sum(self.k.gather(ent, ps) * self.k.gather(rel, pr) * self.k.gather(ent, po), dim=1)
+            score = torch.sum(ent[t[:, 0]] * rel[t[:, 1]] * ent[t[:, 2]], dim=1)
         return F.binary_cross_entropy_with_logits(score, labels_local, reduction="sum") / total_samples
 
 

@@ -416,16 +416,16 @@ def fused_gcs(mode, X, xi, Y, yi, scal, plan, nseg):
     return out
 
 
-def span_gcs(mode, X, Y, meta, plan):
+def span_gcs(mode, X, Y, meta, plan, ext_scal=None):
     """mrg_span_gcs: balanced span form of fused_gcs for the elementwise modes."""
-    X, Y = f32c(X), f32c(Y)
-    require_hip(X, Y, meta)
+    X, Y, ext_scal = f32c(X), f32c(Y), f32c(ext_scal)
+    require_hip(X, Y, meta, ext_scal)
     D, nseg, E = X.shape[1], plan["nseg"], plan["E"]
     out = torch.empty(nseg, D, dtype=torch.float32, device=X.device)     # every row is written: runs, hubs, empty segments
     ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
     rows_y = Y.shape[0] if Y is not None else 0
     nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)          # SURVEY section 8d
-    call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), E, plan["span"], ptr(plan["span_slot"]), plan["n_spans"],
+    call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), ptr(ext_scal), E, plan["span"], ptr(plan["span_slot"]), plan["n_spans"],
                           ptr(plan["hub_seg"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), plan["n_hubs"], plan["n_slots"],
                           ptr(plan["seg_len"]), ptr(out), ptr(ws), nseg, D, stream_of(X)), nbytes=nb)
     return out
@@ -698,3 +698,57 @@ def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_s
 def dense_filter_single(s, s_in, W, b):
     """f_dense_last (s_in None) / f_dense: sigmoid(W [s ; s_in] + b) * s on all rows."""
     return _DenseFilter.apply(0, s, s_in, None, 0, 0, 1.0, 1.0, None, None, None, None, W, b)
+
+
+
+# ---------------------------------------------------------------------------
+# DistMult scoring (the step after the path)
+# ---------------------------------------------------------------------------
+class ScorePlan:
+    """Index structures of a scoring batch of (s, r, o) triples: int32 indices for the forward and
+    three span plans (by subject, by object, by relation) whose metadata carries the element id in
+    the scale slot, so the backward can take the upstream gradient as an external scale."""
+
+    def __init__(self, triplets, n_ent, n_rel):
+        from .graph import span_plan
+        t = triplets.long()
+        s, r, o = t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous()
+        self.T, self.n_ent, self.n_rel = int(t.shape[0]), int(n_ent), int(n_rel)
+        self.s32, self.r32, self.o32 = (x.to(torch.int32).contiguous() for x in (s, r, o))
+
+        def packed(plan, xi, yi):
+            perm = plan["perm"]
+            return torch.stack((plan["seg_sorted"].long(), xi[perm], yi[perm], perm), dim=1).to(torch.int32).contiguous()
+        self.by_s, self.by_o, self.by_r = span_plan(s, n_ent), span_plan(o, n_ent), span_plan(r, n_rel)
+        self.m_s = packed(self.by_s, o, r)        # g_ent[s] += g_t * ent[o] * rel[r]
+        self.m_o = packed(self.by_o, s, r)        # g_ent[o] += g_t * ent[s] * rel[r]
+        self.m_r = packed(self.by_r, s, o)        # g_rel[r] += g_t * ent[s] * ent[o]     (Y = ent as well)
+
+
+class _DistMult(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ent, rel, sp):
+        ent, rel = f32c(ent), f32c(rel)
+        require_hip(ent, rel)
+        D = ent.shape[1]
+        score = torch.empty(sp.T, dtype=torch.float32, device=ent.device)
+        call("mrg_distmult_score", (ptr(ent), ptr(rel), ptr(sp.s32), ptr(sp.r32), ptr(sp.o32), ptr(score), sp.T, D, stream_of(ent)),
+             nbytes=sp.T * (12 * D + 16))
+        ctx.sp = sp
+        ctx.save_for_backward(ent, rel)
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        ent, rel = ctx.saved_tensors
+        sp = ctx.sp
+        g = f32c(g)
+        g_ent = span_gcs("mul", ent, rel, sp.m_s, sp.by_s, ext_scal=g)
+        g_ent += span_gcs("mul", ent, rel, sp.m_o, sp.by_o, ext_scal=g)
+        g_rel = span_gcs("mul", ent, ent, sp.m_r, sp.by_r, ext_scal=g)
+        return g_ent, g_rel, None
+
+
+def distmult_score(ent, rel, sp):
+    """sum_c ent[s] * rel[r] * ent[o] per triple (reference models/model_search_lp.py:169-176)."""
+    return _DistMult.apply(ent, rel, sp)

@@ -174,21 +174,20 @@ class SearchNetwork(nn.Module):
             rel = torch.matmul(rel, self.w_rel)
         return ent, rel
 
-    def _score_plans(self, ent, rel, triplets):
-        """Gather plans of a scoring batch, cached per triplet tensor (bench/search reuse it)."""
-        key = (triplets.data_ptr(), tuple(triplets.shape), ent.shape[0], rel.shape[0])
+    def _score_plan(self, ent, rel, triplets):
+        """Index plan of a scoring batch, cached per triplet tensor (bench / search drivers reuse the batch)."""
+        key = (triplets.data_ptr(), tuple(triplets.shape), triplets._version, ent.shape[0], rel.shape[0])
         if self._gather_cache.get("key") != key:
-            t = triplets.long()
-            self._gather_cache = {"key": key, "plans": (K.GatherPlan(t[:, 0].contiguous(), ent.shape[0]),
-                                                        K.GatherPlan(t[:, 1].contiguous(), rel.shape[0]),
-                                                        K.GatherPlan(t[:, 2].contiguous(), ent.shape[0]))}
-        return self._gather_cache["plans"]
+            self._gather_cache = {"key": key, "plan": K.ScorePlan(triplets, ent.shape[0], rel.shape[0])}
+        return self._gather_cache["plan"]
 
     def calc_score(self, ent, rel, triplets):
-        """DistMult (reference models/model_search_lp.py:169-176); the three row gathers use the
-        HIP gather whose backward is a segmented sum instead of a sort-based index_put."""
-        ps, pr, po = self._score_plans(ent, rel, triplets)
-        return torch.sum(K.gather(ent, ps) * K.gather(rel, pr) * K.gather(ent, po), dim=1)
+        """DistMult (reference models/model_search_lp.py:169-176) in one fused HIP kernel: no [T, D]
+        gathers are materialised; the backward is three balanced segmented-sum launches."""
+        if not ent.is_cuda:
+            t = triplets.long()
+            return torch.sum(ent[t[:, 0]] * rel[t[:, 1]] * ent[t[:, 2]], dim=1)
+        return K.distmult_score(ent, rel, self._score_plan(ent, rel, triplets))
 
     def get_loss(self, g_train, ent, rel, triplets, labels):
         return F.binary_cross_entropy_with_logits(self.calc_score(ent, rel, triplets), labels)

@@ -212,3 +212,30 @@ def test_mixed_epilogue_matches_bn_relu_sum(rows, D, present):
             ref_bn.train(); ref_bn(ys[k].double())
             close(bns[k].running_mean, ref_bn.running_mean.float(), f"running_mean {k}", rtol=1e-5, atol=1e-6)
             close(bns[k].running_var, ref_bn.running_var.float(), f"running_var {k}", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,R,T,D", [(50, 7, 400, 32), (300, 11, 5000, 200), (40, 3, 0, 16), (64, 5, 777, 10)])
+def test_distmult_score_and_gradients(N, R, T, D):
+    """Fused DistMult (reference models/model_search_lp.py:169-176) against the float64 definition;
+    empty batch, ragged D, entities / relations that never occur (zero gradient rows)."""
+    gen = torch.Generator().manual_seed(N + T)
+    ent = torch.randn(N, D, generator=gen)
+    rel = torch.randn(R, D, generator=gen)
+    trip = torch.stack((torch.randint(0, N - 3, (T,), generator=gen), torch.randint(0, R - 1, (T,), generator=gen),
+                        torch.randint(0, N - 3, (T,), generator=gen)), dim=1)
+    w = torch.randn(T, generator=gen)
+    e64, r64 = ent.double().requires_grad_(), rel.double().requires_grad_()
+    ref = torch.sum(e64[trip[:, 0]] * r64[trip[:, 1]] * e64[trip[:, 2]], dim=1)
+    (ref * w.double()).sum().backward()
+    ed, rd = ent.cuda().requires_grad_(), rel.cuda().requires_grad_()
+    sp = K.ScorePlan(trip.cuda(), N, R)
+    got = K.distmult_score(ed, rd, sp)
+    (got * w.cuda()).sum().backward()
+    assert got.shape == (T,)
+    scale = max(1.0, float(ref.abs().max()) if T else 1.0)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().float().numpy(), atol=1e-4 * scale, rtol=1e-4)
+    for a, b in ((ed.grad, e64.grad), (rd.grad, r64.grad)):
+        s = max(1.0, float(b.abs().max()))
+        np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), atol=1e-4 * s, rtol=1e-4)
+    assert torch.all(ed.grad[N - 3:] == 0) and torch.all(rd.grad[R - 1:] == 0)
