@@ -180,6 +180,13 @@ int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, con
                  int64_t n_slots, const int32_t *seg_len,
                  float *out, void *ws, int64_t nseg, int D, void *stream);
 
+/* ---- gradient fan-in -------------------------------------------------------------------
+ * A state read by several candidate operators (MixedOp, reference models/cell_lp.py:25-33; h_in read by
+ * every MixedOp of a cell, models/cell_lp.py:150-186) receives one gradient per reader:
+ *   out[i] = (accumulate ? out[i] : 0) + sum_k xs_host[k][i],  i < n,  1 <= K <= 8
+ * xs_host: HOST array of K device pointers.  Order of summation k = 0..K-1. */
+int mrg_sum_buffers(const float *const *xs_host, int K, float *out, int64_t n, int accumulate, void *stream);
+
 /* ---- DistMult scores (the step after the path) ---------------------------------------
  * Network.calc_score, reference models/model_search_lp.py:169-176:
  *   score[t] = sum_c ent[s_t, c] * rel[r_t, c] * ent[o_t, c]

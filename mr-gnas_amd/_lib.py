@@ -45,6 +45,7 @@ SIGNATURES = {
     "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_sum_buffers": (_I, [_P, _I, _P, _L, _I, _P]),
     "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),

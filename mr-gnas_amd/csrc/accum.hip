@@ -1,0 +1,75 @@
+// K-way sum of equally-shaped buffers: the gradient fan-in of a tensor read by several candidate
+// operators (MixedOp hands one state to up to eleven operators, reference models/cell_lp.py:25-33;
+// a cell hands h_in to every MixedOp, models/cell_lp.py:150-186).  Autograd's pairwise adds move
+// 3 S bytes per extra consumer; one K-way pass moves (K + 1) S in total.  HBM-bound.
+#include "common.hpp"
+
+#define MRG_SUM_MAXK 8
+
+namespace mrg {
+
+struct SumPack { const float* p[MRG_SUM_MAXK]; };
+
+template <int K, bool ACC>
+__global__ __launch_bounds__(MRG_BLOCK) void sum_k(SumPack xs, float* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * MRG_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * MRG_BLOCK) {
+    float4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = reinterpret_cast<const float4*>(xs.p[k])[i];
+    float4 a = ACC ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+
+template <bool ACC>
+__global__ void sum_tail_k(SumPack xs, int K, float* __restrict__ out, int64_t first, int64_t n) {
+  int64_t i = first + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = ACC ? out[i] : 0.f;
+  for (int k = 0; k < K; ++k) a += xs.p[k][i];
+  out[i] = a;
+}
+
+template <bool ACC>
+static void launch_sum(const SumPack& xs, int K, float* out, int64_t n, bool vec, hipStream_t st) {
+  int64_t n4 = vec ? n / 4 : 0;
+  if (n4 > 0) {
+    int grid = grid_for(n4, MRG_BLOCK * 2);
+    switch (K) {
+#define CASE(KK) case KK: hipLaunchKernelGGL((sum_k<KK, ACC>), dim3(grid), dim3(MRG_BLOCK), 0, st, xs, out, n4); break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+  }
+  int64_t first = n4 * 4;
+  if (first < n) {
+    int64_t rem = n - first;
+    hipLaunchKernelGGL((sum_tail_k<ACC>), dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, xs, K, out, first, n);
+  }
+}
+
+}  // namespace mrg
+
+using namespace mrg;
+
+// out[i] = (accumulate ? out[i] : 0) + sum_k xs_host[k][i],  i < n;  1 <= K <= 8 device buffers whose
+// pointers are given in a HOST array.  Summation order is k = 0..K-1 (deterministic).
+extern "C" int mrg_sum_buffers(const float* const* xs_host, int K, float* out, int64_t n, int accumulate, void* stream) {
+  if (K < 1 || K > MRG_SUM_MAXK || n < 0) return MRG_E_SHAPE;
+  if (n == 0) return MRG_OK;
+  if (!xs_host || !out) return MRG_E_NULLPTR;
+  SumPack xs{};
+  bool vec = aligned16(out);
+  for (int k = 0; k < K; ++k) {
+    if (!xs_host[k]) return MRG_E_NULLPTR;
+    xs.p[k] = xs_host[k];
+    vec = vec && aligned16(xs_host[k]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (accumulate) launch_sum<true>(xs, K, out, n, vec, st);
+  else launch_sum<false>(xs, K, out, n, vec, st);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}

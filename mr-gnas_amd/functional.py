@@ -9,7 +9,7 @@ price the kernels against the roofline.
 import torch
 
 from . import _lib
-from ._lib import call, f32c, ptr, require_hip, stream_of
+from ._lib import ptr_array, call, f32c, ptr, require_hip, stream_of
 
 COMPOSE = {"mult": 0, "sub": 1, "add": 2}
 REDUCE = {"sum": 0, "mean": 1, "max": 2}
@@ -752,3 +752,61 @@ class _DistMult(torch.autograd.Function):
 def distmult_score(ent, rel, sp):
     """sum_c ent[s] * rel[r] * ent[o] per triple (reference models/model_search_lp.py:169-176)."""
     return _DistMult.apply(ent, rel, sp)
+
+
+
+# ---------------------------------------------------------------------------
+# gradient fan-in of a tensor with several readers
+# ---------------------------------------------------------------------------
+def sum_buffers(xs):
+    """Sum of equally-shaped HIP tensors in K-way passes (mrg_sum_buffers), k = 0..K-1 order."""
+    xs = [f32c(x) for x in xs]
+    require_hip(*xs)
+    out = torch.empty_like(xs[0])
+    n = out.numel()
+    for i in range(0, len(xs), 8):
+        part = xs[i:i + 8]
+        call("mrg_sum_buffers", (ptr_array(part), len(part), ptr(out), n, int(i > 0), stream_of(out)),
+             nbytes=4 * n * (len(part) + 1 + int(i > 0)))
+    return out
+
+
+class _Fanout(torch.autograd.Function):
+    """k aliases of one tensor whose gradients are summed in one K-way pass instead of k - 1
+    pairwise adds.  Aliases nobody reads cost nothing (their gradient stays None)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if not gs[0].is_cuda or any(g.shape != gs[0].shape for g in gs):
+            tot = gs[0]
+            for g in gs[1:]:
+                tot = tot + g
+            return tot, None
+        return sum_buffers(gs), None
+
+
+class Fan:
+    """Hands out aliases of `x` to its readers: ``fan.take()`` per reader, at most `cap` of them.
+    Without autograd (or for tensors that need no gradient) the tensor itself is returned."""
+
+    def __init__(self, x, cap):
+        self.x = x
+        self._live = torch.is_grad_enabled() and x.requires_grad and cap > 1
+        self._views = list(_Fanout.apply(x, cap)) if self._live else None
+
+    def take(self):
+        if not self._live:
+            return self.x
+        if not self._views:
+            raise RuntimeError("Fan: more readers than announced")
+        return self._views.pop()

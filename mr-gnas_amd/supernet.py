@@ -58,12 +58,17 @@ class MixedOp(nn.Module):
         """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
         BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
         materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
-        if not h.is_cuda:                     # reference formulation (registry of non-HIP test operators)
+        if not (h.x if isinstance(h, K.Fan) else h).is_cuda:    # reference formulation (registry of non-HIP test operators)
             total = 0
             for w, (op, bn, act) in zip(weights, self._ops):
                 total = total + w * act(bn(op(g, h, h_in).float()))
             return total
-        ys = [None if isinstance(op, OPS.f_zero_op) else op(g, h, h_in) for op, _, _ in self._ops]
+        # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
+        # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
+        n = len(self._ops)
+        fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
+        fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
+        ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
         return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
 
 
@@ -89,20 +94,28 @@ class SuperCell(nn.Module):
         self.cell_last = mk(sum(n_first + i for i in range(n_last)), OPS.LAST_OPS)
         self.concat_weights = nn.Linear((n_first + n_last) * feature_dim, feature_dim)
 
-    @staticmethod
-    def _dense_stage(stage, states, weights, g, h_in, steps):
+    def _fan(self, x):
+        """Reader bookkeeping for one state: every candidate of every MixedOp of the cell may read it."""
+        if not x.is_cuda:
+            return x
+        n_mixed = 1 + len(self.cell_first._ops) + len(self.cell_middle._ops) + len(self.cell_last._ops)
+        width = max(len(m._ops) for st in (self.cell_first, self.cell_middle, self.cell_last) for m in st._ops)
+        return K.Fan(x, 2 * n_mixed * width + 2)
+
+    def _dense_stage(self, stage, states, weights, g, h_in, steps):
         off = 0
         for _ in range(steps):
             s = sum(stage._ops[off + j](weights[off + j], g, h, h_in) for j, h in enumerate(states))
             off += len(states)
-            states.append(s)
+            states.append(self._fan(s))
         return states
 
     def forward(self, g, src_emb, hr, w_zero, w_first, w_middle, w_last):
-        h_in = self.cell_zero._ops[0](w_zero[0], g, src_emb, hr)
+        h_in = self._fan(self.cell_zero._ops[0](w_zero[0], g, src_emb, hr))
         states = self._dense_stage(self.cell_first, [h_in], w_first, g, h_in, self.n_first)[1:]
-        states = [self.cell_middle._ops[i](w_middle[i], g, states[i], h_in) for i in range(self.n_first)]
+        states = [self._fan(self.cell_middle._ops[i](w_middle[i], g, states[i], h_in)) for i in range(self.n_first)]
         states = self._dense_stage(self.cell_last, states, w_last, g, h_in, self.n_last)
+        states = [s.take() if isinstance(s, K.Fan) else s for s in states]
         return self.concat_weights(torch.cat(states, dim=1))
 
 
