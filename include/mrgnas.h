@@ -228,12 +228,26 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
 /* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
  * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)
  * and the post-aggregation linears of CompGraphConv (reference models/compgcn.py:77-78,100,103).
- * Y[rows, Nout] = act(X[rows, K] W[Nout, K]^T + bias) */
-int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y,
+ * Y[rows, Nout] = act(X[rows, K] W[Nout, K]^T + bias)
+ *
+ * Two matrix cores serve every tall-skinny product of the library (this one, mrg_linear_bwd_input,
+ * mrg_dense_filter_fwd):
+ *   - split core: each f32 operand is written as the sum of three bf16 numbers (error <= 2^-26 relative) and the
+ *     product is accumulated in f32 from the six leading cross terms on the bf16 matrix pipe -- same error class
+ *     as an f32 FMA chain (tests pin it against float64 next to the exact core), 2-3x the throughput.  Needs a
+ *     workspace of mrg_gemm_workspace_bytes(K, Nout) bytes for the pre-split weight, K % 4 == 0, K > 48 and
+ *     16-byte aligned rows;
+ *   - exact core: v_mfma_f32_32x32x2_f32; taken when ws == NULL, the operands do not qualify, or after
+ *     mrg_gemm_set_mode(1).
+ * ws: NULL, or mrg_gemm_workspace_bytes(K, Nout) bytes of device memory private to this call. */
+int64_t mrg_gemm_workspace_bytes(int K, int Nout);
+/* 0 (default): split core where possible; 1: exact-f32 core only (process-wide). */
+int mrg_gemm_set_mode(int mode);
+int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);
 /* gX[rows, K] (+)= gY[rows, Nout] W[:, 0:K]   (gY already masked by the activation).  W is
  * [Nout][ldw] row-major, ldw >= K (a column block of a wider weight, e.g. one half of an
- * nn.Linear(2D, D)); accumulate != 0 adds into gX.  ws holds the transposed block. */
+ * nn.Linear(2D, D)); accumulate != 0 adds into gX.  ws (mandatory) holds the split / transposed block. */
 int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout);
 int mrg_linear_bwd_input(const float *gY, const float *W, float *gX, void *ws,
                          int64_t rows, int K, int Nout, int ldw, int accumulate, void *stream);
@@ -251,9 +265,9 @@ int mrg_linear_bwd_weight(const float *gY, const float *X1, const float *X2, flo
  *   kind 1:  out = z * c
  *   c = scale * (rowscale ? rowscale[row] : 1)     (the reference's 1/3 and edge norm)
  * torch.cat([s, s_in], 1) is never materialised: the GEMM reads both sources; gate, scale and
- * norm are applied in its epilogue. */
+ * norm are applied in its epilogue.  ws: NULL or mrg_gemm_workspace_bytes(K, D) bytes, K = D or 2D (see mrg_linear_fwd). */
 int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const float *W, const float *bias,
-                         const float *rowscale, float scale, float *out, float *gate,
+                         const float *rowscale, float scale, float *out, float *gate, void *ws,
                          int64_t rows, int D, void *stream);
 /* backward, step 1:  kind 0: dz = g*s*c*gate*(1-gate), gs = g*c*gate (direct term);  kind 1: dz = g*c.
  * Steps 2-3 are mrg_linear_bwd_input (gs += dz W[:, :D]; gs_in = dz W[:, D:]) and

@@ -6,7 +6,7 @@
 //   f_dense_op       reference models/operations_lp.py:345-354   out = sigmoid(W [s ; s_in] + b) * s
 // One call handles one direction segment (rows with one weight matrix); the caller loops over
 // in / out / self.  MFMA-bound: 2*rows*K*D flop, K = 2D (or D for f_dense_last).
-#include "gemm.hpp"
+#include "gemm_x3.hpp"
 
 namespace mrg {
 
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void dense_dz_k(const float* __restrict_
 using namespace mrg;
 
 extern "C" int mrg_dense_filter_fwd(int kind, const float* s, const float* s_in, const float* W, const float* bias,
-                                    const float* rowscale, float scale, float* out, float* gate, int64_t rows, int D,
+                                    const float* rowscale, float scale, float* out, float* gate, void* ws, int64_t rows, int D,
                                     void* stream) {
   if (kind != 0 && kind != 1) return MRG_E_ENUM;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
@@ -60,14 +60,14 @@ extern "C" int mrg_dense_filter_fwd(int kind, const float* s, const float* s_in,
   GemmArgs a{};
   a.A1 = s; a.K1 = D;
   a.A2 = s_in; a.K2 = s_in ? D : 0;
-  a.B = W; a.ldb = a.K1 + a.K2;
+  a.B = W;
   a.bias = bias; a.C = out; a.ldc = D; a.N = D; a.rows = rows;
   a.rowscale = rowscale; a.scale = scale;
   if (kind == 0) {
     a.S = s; a.ld_s = D; a.aux = gate;
-    return launch_rowgemm<EPI_GATE>(a, (hipStream_t)stream);
+    return launch_gemm<EPI_GATE>(a, a.K1 + a.K2, 1, ws, (hipStream_t)stream);
   }
-  return launch_rowgemm<EPI_SCALE>(a, (hipStream_t)stream);
+  return launch_gemm<EPI_SCALE>(a, a.K1 + a.K2, 1, ws, (hipStream_t)stream);
 }
 
 // dz (and, for the gated kinds, the direct term of the gradient w.r.t. s):

@@ -4,7 +4,7 @@
 // forward / input-gradient use the pipelined row GEMM; the weight gradient is a split-over-rows
 // GEMM (each workgroup reduces a chunk of rows into register-resident output tiles, partial
 // tiles are combined in a fixed order), also software-pipelined, and optionally dual-source.
-#include "gemm.hpp"
+#include "gemm_x3.hpp"
 
 namespace mrg {
 
@@ -384,24 +384,36 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
 
 using namespace mrg;
 
-extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias, float* Y, int64_t rows, int K, int Nout,
+extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
+  if (K <= 0 || Nout <= 0) return 0;
+  return (int64_t)gemm_workspace_bytes(K, Nout);
+}
+
+extern "C" int mrg_gemm_set_mode(int mode) {
+  if (mode != 0 && mode != 1) return MRG_E_ENUM;
+  gemm_mode() = mode;
+  return MRG_OK;
+}
+
+extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias, float* Y, void* ws, int64_t rows, int K, int Nout,
                               int act, void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
   if (act != MRG_ACT_NONE && act != MRG_ACT_RELU) return MRG_E_ENUM;
   if (rows == 0) return MRG_OK;
   if (!X || !W || !Y) return MRG_E_NULLPTR;
   GemmArgs a{};
-  a.A1 = X; a.K1 = K; a.B = W; a.ldb = K; a.bias = bias; a.C = Y; a.ldc = Nout; a.N = Nout; a.rows = rows; a.act = act;
-  return launch_rowgemm<EPI_BIAS_ACT>(a, (hipStream_t)stream);
+  a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.C = Y; a.ldc = Nout; a.N = Nout; a.rows = rows; a.act = act;
+  return launch_gemm<EPI_BIAS_ACT>(a, K, 1, ws, (hipStream_t)stream);
 }
 
 extern "C" int64_t mrg_linear_bwd_input_workspace_bytes(int K, int Nout) {
   if (K <= 0 || Nout <= 0) return 0;
-  return (int64_t)K * Nout * sizeof(float);
+  return (int64_t)gemm_workspace_bytes(Nout, K);
 }
 
 // gX[rows, K] (+)= gY[rows, Nout] * W[:, 0:K]   where W is [Nout][ldw] row-major (ldw >= K: a column block
 // of a wider weight, e.g. one half of an nn.Linear(2D, D)); accumulate != 0 adds into the existing gX.
+// The core sees B(n = k_in, k = n_out) = W[n_out * ldw + k_in]: a strided view, no transpose pass on the split path.
 extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, void* ws, int64_t rows, int K, int Nout,
                                     int ldw, int accumulate, void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0 || ldw < K) return MRG_E_SHAPE;
@@ -409,15 +421,13 @@ extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, 
   if (!gY || !W || !gX) return MRG_E_NULLPTR;
   if (!ws) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  // present (W[:, 0:K])^T = [K][Nout] row-major to the core
-  launch_transpose(W, (float*)ws, Nout, K, ldw, st);
   GemmArgs a{};
-  a.A1 = gY; a.K1 = Nout; a.B = (const float*)ws; a.ldb = Nout; a.C = gX; a.ldc = K; a.N = K; a.rows = rows; a.act = MRG_ACT_NONE;
+  a.A1 = gY; a.K1 = Nout; a.B = W; a.C = gX; a.ldc = K; a.N = K; a.rows = rows; a.act = MRG_ACT_NONE;
   if (accumulate) {
     a.Cin = gX; a.ld_cin = K;
-    return launch_rowgemm<EPI_ACCUM>(a, st);
+    return launch_gemm<EPI_ACCUM>(a, 1, ldw, ws, st);
   }
-  return launch_rowgemm<EPI_BIAS_ACT>(a, st);
+  return launch_gemm<EPI_BIAS_ACT>(a, 1, ldw, ws, st);
 }
 
 extern "C" int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout) {

@@ -269,7 +269,8 @@ class _LinReluAgg(torch.autograd.Function):
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
         st = stream_of(x)
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
-        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), E, D, D, 1, st),
+        gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
+        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
              nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
         if mode == 2:
             out, arg = _seg_fwd(2, y, x[E:], graph.plan(), N, D)
@@ -319,7 +320,8 @@ class _Linear(torch.autograd.Function):
         if W.shape[1] != K:
             raise _lib.MrgnasError(f"linear: weight {tuple(W.shape)} does not match input width {K}")
         y = torch.empty(rows, Nout, dtype=torch.float32, device=x.device)
-        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), rows, K, Nout, act, stream_of(x)),
+        gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", K, Nout), x)
+        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), rows, K, Nout, act, stream_of(x)),
              nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
         ctx.act, ctx.has_b = act, b is not None
         ctx.save_for_backward(x, W, y if act == 1 else None)
@@ -639,9 +641,10 @@ class _DenseFilter(torch.autograd.Function):
             if hi <= lo:
                 continue
             rs = norm[lo:hi] if (edge and norm is not None) else None
+            gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s)
             call("mrg_dense_filter_fwd", (kind, ptr(s[lo:hi]), ptr(s_in[lo:hi]) if s_in is not None else None, ptr(W), ptr(b),
                                           ptr(rs), scale, ptr(out[lo:hi]), ptr(gate[lo:hi]) if gate is not None else None,
-                                          hi - lo, D, st),
+                                          ptr(gws), hi - lo, D, st),
                  nbytes=4 * (hi - lo) * (K_ + D * (2 if kind == 0 else 1)), flops=2 * (hi - lo) * K_ * D)
         ctx.cfg = (kind, b0, b1, scale_edge, scale_self)
         ctx.save_for_backward(s, s_in, norm, gate, *params)

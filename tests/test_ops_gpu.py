@@ -239,3 +239,43 @@ def test_distmult_score_and_gradients(N, R, T, D):
         s = max(1.0, float(b.abs().max()))
         np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), atol=1e-4 * s, rtol=1e-4)
     assert torch.all(ed.grad[N - 3:] == 0) and torch.all(rd.grad[R - 1:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K1,K2,Nout", [(70000, 200, 200, 200), (70001, 200, 0, 200), (3000, 100, 100, 100), (513, 64, 0, 40),
+                                             (66000, 52, 0, 300), (259, 400, 0, 7)])
+def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
+    """The split-bf16 matrix core (six bf16 cross terms, f32 accumulate) against the exact-f32 MFMA core, both
+    measured against a float64 product: its error may not exceed 1.5x the exact core's (+ 1e-6 of the output
+    scale).  Covers dual-source K, K % 16 != 0, ragged row blocks, >1 column block, both row-tile shapes."""
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + Nout)
+    s = (torch.randn(rows, K1, generator=gen) * 3).to(DEV)
+    s_in = torch.randn(rows, K2, generator=gen).to(DEV) if K2 else None
+    W = (torch.randn(Nout, K1 + K2, generator=gen) / (K1 + K2) ** 0.5).to(DEV)
+    b = torch.randn(Nout, generator=gen).to(DEV)
+    x = s if s_in is None else torch.cat((s, s_in), 1)
+    ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+    ref_gx = gy.double() @ W.double()
+    errs = {}
+    try:
+        for mode in (0, 1):
+            assert lib.mrg_gemm_set_mode(mode) == 0
+            if K2 == 0:
+                out = K.linear(x, W, b, None)
+                xg = x.clone().requires_grad_(True)
+                K.linear(xg, W, b, None).backward(gy)
+                errs[mode] = (float((out.double() - ref).abs().max()), float((xg.grad.double() - ref_gx).abs().max()))
+            else:
+                out = torch.empty(rows, Nout, device=DEV)
+                ws = torch.empty(int(lib.mrg_gemm_workspace_bytes(K1 + K2, Nout)), dtype=torch.uint8, device=DEV)
+                from mr_gnas_amd._lib import call, ptr, stream_of
+                call("mrg_dense_filter_fwd", (1, ptr(s), ptr(s_in), ptr(W), ptr(b), None, 1.0, ptr(out), None, ptr(ws), rows, K1,
+                                              stream_of(out)))
+                errs[mode] = (float((out.double() - ref).abs().max()), 0.0)
+    finally:
+        lib.mrg_gemm_set_mode(0)
+    for i, scale in ((0, float(ref.abs().max())), (1, float(ref_gx.abs().max()))):
+        assert errs[0][i] <= 1.5 * errs[1][i] + 1e-6 * scale, (errs, scale)
+        assert errs[0][i] <= 2e-5 * scale

@@ -1,0 +1,58 @@
+// Lab bench for the 3-way bf16 split GEMM core against the exact-f32 MFMA core: time + error vs float64.
+// build: hipcc --offload-arch=gfx950 -O3 -I mr-gnas_amd/csrc tools/gemm_x3_lab.hip -o /tmp/gemm_x3_lab
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "gemm_x3.hpp"
+using namespace mrg;
+
+static float frand() { return (float)rand() / RAND_MAX - 0.5f; }
+
+int main(int argc, char** argv) {
+  int64_t rows = argc > 1 ? atoll(argv[1]) : 558771;
+  int K1 = argc > 2 ? atoi(argv[2]) : 200, K2 = argc > 3 ? atoi(argv[3]) : 200, N = argc > 4 ? atoi(argv[4]) : 200;
+  int K = K1 + K2;
+  float *A1, *A2, *B, *C, *C2; void* Bp;
+  hipMalloc(&A1, rows * K1 * 4); hipMalloc(&A2, rows * (K2 ? K2 : 4) * 4); hipMalloc(&B, (size_t)N * K * 4);
+  hipMalloc(&C, rows * N * 4); hipMalloc(&C2, rows * N * 4);
+  std::vector<float> h1(rows * K1), h2(rows * (size_t)K2), hb((size_t)N * K), bias(N);
+  for (auto& v : h1) v = frand() * 4; for (auto& v : h2) v = frand(); for (auto& v : hb) v = frand() * 0.2f; for (auto& v : bias) v = frand();
+  hipMemcpy(A1, h1.data(), h1.size() * 4, hipMemcpyHostToDevice);
+  if (K2) hipMemcpy(A2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  float* dbias; hipMalloc(&dbias, N * 4); hipMemcpy(dbias, bias.data(), N * 4, hipMemcpyHostToDevice);
+  const int nt = gemm_pick_nt(N);
+  hipMalloc(&Bp, x3_bsplit_bytes(N, K, nt));
+  GemmArgs a{}; a.A1 = A1; a.A2 = K2 ? A2 : nullptr; a.K1 = K1; a.K2 = K2; a.B = B; a.ldb = K; a.C = C; a.ldc = N; a.N = N; a.rows = rows;
+  a.bias = dbias; a.act = 0;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char* name, auto fn) {
+    fn(); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) fn();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    printf("%-28s %8.3f ms  %7.1f TF/s (f32-equivalent)  err=%s\n", name, ms, 2.0 * rows * K * N / ms * 1e-9, hipGetErrorString(hipGetLastError()));
+  };
+  timeit("x3 (split + gemm)", [&] { launch_bsplit(B, K, 1, N, K, nt, Bp, 0); launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  timeit("x3 (gemm only)", [&] { launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  GemmArgs b = a; b.C = C2;
+  timeit("f32 mfma", [&] { launch_rowgemm<EPI_BIAS_ACT>(b, 0); });
+  // error vs float64 on a sample of rows
+  std::vector<float> c1(rows * N), c2(rows * N);
+  hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(c2.data(), C2, c2.size() * 4, hipMemcpyDeviceToHost);
+  double e1m = 0, e2m = 0, e1s = 0, e2s = 0, ref_max = 0; int64_t cnt = 0;
+  for (int64_t r = 0; r < rows; r += (r < 300 || r > rows - 300) ? 1 : 997) {
+    for (int n = 0; n < N; ++n) {
+      double s = bias[n];
+      for (int k = 0; k < K1; ++k) s += (double)h1[r * K1 + k] * hb[(size_t)n * K + k];
+      for (int k = 0; k < K2; ++k) s += (double)h2[r * K2 + k] * hb[(size_t)n * K + K1 + k];
+      double d1 = fabs(c1[r * N + n] - s), d2 = fabs(c2[r * N + n] - s);
+      e1m = fmax(e1m, d1); e2m = fmax(e2m, d2); e1s += d1 * d1; e2s += d2 * d2; ref_max = fmax(ref_max, fabs(s)); ++cnt;
+    }
+  }
+  printf("vs float64 over %lld outputs (|ref| max %.3f): x3 max %.3e rms %.3e | f32 mfma max %.3e rms %.3e\n", (long long)cnt, ref_max,
+         e1m, sqrt(e1s / cnt), e2m, sqrt(e2s / cnt));
+  return 0;
+}
