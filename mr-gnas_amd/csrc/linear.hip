@@ -171,7 +171,6 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_dma_k(Wgr
   const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
   const int ldg = a.TM * 32, ldx = tnb * 32, stage = WBR * (ldg + a.TNB * 32);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int ntiles = a.TM * tnb;
   const int g4 = ldg / 4, x4 = ldx / 4, nf4 = WBR * (g4 + x4);
   const int K = a.K1 + a.K2;
   f32x16 acc[TPW];
@@ -219,57 +218,221 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_dma_k(Wgr
   };
   // per-tile LDS byte offsets of this lane's operands
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
-  unsigned goff[TPW], xoff[TPW];
+  // wave w owns column tile n = w of the block (tnb <= 4) and every row tile m = i: one X' fragment read
+  // feeds TM MFMAs (LDS delivers 64 B/clk per CU; two fragment reads per 64-cycle MFMA on 8 waves saturate it)
+  unsigned goff[TPW];
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int id = wave + 4 * i;
-    const int m = id < ntiles ? id / tnb : 0, n = id < ntiles ? id - m * tnb : 0;
-    goff[i] = (unsigned)((lh * ldg + m * 32 + li) * 4);
-    xoff[i] = (unsigned)((WBR * ldg + lh * ldx + n * 32 + li) * 4);
-  }
+  for (int i = 0; i < TPW; ++i) goff[i] = (unsigned)((lh * ldg + (i < a.TM ? i : 0) * 32 + li) * 4);
+  const unsigned xoff = (unsigned)((WBR * ldg + lh * ldx + (wave < tnb ? wave : 0) * 32 + li) * 4);
+  const bool active = wave < tnb;
+  // 3-slot LDS ring: the DMA runs two 16-row tiles (~3 us of MFMA time) ahead; vmcnt is waited on with the
+  // number of younger DMA instructions of this wave, never drained
+  int per_tile = 0;
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) per_tile += (wave * 64 + i * MRG_BLOCK < nf4) ? 1 : 0;
   if (r_begin < r_end) fetch(0, r_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (r_begin + WBR < r_end) fetch(1, r_begin + WBR, 1);
   int cur = 0;
   int64_t tile = 0;
   for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR, ++tile) {
-    const bool more = r0 + WBR < r_end;
-    if (more) fetch(cur ^ 1, r0 + WBR, tile + 1);
+    wait_vmcnt(r0 + WBR < r_end ? per_tile : 0);           // tile `tile` has landed (this wave's part) ...
+    __builtin_amdgcn_s_barrier();                          // ... everyone's part; all reads of the previous tile are done
+    if (r0 + 2 * WBR < r_end) fetch(cur >= 1 ? cur - 1 : 2, r0 + 2 * WBR, tile + 2);   // slot (tile + 2) % 3
     const unsigned base = lds0 + cur * stage * 4;
-#pragma unroll 1
+    // fragment reads of k-step t+1 are in flight while the MFMAs of k-step t issue
+    float gv[2][TPW], xv[2];
+    auto frag = [&](int b, int t) {
+      asm volatile("ds_read_b32 %0, %1" : "=v"(xv[b]) : "v"(base + xoff + t * 2 * ldx * 4));
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(gv[b][i]) : "v"(base + goff[i] + t * 2 * ldg * 4));
+    };
+    frag(0, 0);
+#pragma unroll
     for (int t = 0; t < WBR / 2; ++t) {
-      float gv[TPW], xv[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        asm volatile("ds_read_b32 %0, %1" : "=v"(gv[i]) : "v"(base + goff[i] + t * 2 * ldg * 4));
-        asm volatile("ds_read_b32 %0, %1" : "=v"(xv[i]) : "v"(base + xoff[i] + t * 2 * ldx * 4));
+      const int c = t & 1;
+      if (t + 1 < WBR / 2) {
+        frag(c ^ 1, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TPW + 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (active) {
 #pragma unroll
-      for (int i = 0; i < TPW; ++i)
-        if (wave + 4 * i < ntiles) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[i], xv[i], acc[i], 0, 0, 0);
+        for (int i = 0; i < TPW; ++i)
+          if (i < a.TM) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[c][i], xv[c], acc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur ^= 1;
-    }
+    cur = cur == 2 ? 0 : cur + 1;
   }
   const int ldw = a.TN * 32;
   float* out = a.ws + (int64_t)blockIdx.x * ldg * ldw;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int id = wave + 4 * i;
-    if (id < ntiles) {
-      const int m = id / tnb, n = id - m * tnb;
+    if (active && i < a.TM) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[(int64_t)row * ldw + (tn0 + n) * 32 + li] = acc[i][r];
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(int64_t)row * ldw + (tn0 + wave) * 32 + li] = acc[i][r];
       }
     }
   }
+}
+
+// ---- split-bf16 weight gradient (see gemm_x3.hpp for the arithmetic) ------------------------------
+// Both operands are activations here, so both are split in registers.  512 threads = 8 waves (two per SIMD:
+// the splits of one wave run under the MFMAs of the other); the workgroup owns all TM <= 7 row tiles of gW
+// and KT = 8 (NG = 2) or 16 (NG = 1, TM <= 4) column tiles; wave (g, p) owns row tiles [4g, 4g+4) x column
+// tiles {2p, 2p+1}: 6 fragments are split (264 VALU instructions) for 48 MFMAs per 16 rows.
+// LDS: 3-slot ring of [16 rows][A: 57 chunks | B: KT*8+1 chunks] (16-byte chunks; the odd pitch makes the
+// transposed fragment reads -- 8 ds_read_b32, rows 8h..8h+7 of one column per lane -- conflict free).
+constexpr int WX_THREADS = 512;
+constexpr int WX_APITCH = 57 * 4;            // floats per A row in LDS (224 columns + one pad chunk)
+
+template <int NG>
+__global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
+  constexpr int KP = 8 / NG, KT = 2 * KP;
+  constexpr int BPITCH = (KT * 8 + 1) * 4;
+  constexpr int ACH = WBR * 57, BCH = WBR * (KT * 8 + 1), STAGE_CH = ACH + BCH;
+  constexpr int NPF = (STAGE_CH + WX_THREADS - 1) / WX_THREADS;
+  extern __shared__ __align__(16) float smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int tn0 = (int)(((int64_t)blockIdx.y * a.TN) / gridDim.y);
+  const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wg = wave / KP, wp = wave % KP;
+  const int m0 = wg * 4;
+  const int an = a.TM - m0 < 4 ? (a.TM - m0 > 0 ? a.TM - m0 : 0) : 4;      // row tiles of this wave
+  const int kn = tnb - 2 * wp < 2 ? (tnb - 2 * wp > 0 ? tnb - 2 * wp : 0) : 2;   // column tiles of this wave
+  const int K = a.K1 + a.K2;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r_end = r_begin + a.rows_per_block;
+  if (r_end > a.rows) r_end = a.rows;
+
+  // loop-invariant DMA metadata of this thread's chunks
+  const float* src[NPF]; int64_t stride[NPF]; int rr[NPF]; int kind[NPF];     // kind: 0 data, 1 ones, 2 zeros
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int f = tid + i * WX_THREADS;
+    const bool isg = f < ACH;
+    const int f2 = isg ? f : (f < STAGE_CH ? f - ACH : 0);
+    const int per = isg ? 57 : KT * 8 + 1;
+    const int r = f2 / per, c = (f2 - r * per) * 4;
+    rr[i] = r;
+    if (isg) {
+      kind[i] = c < a.Nout ? 0 : 2;
+      src[i] = a.gY + (r_begin + r) * a.Nout + (c < a.Nout ? c : 0);
+      stride[i] = (int64_t)WBR * a.Nout;
+    } else {
+      const int cg = tn0 * 32 + c;
+      const bool incol = c < tnb * 32;
+      const XSel sx = wgrad_sel_x(a, (incol && cg < K) ? cg : 0);
+      kind[i] = (incol && cg < K) ? 0 : ((incol && cg == K) ? 1 : 2);
+      src[i] = sx.base + (r_begin + r) * sx.ld + sx.kk;
+      stride[i] = (int64_t)WBR * sx.ld;
+    }
+  }
+  int per_tile = 0;
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) per_tile += (wave * 64 + i * WX_THREADS < STAGE_CH) ? 1 : 0;
+  auto fetch = [&](int buf, int64_t r0, int64_t tile) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int f = tid + i * WX_THREADS;
+      if (f - lane < STAGE_CH) {                            // wave-uniform
+        const bool rv = r0 + rr[i] < r_end;
+        const float* p = (rv && kind[i] == 0) ? src[i] + tile * stride[i] : ((rv && kind[i] == 1) ? mrg_ones16 : mrg_zeros16);
+        if (f < STAGE_CH)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(smem + (buf * STAGE_CH + (f - lane)) * 4), 16, 0, 0);
+      }
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned a_off = (unsigned)((8 * lh * WX_APITCH + m0 * 32 + li) * 4);
+  const unsigned b_off = (unsigned)((ACH * 4 + 8 * lh * BPITCH + 2 * wp * 32 + li) * 4);
+  // one fragment: rows 8h..8h+7 of one column, split into three bf16 planes
+  auto frag = [&](unsigned addr, auto pitch_c, u32x4& H, u32x4& M, u32x4& L) {
+    constexpr int PB = decltype(pitch_c)::value * 4;
+    float v[8];
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v[0]) : "v"(addr));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[1]) : "v"(addr), "n"(PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[2]) : "v"(addr), "n"(2 * PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[3]) : "v"(addr), "n"(3 * PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[4]) : "v"(addr), "n"(4 * PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[5]) : "v"(addr), "n"(5 * PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[6]) : "v"(addr), "n"(6 * PB));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[7]) : "v"(addr), "n"(7 * PB));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h, m, l;
+      split_pair(v[2 * j], v[2 * j + 1], h, m, l);
+      H[j] = h; M[j] = m; L[j] = l;
+    }
+  };
+
+  if (r_begin < r_end) fetch(0, r_begin, 0);
+  if (r_begin + WBR < r_end) fetch(1, r_begin + WBR, 1);
+  int cur = 0;
+  int64_t tile = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR, ++tile) {
+    wait_vmcnt(r0 + WBR < r_end ? per_tile : 0);
+    __builtin_amdgcn_s_barrier();
+    if (r0 + 2 * WBR < r_end) fetch(cur >= 1 ? cur - 1 : 2, r0 + 2 * WBR, tile + 2);
+    const unsigned base = lds0 + cur * (STAGE_CH * 16);
+    if (an > 0 && kn > 0) {
+      u32x4 bh[2], bm[2], bl[2];
+      frag(base + b_off, std::integral_constant<int, BPITCH>{}, bh[0], bm[0], bl[0]);
+      if (kn > 1) frag(base + b_off + 128, std::integral_constant<int, BPITCH>{}, bh[1], bm[1], bl[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < an) {
+          u32x4 ah, am, al;
+          frag(base + a_off + i * 128, std::integral_constant<int, WX_APITCH>{}, ah, am, al);
+          const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (j < kn) {
+              const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[j]), Bm = __builtin_bit_cast(bf16x8, bm[j]), Bl = __builtin_bit_cast(bf16x8, bl[j]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  const int ldw = a.TN * 32;
+  float* out = a.ws + (int64_t)blockIdx.x * (a.TM * 32) * ldw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (i < an && j < kn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (m0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          out[(int64_t)row * ldw + (tn0 + 2 * wp + j) * 32 + li] = acc[i][j][r];
+        }
+      }
 }
 
 // gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
@@ -301,20 +464,26 @@ struct WgradPlan {
   bool ok;
 };
 
-static WgradPlan wgrad_plan(int64_t rows, int K, int Nout) {
+static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   WgradPlan p{};
   p.TM = (Nout + 31) / 32;
   p.TN = (K + 1 + 31) / 32;
-  // at most 28 accumulator tiles (7 per wave, 112 registers) per workgroup so that two workgroups
-  // share a CU; wider outputs split the X' column tiles over grid.y (gY is then re-read per split)
-  p.TNB = p.TM * p.TN <= 28 ? p.TN : (28 / p.TM > 0 ? 28 / p.TM : 0);
-  int per_wave = p.TNB > 0 ? (p.TM * p.TNB + 3) / 4 : 99;
   const int opts[] = {1, 2, 4, 7, 13};
   p.tpw = 0;
-  for (int o : opts) if (per_wave <= o) { p.tpw = o; break; }
+  if (dma && p.TM <= 7) {
+    // DMA kernel: wave w owns column tile w of the block (<= 4 per block) and all TM row tiles
+    p.TNB = p.TN < 4 ? p.TN : 4;
+    for (int o : opts) if (p.TM <= o) { p.tpw = o; break; }
+  } else {
+    // at most 28 accumulator tiles (7 per wave, 112 registers) per workgroup so that two workgroups
+    // share a CU; wider outputs split the X' column tiles over grid.y (gY is then re-read per split)
+    p.TNB = p.TM * p.TN <= 28 ? p.TN : (28 / p.TM > 0 ? 28 / p.TM : 0);
+    int per_wave = p.TNB > 0 ? (p.TM * p.TNB + 3) / 4 : 99;
+    for (int o : opts) if (per_wave <= o) { p.tpw = o; break; }
+  }
   int nf4 = WBR * (p.TM + p.TNB) * 8;                    // float4 per staged tile
   p.npf = (nf4 + MRG_BLOCK - 1) / MRG_BLOCK;
-  p.lds = (size_t)2 * WBR * (p.TM + p.TNB) * 32 * sizeof(float);
+  p.lds = (size_t)(dma ? 3 : 2) * WBR * (p.TM + p.TNB) * 32 * sizeof(float);
   p.ok = p.tpw > 0 && p.lds <= 160 * 1024 && p.npf <= 16;
   int64_t tiles = (rows + WBR - 1) / WBR;
   int64_t G = tiles < 512 ? tiles : 512;
@@ -341,14 +510,32 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
     if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Nout, st);
     return (int)e;
   }
-  WgradPlan p = wgrad_plan(rows, K, Nout);
+  const bool vec0 = (Nout % 4 == 0) && (K1 % 4 == 0) && (K2 % 4 == 0) && aligned16(gY) && aligned16(X1) && (!X2 || K2 == 0 || aligned16(X2)) &&
+                    Nout >= 4 && K1 >= 4 && (K2 == 0 || K2 >= 4) && Nout <= 224;
+  WgradPlan p = wgrad_plan(rows, K, Nout, vec0);
   if (!p.ok) return MRG_E_SHAPE;
   WgradArgs a{};
   a.gY = gY; a.Nout = Nout; a.X1 = X1; a.X2 = X2; a.K1 = K1; a.K2 = K2; a.ws = (float*)ws;
   a.rows = rows; a.rows_per_block = p.rows_per_block; a.TM = p.TM; a.TN = p.TN; a.TNB = p.TNB;
   if (!X2 || K2 == 0) { a.X2 = X1; a.K2 = 0; }
-  const bool vec = (Nout % 4 == 0) && (K1 % 4 == 0) && (a.K2 % 4 == 0) && aligned16(gY) && aligned16(X1) && aligned16(a.X2) &&
-                   Nout >= 4 && K1 >= 4 && (a.K2 == 0 || a.K2 >= 4);
+  const bool vec = vec0;
+  if (vec && gemm_mode() == 0 && p.TM <= 7) {        // split-bf16 core
+    const int ng = p.TM <= 4 ? 1 : 2, kt = 16 / ng;
+    dim3 gridx(p.G, (p.TN + kt - 1) / kt);
+    const size_t ldsx = (size_t)3 * WBR * (57 + kt * 8 + 1) * 16;
+    if (ng == 1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      hipLaunchKernelGGL((wgrad_x3_k<1>), gridx, dim3(WX_THREADS), ldsx, st, a);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      hipLaunchKernelGGL((wgrad_x3_k<2>), gridx, dim3(WX_THREADS), ldsx, st, a);
+    }
+    MRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias, p.G, K, Nout,
+                       p.TM * 32, p.TN * 32);
+    MRG_LAUNCH_CHECK();
+    return MRG_OK;
+  }
   dim3 grid(p.G, (p.TN + p.TNB - 1) / p.TNB);      // y-blocks own ~TN/grid.y column tiles each (<= TNB)
 #define GO(T, F)                                                                                                       \
   do {                                                                                                                 \

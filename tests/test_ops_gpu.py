@@ -279,3 +279,33 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     for i, scale in ((0, float(ref.abs().max())), (1, float(ref_gx.abs().max()))):
         assert errs[0][i] <= 1.5 * errs[1][i] + 1e-6 * scale, (errs, scale)
         assert errs[0][i] <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 200, 200), (40000, 200, 0, 200), (3000, 100, 100, 100), (517, 64, 0, 40),
+                                             (20000, 52, 0, 128), (259, 400, 0, 8), (16, 200, 200, 200), (0, 64, 64, 64)])
+def test_split_core_weight_gradient(rows, K1, K2, Nout):
+    """gW = gY^T [X1 | X2], gb = column sums of gY on the split-bf16 core against the exact-f32 core, both against
+    float64: ragged last row tile, 1 / 2 row-tile groups, 1..2 column blocks, bias column, empty input."""
+    from mr_gnas_amd._lib import call, ptr, stream_of
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + Nout + K2)
+    gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+    x1 = (torch.randn(rows, K1, generator=gen) * 2).to(DEV)
+    x2 = torch.randn(rows, K2, generator=gen).to(DEV) if K2 else None
+    x = x1 if x2 is None else torch.cat((x1, x2), 1)
+    ref_w = gy.double().t() @ x.double()
+    ref_b = gy.double().sum(0)
+    errs = {}
+    try:
+        for mode in (0, 1):
+            assert lib.mrg_gemm_set_mode(mode) == 0
+            gW, gb = torch.full((Nout, K1 + K2), 7.0, device=DEV), torch.full((Nout,), 7.0, device=DEV)
+            ws = torch.empty(max(16, int(lib.mrg_linear_bwd_weight_workspace_bytes(rows, K1 + K2, Nout))), dtype=torch.uint8, device=DEV)
+            call("mrg_linear_bwd_weight", (ptr(gy), ptr(x1), ptr(x2), ptr(gW), ptr(gb), ptr(ws), rows, K1, K2, Nout, stream_of(gW)))
+            errs[mode] = (float((gW.double() - ref_w).abs().max()), float((gb.double() - ref_b).abs().max()))
+    finally:
+        lib.mrg_gemm_set_mode(0)
+    for i, scale in ((0, max(1.0, float(ref_w.abs().max()) if rows else 1.0)), (1, max(1.0, float(ref_b.abs().max()) if rows else 1.0))):
+        assert errs[0][i] <= 1.5 * errs[1][i] + 2e-6 * scale, (errs, scale)
+        assert errs[0][i] <= 2e-5 * scale

@@ -115,6 +115,19 @@ def main():
         gy = rnd(E, D)
         rec("linear_bwd_input", timeit(lambda: torch.autograd.grad(out, xs, gy, retain_graph=True), args.reps), 0, fl)
         rec("linear_bwd_weight", timeit(lambda: torch.autograd.grad(out, Ws, gy, retain_graph=True), args.reps), 0, fl)
+    if want("wgrad"):
+        from mr_gnas_amd._lib import call, ptr, stream_of
+        lib = _lib.load()
+        for rows, K1, K2 in ((M, D, D), (M, D, 0), (E // 2, D, D), (N, D, D)):
+            gy, x1, x2 = rnd(rows, D), rnd(rows, K1), (rnd(rows, K2) if K2 else None)
+            gW, gb = torch.empty(D, K1 + K2, device=dev), torch.empty(D, device=dev)
+            ws = torch.empty(int(lib.mrg_linear_bwd_weight_workspace_bytes(rows, K1 + K2, D)), dtype=torch.uint8, device=dev)
+            fn = lambda: call("mrg_linear_bwd_weight", (ptr(gy), ptr(x1), ptr(x2), ptr(gW), ptr(gb), ptr(ws), rows, K1, K2, D, stream_of(gy)))
+            rec(f"wgrad rows={rows} K={K1}+{K2}", timeit(fn, args.reps), 0, 2 * rows * (K1 + K2) * D)
+            gx = torch.empty(rows, K1, device=dev); W = rnd(D, K1 + K2)
+            wt = torch.empty(int(lib.mrg_linear_bwd_input_workspace_bytes(K1, D)), dtype=torch.uint8, device=dev)
+            fn2 = lambda: call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), rows, K1, D, K1 + K2, 0, stream_of(gy)))
+            rec(f"bwd_input rows={rows} K={K1}", timeit(fn2, args.reps), 0, 2 * rows * K1 * D)
     print(json.dumps({"shape": args.shape, "N": N, "E": E, "D": D, "kernels": res}))
 
 
