@@ -215,8 +215,9 @@ class ShardedSupernet:
 
     # -- pieces ---------------------------------------------------------------------------
     def _mixed(self, mixed_op, w, h, h_in, total_rows):
-        if h.is_cuda:          # fused HIP epilogue with the statistics all-reduced in between
+        if (h.x if isinstance(h, K.Fan) else h).is_cuda:   # fused HIP epilogue with the statistics all-reduced in between
             return mixed_op(w, self.s, h, h_in, group=self._stat_group(), total_rows=total_rows)
+        h, h_in = (t.x if isinstance(t, K.Fan) else t for t in (h, h_in))
         out = 0
         for wk, (op, bn, act) in zip(w, mixed_op._ops):
             out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
@@ -243,8 +244,14 @@ class ShardedSupernet:
         return self.group if self.group is not None else dist.group.WORLD
 
     def _mixed_middle(self, mixed_op, w, h, total_nodes):
+        if isinstance(h, K.Fan):
+            hs = h
+            h = hs.x
+            take = hs.take
+        else:
+            take = lambda: h
         if h.is_cuda:
-            ys = [self._aggregate(op, name, h) for name, (op, _, _) in zip(OPS.MIDDLE_OPS, mixed_op._ops)]
+            ys = [self._aggregate(op, name, take()) for name, (op, _, _) in zip(OPS.MIDDLE_OPS, mixed_op._ops)]
             return K.mixed_epilogue(ys, [bn for _, bn, _ in mixed_op._ops], w, self._stat_group(), total_nodes)
         out = 0
         for wk, name, (op, bn, act) in zip(w, OPS.MIDDLE_OPS, mixed_op._ops):
@@ -253,18 +260,20 @@ class ShardedSupernet:
 
     def _cell(self, cell, x, hr, wz, wf, wm, wl):
         M, N = self.rows_total, self.s.number_of_nodes()
-        h_in = self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M)
+        fan = cell._fan                                    # one K-way gradient sum per state (supernet.SuperCell._fan)
+        h_in = fan(self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M))
         states, off = [h_in], 0
         for _ in range(cell.n_first):
             sN = sum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
             off += len(states)
-            states.append(sN)
-        states = [self._mixed_middle(cell.cell_middle._ops[i], wm[i], states[1 + i], N) for i in range(cell.n_first)]
+            states.append(fan(sN))
+        states = [fan(self._mixed_middle(cell.cell_middle._ops[i], wm[i], states[1 + i], N)) for i in range(cell.n_first)]
         off = 0
         for _ in range(cell.n_last):
             sN = sum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
             off += len(states)
-            states.append(sN)
+            states.append(fan(sN))
+        states = [t.take() if isinstance(t, K.Fan) else t for t in states]
         return cell.concat_weights(torch.cat(states, dim=1))
 
     # -- the step ---------------------------------------------------------------------------
