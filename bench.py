@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--negative", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture one whole step in a HIP graph and time K replays (launch-bound small step graphs; "
+                         "the per-kernel events of the roofline then come from the instrumented eager step)")
     ap.add_argument("--exact-f32", action="store_true",
                     help="run every GEMM on the exact-f32 MFMA core (mrg_gemm_set_mode(1)) instead of the split-bf16 core")
     ap.add_argument("--cpu-sample", type=int, default=30000, help="graph_batch_size of the CPU-baseline sample")
@@ -280,18 +283,32 @@ def main():
     table = kernel_table(_lib.meter.stop())
     dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
 
+    run_step = step
+    if args.hip_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run_step = graph.replay
+        log("one step captured in a HIP graph")
+
     # ---- timed region: exactly K steps, barrier + synchronize on both sides --------------------
-    if dominant:
+    if dominant and not args.hip_graph:
         _lib.meter.start([dominant])
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    dom_stats = kernel_table(_lib.meter.stop()) if dominant else {}
+    dom_stats = (kernel_table(_lib.meter.stop()) if not args.hip_graph else table) if dominant else {}
     log(f"timed {args.steps} steps in {dt:.3f} s")
     if sharded:
         import torch.distributed as dist
@@ -314,7 +331,8 @@ def main():
                    "matrix_core": ("exact f32 MFMA (v_mfma_f32_32x32x2_f32)" if args.exact_f32 else
                                    "f32 via 3-way bf16 split: 6 cross terms on v_mfma_f32_32x32x16_bf16, f32 accumulate "
                                    "(error vs float64 pinned <= 1.5x the exact-f32 core in tests)"),
-                   "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL"},
+                   "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL",
+                   "launch": "hip graph replay" if args.hip_graph else "eager"},
         "loss": float(step.last_loss) if step.last_loss is not None else None,
     }
     if dominant and dominant in dom_stats:
