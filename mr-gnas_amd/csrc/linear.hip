@@ -285,7 +285,7 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_dma_k(Wgr
 // the splits of one wave run under the MFMAs of the other); the workgroup owns all TM <= 7 row tiles of gW
 // and KT = 8 (NG = 2) or 16 (NG = 1, TM <= 4) column tiles; wave (g, p) owns row tiles [4g, 4g+4) x column
 // tiles {2p, 2p+1}: 6 fragments are split (264 VALU instructions) for 48 MFMAs per 16 rows.
-// LDS: 3-slot ring of [16 rows][A: 57 chunks | B: KT*8+1 chunks] (16-byte chunks; the odd pitch makes the
+// LDS: 4-slot ring (the DMA runs three tiles ahead) of [16 rows][A: 57 chunks | B: KT*8+1 chunks] (16-byte chunks; the odd pitch makes the
 // transposed fragment reads -- 8 ds_read_b32, rows 8h..8h+7 of one column per lane -- conflict free).
 constexpr int WX_THREADS = 512;
 constexpr int WX_APITCH = 57 * 4;            // floats per A row in LDS (224 columns + one pad chunk)
@@ -293,6 +293,7 @@ constexpr int WX_APITCH = 57 * 4;            // floats per A row in LDS (224 col
 template <int NG>
 __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
   constexpr int KP = 8 / NG, KT = 2 * KP;
+  constexpr int SLOTS = NG == 2 ? 4 : 3;              // LDS ring; the DMA runs SLOTS-1 tiles ahead
   constexpr int BPITCH = (KT * 8 + 1) * 4;
   constexpr int ACH = WBR * 57, BCH = WBR * (KT * 8 + 1), STAGE_CH = ACH + BCH;
   constexpr int NPF = (STAGE_CH + WX_THREADS - 1) / WX_THREADS;
@@ -385,13 +386,19 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
   };
 
   if (r_begin < r_end) fetch(0, r_begin, 0);
-  if (r_begin + WBR < r_end) fetch(1, r_begin + WBR, 1);
+#pragma unroll
+  for (int t = 1; t < SLOTS - 1; ++t)
+    if (r_begin + t * WBR < r_end) fetch(t, r_begin + t * WBR, t);
   int cur = 0;
   int64_t tile = 0;
   for (int64_t r0 = r_begin; r0 < r_end; r0 += WBR, ++tile) {
-    wait_vmcnt(r0 + WBR < r_end ? per_tile : 0);
+    {                                                      // younger DMA: the tiles already issued behind this one
+      int64_t left = (r_end - r0 + WBR - 1) / WBR - 1;
+      wait_vmcnt((int)(left < SLOTS - 2 ? left : SLOTS - 2) * per_tile);
+    }
     __builtin_amdgcn_s_barrier();
-    if (r0 + 2 * WBR < r_end) fetch(cur >= 1 ? cur - 1 : 2, r0 + 2 * WBR, tile + 2);
+    if (r0 + (SLOTS - 1) * WBR < r_end)                    // into the slot read during the previous tile
+      fetch(cur == 0 ? SLOTS - 1 : cur - 1, r0 + (SLOTS - 1) * WBR, tile + SLOTS - 1);
     const unsigned base = lds0 + cur * (STAGE_CH * 16);
     if (an > 0 && kn > 0) {
       u32x4 bh[2], bm[2], bl[2];
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
         }
       }
     }
-    cur = cur == 2 ? 0 : cur + 1;
+    cur = cur == SLOTS - 1 ? 0 : cur + 1;
   }
   const int ldw = a.TN * 32;
   float* out = a.ws + (int64_t)blockIdx.x * (a.TM * 32) * ldw;
@@ -522,7 +529,7 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
   if (vec && gemm_mode() == 0 && p.TM <= 7) {        // split-bf16 core
     const int ng = p.TM <= 4 ? 1 : 2, kt = 16 / ng;
     dim3 gridx(p.G, (p.TN + kt - 1) / kt);
-    const size_t ldsx = (size_t)3 * WBR * (57 + kt * 8 + 1) * 16;
+    const size_t ldsx = (size_t)(ng == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
     if (ng == 1) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
       hipLaunchKernelGGL((wgrad_x3_k<1>), gridx, dim3(WX_THREADS), ldsx, st, a);
