@@ -620,6 +620,33 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
 # ---------------------------------------------------------------------------
 # dense (per-feature) filters on the MFMA row GEMM
 # ---------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+class _Fork:
+    """Independent kernel chains (the direction segments of one operator write disjoint row ranges) run on
+    side HIP streams and join back: the tail of one GEMM (a 272 115-row segment fills 4.15 rounds of the chip,
+    the 14 541 self rows a fifth of one) is filled by the workgroups of the next instead of idling.
+    Every tensor the chains touch is allocated on the main stream BEFORE the fork."""
+
+    def __init__(self, device, n):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        pool = _SIDE_STREAMS.setdefault(key, [])
+        while len(pool) < n - 1:
+            pool.append(torch.cuda.Stream(device=device))
+        self.side = pool[:max(n - 1, 0)]
+        for st in self.side:
+            st.wait_stream(self.main)
+
+    def stream(self, i):
+        return self.main if i == 0 else self.side[i - 1]
+
+    def join(self):
+        for st in self.side:
+            self.main.wait_stream(st)
+
+
 class _DenseFilter(torch.autograd.Function):
     """Three direction segments [0,b0) [b0,b1) [b1,M), each with its own nn.Linear (W, b);
     params flat: W_in, b_in, W_out, b_out, W_self, b_self (None for an absent segment / bias).
@@ -635,17 +662,19 @@ class _DenseFilter(torch.autograd.Function):
         out = torch.empty_like(s)
         gate = torch.empty_like(s) if kind == 0 else None
         K_ = 2 * D if s_in is not None else D
-        segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
-        for i, (lo, hi, scale, edge) in enumerate(segs):
+        segs = [(i, lo, hi, scale, edge) for i, (lo, hi, scale, edge) in
+                enumerate(((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))) if hi > lo]
+        gws = [_ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s) for _ in segs]
+        fork = _Fork(s.device, len(segs))
+        for j, (i, lo, hi, scale, edge) in enumerate(segs):
             W, b = params[2 * i], params[2 * i + 1]
-            if hi <= lo:
-                continue
             rs = norm[lo:hi] if (edge and norm is not None) else None
-            gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s)
-            call("mrg_dense_filter_fwd", (kind, ptr(s[lo:hi]), ptr(s_in[lo:hi]) if s_in is not None else None, ptr(W), ptr(b),
-                                          ptr(rs), scale, ptr(out[lo:hi]), ptr(gate[lo:hi]) if gate is not None else None,
-                                          ptr(gws), hi - lo, D, st),
-                 nbytes=4 * (hi - lo) * (K_ + D * (2 if kind == 0 else 1)), flops=2 * (hi - lo) * K_ * D)
+            with torch.cuda.stream(fork.stream(j)):
+                call("mrg_dense_filter_fwd", (kind, ptr(s[lo:hi]), ptr(s_in[lo:hi]) if s_in is not None else None, ptr(W), ptr(b),
+                                              ptr(rs), scale, ptr(out[lo:hi]), ptr(gate[lo:hi]) if gate is not None else None,
+                                              ptr(gws[j]), hi - lo, D, stream_of(s)),
+                     nbytes=4 * (hi - lo) * (K_ + D * (2 if kind == 0 else 1)), flops=2 * (hi - lo) * K_ * D)
+        fork.join()
         ctx.cfg = (kind, b0, b1, scale_edge, scale_self)
         ctx.save_for_backward(s, s_in, norm, gate, *params)
         return out
@@ -662,33 +691,40 @@ class _DenseFilter(torch.autograd.Function):
         K_ = 2 * D if s_in is not None else D
         grads = []
         segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
-        for i, (lo, hi, scale, edge) in enumerate(segs):
+        work = []
+        for i, (lo, hi, scale, edge) in enumerate(segs):               # allocate everything on the main stream first
             W, b = params[2 * i], params[2 * i + 1]
             if W is None:
                 grads += [None, None]
                 continue
+            rows = max(hi - lo, 0)
             gW = torch.empty_like(W)
             gb = torch.empty_like(b) if b is not None else None
-            rows = max(hi - lo, 0)
-            rs = norm[lo:hi] if (edge and norm is not None and rows > 0) else None
-            sl = slice(lo, hi)
-            dz = torch.empty(rows, D, dtype=torch.float32, device=s.device)
-            # 1. dz (+ direct term of gs for the gated kinds)
-            call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(rs), scale,
-                                         ptr(dz), ptr(gs[sl]), rows, D, st), nbytes=4 * rows * D * (5 if kind == 0 else 2))
-            # 2. gs (+)= dz W[:, :D];  gs_in = dz W[:, D:]
-            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s)
-            gwork = dict(nbytes=4 * rows * 2 * D + 4 * D * D, flops=2 * rows * D * D)
-            call("mrg_linear_bwd_input", (ptr(dz), ptr(W), ptr(gs[sl]), ptr(wt), rows, D, D, K_, int(kind == 0), st), **gwork)
-            if s_in is not None:
-                wt2 = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s)
-                call("mrg_linear_bwd_input", (ptr(dz), ptr(W[:, D:]), ptr(gs_in[sl]), ptr(wt2), rows, D, D, K_, 0, st), **gwork)
-            # 3. gW = dz^T [s | s_in], gb = column sums of dz
-            ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)
-            call("mrg_linear_bwd_weight", (ptr(dz), ptr(s[sl]), ptr(s_in[sl]) if s_in is not None else None, ptr(gW), ptr(gb), ptr(ws),
-                                           rows, D, D if s_in is not None else 0, D, st),
-                 nbytes=4 * rows * (D + K_), flops=2 * rows * K_ * D)
             grads += [gW, gb]
+            work.append(dict(W=W, gW=gW, gb=gb, rows=rows, sl=slice(lo, hi), scale=scale,
+                             rs=norm[lo:hi] if (edge and norm is not None and rows > 0) else None,
+                             dz=torch.empty(rows, D, dtype=torch.float32, device=s.device),
+                             wt=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s),
+                             wt2=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s) if s_in is not None else None,
+                             ws=_ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)))
+        fork = _Fork(s.device, len(work))
+        for j, w in enumerate(work):
+            W, rows, sl = w["W"], w["rows"], w["sl"]
+            with torch.cuda.stream(fork.stream(j)):
+                st = stream_of(s)
+                # 1. dz (+ direct term of gs for the gated kinds)
+                call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(w["rs"]),
+                                             w["scale"], ptr(w["dz"]), ptr(gs[sl]), rows, D, st), nbytes=4 * rows * D * (5 if kind == 0 else 2))
+                # 2. gs (+)= dz W[:, :D];  gs_in = dz W[:, D:]
+                gwork = dict(nbytes=4 * rows * 2 * D + 4 * D * D, flops=2 * rows * D * D)
+                call("mrg_linear_bwd_input", (ptr(w["dz"]), ptr(W), ptr(gs[sl]), ptr(w["wt"]), rows, D, D, K_, int(kind == 0), st), **gwork)
+                if s_in is not None:
+                    call("mrg_linear_bwd_input", (ptr(w["dz"]), ptr(W[:, D:]), ptr(gs_in[sl]), ptr(w["wt2"]), rows, D, D, K_, 0, st), **gwork)
+                # 3. gW = dz^T [s | s_in], gb = column sums of dz
+                call("mrg_linear_bwd_weight", (ptr(w["dz"]), ptr(s[sl]), ptr(s_in[sl]) if s_in is not None else None, ptr(w["gW"]),
+                                               ptr(w["gb"]), ptr(w["ws"]), rows, D, D if s_in is not None else 0, D, st),
+                     nbytes=4 * rows * (D + K_), flops=2 * rows * K_ * D)
+        fork.join()
         return (None, gs, gs_in, None, None, None, None, None, *grads)
 
 
