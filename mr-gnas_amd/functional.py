@@ -6,6 +6,8 @@ Inputs are never modified; outputs are fresh tensors.  Every call site states
 the algorithmic bytes / flops of the launch so bench.py can
 price the kernels against the roofline.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -621,17 +623,20 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
 # dense (per-feature) filters on the MFMA row GEMM
 # ---------------------------------------------------------------------------
 _SIDE_STREAMS = {}
+SEGMENT_STREAMS = int(os.environ.get("MRG_SEGMENT_STREAMS", "3"))   # streams the direction segments of one operator use
 
 
-class _Fork:
+class Fork:
     """Independent kernel chains (the direction segments of one operator write disjoint row ranges) run on
     side HIP streams and join back: the tail of one GEMM (a 272 115-row segment fills 4.15 rounds of the chip,
     the 14 541 self rows a fifth of one) is filled by the workgroups of the next instead of idling.
     Every tensor the chains touch is allocated on the main stream BEFORE the fork."""
 
-    def __init__(self, device, n):
+    def __init__(self, device, n, tag="segments"):
+        if tag == "segments":
+            n = min(n, SEGMENT_STREAMS)
         self.main = torch.cuda.current_stream(device)
-        key = (device.index if device.index is not None else torch.cuda.current_device())
+        key = (device.index if device.index is not None else torch.cuda.current_device(), tag)   # one pool per nesting level
         pool = _SIDE_STREAMS.setdefault(key, [])
         while len(pool) < n - 1:
             pool.append(torch.cuda.Stream(device=device))
@@ -640,6 +645,7 @@ class _Fork:
             st.wait_stream(self.main)
 
     def stream(self, i):
+        i %= len(self.side) + 1
         return self.main if i == 0 else self.side[i - 1]
 
     def join(self):
@@ -665,7 +671,7 @@ class _DenseFilter(torch.autograd.Function):
         segs = [(i, lo, hi, scale, edge) for i, (lo, hi, scale, edge) in
                 enumerate(((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))) if hi > lo]
         gws = [_ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s) for _ in segs]
-        fork = _Fork(s.device, len(segs))
+        fork = Fork(s.device, len(segs))
         for j, (i, lo, hi, scale, edge) in enumerate(segs):
             W, b = params[2 * i], params[2 * i + 1]
             rs = norm[lo:hi] if (edge and norm is not None) else None
@@ -707,7 +713,7 @@ class _DenseFilter(torch.autograd.Function):
                              wt=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s),
                              wt2=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s) if s_in is not None else None,
                              ws=_ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)))
-        fork = _Fork(s.device, len(work))
+        fork = Fork(s.device, len(work))
         for j, w in enumerate(work):
             W, rows, sl = w["W"], w["rows"], w["sl"]
             with torch.cuda.stream(fork.stream(j)):

@@ -16,6 +16,8 @@ cannot travel).  Module/attribute names follow the reference so that its
 """
 import collections
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -45,6 +47,9 @@ def _xavier_param(*shape):
 # ---------------------------------------------------------------------------
 # supernet
 # ---------------------------------------------------------------------------
+MIXED_STREAMS = int(os.environ.get("MRG_MIXED_STREAMS", "4"))   # HIP streams the candidates of a MixedOp are spread over
+
+
 class MixedOp(nn.Module):
     """sum_k w_k * ReLU(BN_k(op_k(g, h, h_in)))   (reference models/cell_lp.py:12-33)."""
 
@@ -68,7 +73,21 @@ class MixedOp(nn.Module):
         n = len(self._ops)
         fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
         fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
-        ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
+        # The candidates are independent: they run round-robin on a few HIP streams so that the tail of one
+        # kernel (a GEMM workgroup owns a whole CU) is filled by another candidate's kernels.  Autograd replays
+        # each candidate's backward on the stream its forward ran on.
+        dev = fh.x.device
+        fork = K.Fork(dev, min(MIXED_STREAMS, n), tag="candidates")
+        ys = []
+        for k, (op, _, _) in enumerate(self._ops):
+            if isinstance(op, OPS.f_zero_op):
+                ys.append(None)
+                continue
+            with torch.cuda.stream(fork.stream(k % max(1, min(MIXED_STREAMS, n)))):
+                y = op(g, fh.take(), fi.take())
+            y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
+            ys.append(y)
+        fork.join()
         return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
 
 
