@@ -6,6 +6,7 @@ Inputs are never modified; outputs are fresh tensors.  Every call site states
 the algorithmic bytes / flops of the launch so bench.py can
 price the kernels against the roofline.
 """
+import contextlib
 import os
 
 import torch
@@ -623,6 +624,7 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
 # dense (per-feature) filters on the MFMA row GEMM
 # ---------------------------------------------------------------------------
 _SIDE_STREAMS = {}
+FORK_MIN_ROWS = 1 << 17      # below this many rows an operator is launch-bound: no side streams
 SEGMENT_STREAMS = int(os.environ.get("MRG_SEGMENT_STREAMS", "3"))   # streams the direction segments of one operator use
 
 
@@ -648,6 +650,10 @@ class Fork:
         i %= len(self.side) + 1
         return self.main if i == 0 else self.side[i - 1]
 
+    def on(self, i):
+        """Context: launch on chain i's stream (nothing to switch when there are no side streams)."""
+        return torch.cuda.stream(self.stream(i)) if self.side else contextlib.nullcontext()
+
     def join(self):
         for st in self.side:
             self.main.wait_stream(st)
@@ -671,11 +677,11 @@ class _DenseFilter(torch.autograd.Function):
         segs = [(i, lo, hi, scale, edge) for i, (lo, hi, scale, edge) in
                 enumerate(((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))) if hi > lo]
         gws = [_ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s) for _ in segs]
-        fork = Fork(s.device, len(segs))
+        fork = Fork(s.device, len(segs) if M >= FORK_MIN_ROWS else 1)
         for j, (i, lo, hi, scale, edge) in enumerate(segs):
             W, b = params[2 * i], params[2 * i + 1]
             rs = norm[lo:hi] if (edge and norm is not None) else None
-            with torch.cuda.stream(fork.stream(j)):
+            with fork.on(j):
                 call("mrg_dense_filter_fwd", (kind, ptr(s[lo:hi]), ptr(s_in[lo:hi]) if s_in is not None else None, ptr(W), ptr(b),
                                               ptr(rs), scale, ptr(out[lo:hi]), ptr(gate[lo:hi]) if gate is not None else None,
                                               ptr(gws[j]), hi - lo, D, stream_of(s)),
@@ -713,10 +719,10 @@ class _DenseFilter(torch.autograd.Function):
                              wt=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s),
                              wt2=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s) if s_in is not None else None,
                              ws=_ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)))
-        fork = Fork(s.device, len(work))
+        fork = Fork(s.device, len(work) if M >= FORK_MIN_ROWS else 1)
         for j, w in enumerate(work):
             W, rows, sl = w["W"], w["rows"], w["sl"]
-            with torch.cuda.stream(fork.stream(j)):
+            with fork.on(j):
                 st = stream_of(s)
                 # 1. dz (+ direct term of gs for the gated kinds)
                 call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(w["rs"]),
@@ -842,16 +848,27 @@ class _Fanout(torch.autograd.Function):
 
 class Fan:
     """Hands out aliases of `x` to its readers: ``fan.take()`` per reader, at most `cap` of them.
-    Without autograd (or for tensors that need no gradient) the tensor itself is returned."""
+    Aliases are created a dozen at a time (a further batch hangs off the last alias of the previous one, so
+    its gradients arrive as one pre-summed tensor).  Without autograd (or for tensors that need no
+    gradient) the tensor itself is returned."""
+
+    BATCH = 12
 
     def __init__(self, x, cap):
         self.x = x
+        self.left = cap
         self._live = torch.is_grad_enabled() and x.requires_grad and cap > 1
-        self._views = list(_Fanout.apply(x, cap)) if self._live else None
+        self._views = []
+        self._root = x
 
     def take(self):
         if not self._live:
             return self.x
-        if not self._views:
+        if self.left <= 0:
             raise RuntimeError("Fan: more readers than announced")
+        self.left -= 1
+        if not self._views:
+            views = list(_Fanout.apply(self._root, self.BATCH))
+            self._root = views.pop()                    # source of the next batch, if one is ever needed
+            self._views = views
         return self._views.pop()

@@ -77,13 +77,18 @@ class MixedOp(nn.Module):
         # kernel (a GEMM workgroup owns a whole CU) is filled by another candidate's kernels.  Autograd replays
         # each candidate's backward on the stream its forward ran on.
         dev = fh.x.device
-        fork = K.Fork(dev, min(MIXED_STREAMS, n), tag="candidates")
+        # (launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows)
+        nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
+        if nstreams <= 1:
+            ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
+        fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
         for k, (op, _, _) in enumerate(self._ops):
             if isinstance(op, OPS.f_zero_op):
                 ys.append(None)
                 continue
-            with torch.cuda.stream(fork.stream(k % max(1, min(MIXED_STREAMS, n)))):
+            with torch.cuda.stream(fork.stream(k)):
                 y = op(g, fh.take(), fi.take())
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
