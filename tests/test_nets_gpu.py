@@ -38,8 +38,24 @@ def test_fixed_genotype_network(case):
     grads_close(net, z, 5e-4, case)
 
 
+@pytest.fixture(params=["one stream", "side streams"])
+def streams(request, monkeypatch):
+    """The candidates of a MixedOp / the direction segments of a dense filter go to side HIP streams only for
+    >= 128k rows; the second parametrisation forces that path on the small golden graphs (repeated three times:
+    a missing stream dependency shows up as a flaky mismatch)."""
+    if request.param == "side streams":
+        from mr_gnas_amd import functional as K
+        monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+    return request.param
+
+
 @pytest.mark.parametrize("case", ["supernet_tiny", "supernet_d24"])
-def test_supernet_step(case):
+def test_supernet_step(case, streams):
+    for _ in range(3 if streams == "side streams" else 1):
+        _supernet_step(case)
+
+
+def _supernet_step(case):
     z = load_golden(case)
     n = z["node_id"].numel()
     g = G.RelGraph(n, z["src"], z["dst"], z["edge_type"], z["norm"], device=DEV)

@@ -14,7 +14,11 @@ import sys
 
 # C-ABI entry point -> substrings of the device kernels it launches (one of each per call)
 ENTRY_KERNELS = {
-    "mrg_linear_bwd_weight": ["wgrad_dma_k", "wgrad_reduce_k"],
+    "mrg_linear_bwd_weight": ["wgrad_x3_k", "wgrad_reduce_k"],
+    "mrg_linear_bwd_input": ["bsplit_k", "rowgemm_x3_k<7, 2, 0"],        # EPI_BIAS_ACT instances (shared with mrg_linear_fwd)
+    "mrg_dense_filter_fwd": ["bsplit_k", "rowgemm_x3_k<7, 2, 1"],        # EPI_GATE
+    "mrg_sum_buffers": ["sum_k"],
+    "mrg_distmult_score": ["distmult_k"],
     "mrg_span_gcs": ["span_gcs_k"],
     "mrg_mix_bwd_apply": ["mix_bwd_apply_k"],
     "mrg_mix_fwd": ["mix_fwd_k"],
