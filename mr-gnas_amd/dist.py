@@ -96,10 +96,14 @@ class EdgeShard(RelGraph):
 # collectives with adjoint backward
 # ---------------------------------------------------------------------------
 class _AllReduceSum(torch.autograd.Function):
+    """inplace=True reduces into x itself (a temporary nobody else reads, e.g. a fresh segment-sum partial)."""
+
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, inplace=False):
         ctx.group = group
-        y = x.clone()
+        y = x if inplace else x.clone()
+        if inplace:
+            ctx.mark_dirty(x)
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
         return y
 
@@ -107,7 +111,7 @@ class _AllReduceSum(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous().clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g, None
+        return g, None, None
 
 
 class _AllReduceMax(torch.autograd.Function):
@@ -229,16 +233,23 @@ class ShardedSupernet:
         s, E = self.s, self.s.num_edges()
         if name == "a_sum":
             part = self.k.seg_reduce("sum", x[:E], None, s)
-            h = _AllReduceSum.apply(part, self.group)[s.node_lo:s.node_hi]
+            h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
             h = op.drop_sum(h)
         else:
             m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
             if name == "a_max":
                 h = _AllReduceMax.apply(self.k.seg_reduce("max", m, None, s), self.group)[s.node_lo:s.node_hi]
             else:
-                h = _AllReduceSum.apply(self.k.seg_reduce("sum", m, None, s), self.group)[s.node_lo:s.node_hi]
-                h = h / s.global_in_degree[s.node_lo:s.node_hi].clamp(min=1).to(h.dtype).view(-1, 1)
+                h = _AllReduceSum.apply(self.k.seg_reduce("sum", m, None, s), self.group, True)[s.node_lo:s.node_hi]
+                h = h * self._inv_degree()
         return h + x[E:]
+
+    def _inv_degree(self):
+        """1 / max(in-degree, 1) of the own node rows over the WHOLE graph, [n_own, 1] (computed once)."""
+        if getattr(self, "_inv_deg", None) is None:
+            s = self.s
+            self._inv_deg = (1.0 / s.global_in_degree[s.node_lo:s.node_hi].clamp(min=1).to(torch.float32)).view(-1, 1).contiguous()
+        return self._inv_deg
 
     def _stat_group(self):
         return self.group if self.group is not None else dist.group.WORLD
