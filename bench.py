@@ -290,6 +290,9 @@ def main():
     dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
 
     run_step = step
+    if args.hip_graph and sharded:
+        # measured: the RCCL watchdog thread dies with hipErrorStreamCaptureUnsupported while a step with collectives is captured
+        raise SystemExit("--hip-graph is only supported for the single-GPU step")
     if args.hip_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
