@@ -493,7 +493,9 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   p.lds = (size_t)(dma ? 3 : 2) * WBR * (p.TM + p.TNB) * 32 * sizeof(float);
   p.ok = p.tpw > 0 && p.lds <= 160 * 1024 && p.npf <= 16;
   int64_t tiles = (rows + WBR - 1) / WBR;
-  int64_t G = tiles < 512 ? tiles : 512;
+  // >= 16 row tiles per workgroup: every extra workgroup costs a TM*32 x TN*32 partial tile (372 KB at 200 x 400)
+  // that the ordered reduction has to read back
+  int64_t G = (tiles + 15) / 16 < 512 ? (tiles + 15) / 16 : 512;
   if (G < 1) G = 1;
   int64_t tpb = (tiles + G - 1) / G;
   if (tpb < 1) tpb = 1;

@@ -557,9 +557,8 @@ class _MixedEpilogue(torch.autograd.Function):
             rv = ptr_array([b.running_var if track else None for b in cfg.bns])
             mom = bn0.momentum if bn0.momentum is not None else 0.1
             call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
-            if track:
-                for b in cfg.bns:
-                    b.num_batches_tracked += 1
+            if track:                                      # one multi-tensor launch instead of one per BatchNorm
+                torch._foreach_add_([b.num_batches_tracked for b in cfg.bns], 1)
         else:   # eval: fixed statistics
             for k, b in enumerate(cfg.bns):
                 invstd = torch.rsqrt(b.running_var + b.eps)
