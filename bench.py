@@ -291,7 +291,8 @@ def main():
 
     run_step = step
     if args.hip_graph and sharded:
-        # measured: the RCCL watchdog thread dies with hipErrorStreamCaptureUnsupported while a step with collectives is captured
+        # measured: capturing a step with RCCL collectives kills the watchdog thread (hipErrorStreamCaptureUnsupported) in the
+        # default capture mode and segfaults in thread_local mode on the full graph
         raise SystemExit("--hip-graph is only supported for the single-GPU step")
     if args.hip_graph:
         side = torch.cuda.Stream()
@@ -301,7 +302,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global)
+        # capture mode that poll is an error (hipErrorStreamCaptureUnsupported) and takes the process down
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             step()
         run_step = graph.replay
         log("one step captured in a HIP graph")
