@@ -236,11 +236,16 @@ class ShardedSupernet:
             h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
             h = op.drop_sum(h)
         else:
-            m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
-            if name == "a_max":
-                h = _AllReduceMax.apply(self.k.seg_reduce("max", m, None, s), self.group)[s.node_lo:s.node_hi]
+            fused = getattr(self.k, "linear_relu_partial", None)       # HIP: one autograd node (ReLU mask inside the reducer's backward)
+            if fused is not None and x.is_cuda:
+                part = fused("max" if name == "a_max" else "sum", x, op.linear.weight, op.linear.bias, s)
             else:
-                h = _AllReduceSum.apply(self.k.seg_reduce("sum", m, None, s), self.group, True)[s.node_lo:s.node_hi]
+                m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
+                part = self.k.seg_reduce("max" if name == "a_max" else "sum", m, None, s)
+            if name == "a_max":
+                h = _AllReduceMax.apply(part, self.group)[s.node_lo:s.node_hi]
+            else:
+                h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
                 h = h * self._inv_degree()
         return h + x[E:]
 

@@ -310,6 +310,59 @@ def linear_relu_aggregate(kind, x, W, b, graph):
     return _LinReluAgg.apply(REDUCE[kind], x, W, b, graph)
 
 
+class _LinReluPartial(torch.autograd.Function):
+    """The edge part of a_max / a_mean on ONE relation block of a sharded graph (mr-gnas_amd/dist.py): this
+    rank's partial  part[v] = max | sum over its LOCAL in-edges of ReLU(W x_e + b)  for all N nodes; the caller
+    all-reduces it, scales (mean) and adds the residual self rows.  x is the block's [E_local + n_own, D]
+    tensor (rows [E_local, ...) are not read; their gradient is zero here).  One autograd node: the ReLU mask
+    is applied inside the reducer's backward kernel, as in _LinReluAgg."""
+
+    @staticmethod
+    def forward(ctx, mode, x, W, b, graph):
+        x, W, b = f32c(x), f32c(W), f32c(b)
+        require_hip(x, W, b)
+        E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
+        st = stream_of(x)
+        y = torch.empty(E, D, dtype=torch.float32, device=x.device)
+        gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
+        call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
+             nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
+        if mode == 2:
+            out, arg = _seg_fwd(2, y, None, graph.plan(), N, D)
+        else:
+            sp, meta = graph.agg_plan("sum")
+            out, arg = span_gcs("copy", y, None, meta, sp), None
+        ctx.mode, ctx.graph = mode, graph
+        ctx.save_for_backward(x, W, y, *((arg,) if arg is not None else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, *rest = ctx.saved_tensors
+        arg = rest[0] if rest else None
+        graph, mode = ctx.graph, ctx.mode
+        g = f32c(g)
+        E, D = graph.num_edges(), x.shape[1]
+        st = stream_of(x)
+        gx = torch.empty_like(x)
+        gx[E:].zero_()
+        gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
+        _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)            # gy masked by ReLU
+        work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
+        wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
+        call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
+        gW = torch.empty_like(W)
+        gb = torch.empty(D, dtype=torch.float32, device=x.device)
+        ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", E, D, D), x)
+        call("mrg_linear_bwd_weight", (ptr(gy), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), E, D, 0, D, st), **work)
+        return None, gx, gW, gb, None
+
+
+def linear_relu_partial(kind, x, W, b, graph):
+    """kind "max" or "sum" (a_mean: the caller divides the all-reduced sum by the global in-degree)."""
+    return _LinReluPartial.apply(REDUCE[kind], x, W, b, graph)
+
+
 # ---------------------------------------------------------------------------
 # dense linear on rows (fp32 MFMA)
 # ---------------------------------------------------------------------------
