@@ -1,0 +1,167 @@
+"""Parity at BASELINE.json's full size (FB15k-237 shape: N = 14 541, E = 544 230, M = 558 771, D = 200).
+
+The CPU oracle needs minutes per operator at this size, so these tests use properties that do not depend on
+it: bit-exact agreement of index / max work with an independent torch formulation on the device, checksums
+(a sum over all output rows equals a float64 sum over all contributing input rows: every edge counted exactly
+once), linearity in the inputs, and a row sample of every GEMM against float64.  All calls go through the
+C ABI (mr_gnas_amd.functional / the operator modules)."""
+import numpy as np
+import pytest
+import torch
+
+import mr_gnas_amd
+from mr_gnas_amd import functional as K, graph as G, operations_lp as O, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D = 200
+
+
+@pytest.fixture(scope="module")
+def kg():
+    n, r, t = synth.SHAPES["fb15k237"]
+    tri = synth.synth_kg(n, r, t, 0)
+    g = G.build_search_graph(n, r, tri).to(DEV)
+    src, dst, _ = g.edges(form="all")
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    return dict(g=g, N=n, R=r, E=g.num_edges(), src=src, dst=dst, etype=g.edata["e_type"], gen=gen,
+                rnd=lambda *s: torch.randn(*s, device=DEV, generator=gen))
+
+
+def colsum64(t):
+    return t.double().sum(0)
+
+
+def assert_cols(a, b, rel, what):
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= rel * max(scale, 1.0), f"{what}: column checksum off by {err:.3e} (scale {scale:.3e})"
+
+
+def test_gather_full_graph_is_bit_exact(kg):
+    """G: all_ent[src_final], rel[etype_final] (reference models/model_search_lp.py:135-145) for all M rows."""
+    N, E = kg["N"], kg["E"]
+    ent, rel = kg["rnd"](N, D), kg["rnd"](2 * kg["R"] + 1, D)
+    idx_e = torch.cat((kg["src"].long(), torch.arange(N, device=DEV)))
+    idx_r = torch.cat((kg["etype"].long(), torch.full((N,), 2 * kg["R"], dtype=torch.long, device=DEV)))
+    assert torch.equal(K.gather(ent, K.GatherPlan(idx_e, N)), ent[idx_e])
+    assert torch.equal(K.gather(rel, K.GatherPlan(idx_r, 2 * kg["R"] + 1)), rel[idx_r])
+    # and its backward (segmented sum over the inverted index): every row's gradient lands exactly once
+    e = ent.clone().requires_grad_(True)
+    gm = kg["rnd"](E + N, D)
+    K.gather(e, K.GatherPlan(idx_e, N)).backward(gm)
+    ref = torch.zeros(N, D, dtype=torch.float64, device=DEV).index_add_(0, idx_e, gm.double())
+    np.testing.assert_allclose(e.grad.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+def test_segmented_max_full_graph_is_bit_exact(kg):
+    """DGL update_all(copy_e, max) (reference models/operations_lp.py:233): exact agreement with scatter_reduce(amax),
+    zero rows for nodes without in-edges, gradient routed to exactly one edge per (node, column)."""
+    N, E = kg["N"], kg["E"]
+    msg = torch.relu(kg["rnd"](E, D)).requires_grad_(True)
+    self_rows = kg["rnd"](N, D)
+    out = K.seg_reduce("max", msg, self_rows, kg["g"])
+    ref = torch.zeros(N, D, device=DEV).scatter_reduce(0, kg["dst"].long().view(-1, 1).expand(E, D), msg.detach(), "amax",
+                                                         include_self=False)
+    assert torch.equal(out.detach(), ref + self_rows)
+    gout = kg["rnd"](N, D)
+    out.backward(gout)
+    has_in = torch.zeros(N, dtype=torch.bool, device=DEV)
+    has_in[kg["dst"].long()] = True
+    # exactly one edge per (destination with in-edges, column) receives the gradient
+    hits = torch.zeros(N, D, device=DEV).index_add_(0, kg["dst"].long(), (msg.grad != 0).float())
+    assert float(hits[has_in].max()) <= 1.0 and float(hits[~has_in].abs().max() if (~has_in).any() else 0.0) == 0.0
+    assert_cols(colsum64(msg.grad), colsum64(gout * (hits > 0)), 1e-5, "max backward")
+
+
+def test_a_sum_checksum_and_linearity(kg):
+    """a_sum (reference models/operations_lp.py:252-264, dropout off): sum_v out[v] = sum_e x[e] + sum_v x[E+v]."""
+    N, E = kg["N"], kg["E"]
+    op = O.MIXED_OPS["a_sum"]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+    x1, x2 = kg["rnd"](E + N, D), kg["rnd"](E + N, D)
+    o1, o2, o12 = op(kg["g"], x1, None), op(kg["g"], x2, None), op(kg["g"], x1 + x2, None)
+    assert o1.shape == (N, D)
+    assert_cols(colsum64(o1), colsum64(x1), 1e-6, "a_sum checksum")
+    assert float((o12 - (o1 + o2)).abs().max()) <= 1e-4 * float(o12.abs().max())
+
+
+def test_a_mean_and_a_max_against_device_formulation(kg):
+    """a_mean / a_max at full size: Linear + ReLU on the split matrix core, then the reducer, against a float64 /
+    scatter_reduce formulation of the same operator on the device."""
+    N, E = kg["N"], kg["E"]
+    x = kg["rnd"](E + N, D)
+    dstx = kg["dst"].long().view(-1, 1).expand(E, D)
+    for name, red in (("a_mean", "mean"), ("a_max", "amax")):
+        op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+        with torch.no_grad():
+            out = op(kg["g"], x, None)
+            m = torch.relu(torch.nn.functional.linear(x[:E].double(), op.linear.weight.double(), op.linear.bias.double()))
+            ref = torch.zeros(N, D, dtype=torch.float64, device=DEV).scatter_reduce(0, dstx, m, red, include_self=False) + x[E:].double()
+        err = float((out.double() - ref).abs().max())
+        assert err <= 1e-4 * float(ref.abs().max()), f"{name}: {err:.3e}"
+
+
+def test_sparse_gate_and_compose_checksums(kg):
+    """f_sparse_comp (reference :304-343) against its float64 definition on a row sample; pre_sub / pre_mult exactly."""
+    N, E = kg["N"], kg["E"]
+    M = E + N
+    s, s_in = kg["rnd"](M, D), kg["rnd"](M, D)
+    assert torch.equal(O.MIXED_OPS["pre_sub"]({})(kg["g"], s, s_in), s - s_in)
+    assert torch.equal(O.MIXED_OPS["pre_mult"]({})(kg["g"], s, s_in), s * s_in)
+    op = O.MIXED_OPS["f_sparse_comp"]({"feature_dim": D}).to(DEV)
+    with torch.no_grad():
+        out = op(kg["g"], s, s_in)
+        rows = torch.cat((torch.arange(0, 4096, device=DEV), torch.arange(E // 2 - 2048, E // 2 + 2048, device=DEV),
+                          torch.arange(E - 2048, E + 2048, device=DEV), torch.arange(M - 4096, M, device=DEV)))
+        norm = kg["g"].edata["norm"].view(-1).double()
+        for lo, hi, W, a in ((0, E // 2, op.W_in, op.a_in), (E // 2, E, op.W_out, op.a_out), (E, M, op.W_self, op.a_self)):
+            r = rows[(rows >= lo) & (rows < hi)]
+            cat = torch.cat((s[r], s_in[r]), 1).double()
+            gate = torch.sigmoid(torch.nn.functional.linear(torch.nn.functional.linear(cat, W.weight.double(), W.bias.double()), a.weight.double()))
+            ref = gate * s[r].double() / 3.0
+            if hi <= E:
+                ref = ref * norm[r].view(-1, 1)
+            err = float((out[r].double() - ref).abs().max())
+            assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"rows [{lo},{hi}): {err:.3e}"
+
+
+def test_dense_filter_and_linear_full_rows(kg):
+    """The tall-skinny GEMMs at M rows: a row sample against float64 and the linearity checksum
+    sum_rows(X W^T + b) = (sum_rows X) W^T + M b, which involves every row."""
+    N, E = kg["N"], kg["E"]
+    M = E + N
+    x = kg["rnd"](M, D)
+    W, b = kg["rnd"](D, D) / D ** 0.5, kg["rnd"](D)
+    y = K.linear(x, W, b, None)
+    rows = torch.randint(0, M, (4096,), device=DEV, generator=kg["gen"])
+    ref = torch.nn.functional.linear(x[rows].double(), W.double(), b.double())
+    assert float((y[rows].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    chk = torch.nn.functional.linear(colsum64(x).view(1, -1), W.double()).view(-1) + M * b.double()
+    assert_cols(colsum64(y), chk, 1e-5, "linear checksum")
+    op = O.MIXED_OPS["f_dense_comp"]({"feature_dim": D}).to(DEV)
+    s_in = kg["rnd"](M, D)
+    with torch.no_grad():
+        out = op(kg["g"], x, s_in)
+    assert out.shape == (M, D) and bool(torch.isfinite(out).all())
+    # the gate is a sigmoid: |out| <= |s| / 3 on every row (norm <= 1), with equality impossible
+    assert bool((out.abs() <= x.abs() / 3.0 + 1e-6).all())
+
+
+def test_distmult_full_batch_checksum(kg):
+    """calc_score (reference models/model_search_lp.py:169-176) over a full negative-sampled batch (~3 M triples):
+    the sum of all scores against float64, computed in chunks."""
+    N, R = kg["N"], kg["R"]
+    T = 2_993_265
+    gen = kg["gen"]
+    trip = torch.stack((torch.randint(0, N, (T,), device=DEV, generator=gen), torch.randint(0, 2 * R + 1, (T,), device=DEV, generator=gen),
+                        torch.randint(0, N, (T,), device=DEV, generator=gen)), 1)
+    ent, rel = kg["rnd"](N, D), kg["rnd"](2 * R + 1, D)
+    score = K.distmult_score(ent, rel, K.ScorePlan(trip, N, 2 * R + 1))
+    ref_sum, ref_abs = 0.0, 0.0
+    for lo in range(0, T, 1 << 19):
+        t = trip[lo:lo + (1 << 19)]
+        sc = (ent[t[:, 0]].double() * rel[t[:, 1]].double() * ent[t[:, 2]].double()).sum(1)
+        ref_sum += float(sc.sum())
+        ref_abs += float(sc.abs().sum())
+        assert float((score[lo:lo + (1 << 19)].double() - sc).abs().max()) <= 1e-4 * max(1.0, float(sc.abs().max()))
+    assert abs(float(score.double().sum()) - ref_sum) <= 1e-6 * ref_abs
