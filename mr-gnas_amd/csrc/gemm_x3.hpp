@@ -192,6 +192,10 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
     }
   };
 
+  // Asynchronous register fills: the asm statements below return at once, the data arrives later and is first
+  // read behind the matching s_waitcnt.  This relies on hipcc keeping each u32x4 in the 4-register tuple the asm
+  // wrote (it is exactly the MFMA operand tuple, so there is nothing to copy); a copy scheduled between the load and
+  // the wait would read stale registers -- the float64 comparisons of tests/test_ops_gpu.py would catch that.
   u32x4 bq[NT][3];
   const unsigned voff = (unsigned)lane * 16u;
   const char* bcol = Bp + (int64_t)blockIdx.y * NT * 3072;
