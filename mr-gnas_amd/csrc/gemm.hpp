@@ -422,7 +422,12 @@ inline int gemm_pick_nt(int ncols) {
   if (t <= 1) return 1;
   if (t <= 2) return 2;
   if (t <= 4) return 4;
-  return 7;                          // wider outputs use several column blocks of 224
+  if (t <= 7) return 7;
+  // wider outputs use several column blocks: the block width that pads the fewest all-zero tiles
+  // (256 columns: 2 x 4 tiles, not 7 + 1 padded to 14), the wider one on ties (A is re-read per column block)
+  int best = 7, waste = ((t + 6) / 7) * 7 - t;
+  if (((t + 3) / 4) * 4 - t < waste) best = 4;
+  return best;
 }
 
 inline size_t gemm_lds_bytes(int nt, int mt, int bk) { return (size_t)2 * (128 * mt + nt * 32) * (bk + 4) * sizeof(float); }

@@ -13,7 +13,7 @@ namespace mrg {
 constexpr int WBR = 16;    // rows per LDS tile
 
 struct WgradArgs {
-  const float* gY; int Nout;                 // [rows][Nout]
+  const float* gY; int Nout; int ldg;        // [rows][ldg], Nout valid columns (a column block of a wider gradient)
   const float* X1; const float* X2; int K1, K2;
   float* ws;
   int64_t rows, rows_per_block;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(MRG_BLOCK, (TPW <= 7 ? 2 : 1)) void wgrad_dma_k(Wgr
     rr[i] = r;
     if (isg) {
       kind[i] = c < a.Nout ? 0 : 2;
-      src[i] = a.gY + (r_begin + r) * a.Nout + (c < a.Nout ? c : 0);
-      stride[i] = (int64_t)WBR * a.Nout;
+      src[i] = a.gY + (r_begin + r) * a.ldg + (c < a.Nout ? c : 0);
+      stride[i] = (int64_t)WBR * a.ldg;
     } else {
       const XSel sx = wgrad_sel_x(a, c < K ? c : 0);
       kind[i] = c < K ? 0 : (c == K ? 1 : 2);
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
     rr[i] = r;
     if (isg) {
       kind[i] = c < a.Nout ? 0 : 2;
-      src[i] = a.gY + (r_begin + r) * a.Nout + (c < a.Nout ? c : 0);
-      stride[i] = (int64_t)WBR * a.Nout;
+      src[i] = a.gY + (r_begin + r) * a.ldg + (c < a.Nout ? c : 0);
+      stride[i] = (int64_t)WBR * a.ldg;
     } else {
       const int cg = tn0 * 32 + c;
       const bool incol = c < tnb * 32;
@@ -511,8 +511,30 @@ int64_t wgrad_workspace_bytes(int64_t rows, int K, int Nout) {
 }
 
 // gW[Nout][K1+K2] = gY^T [X1 | X2], gbias = column sums of gY
+static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const float* X2, int K1, int K2, float* gW, float* gbias, void* ws,
+                           int64_t rows, int Nout, hipStream_t st);
+
 int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int K2, float* gW, float* gbias, void* ws,
                  int64_t rows, int Nout, hipStream_t st) {
+  // more than 7 row tiles of gW (Nout > 224, e.g. D = 256): balanced column blocks of gY, each a launch of the
+  // <= 7-tile kernels (X is re-read per block); same workspace, stream ordered
+  const bool splittable = Nout > 224 && rows > 0 && (Nout % 4 == 0) && (K1 % 4 == 0) && (K2 % 4 == 0) && aligned16(gY) && aligned16(X1) &&
+                          (!X2 || K2 == 0 || aligned16(X2)) && K1 >= 4 && (K2 == 0 || K2 >= 4);
+  if (splittable) {
+    const int nblk = (Nout + 223) / 224;
+    const int cw = (((Nout + nblk - 1) / nblk) + 31) / 32 * 32;
+    for (int n0 = 0; n0 < Nout; n0 += cw) {
+      const int nc = Nout - n0 < cw ? Nout - n0 : cw;
+      int rc = launch_wgrad_one(gY + n0, Nout, X1, X2, K1, K2, gW + (int64_t)n0 * (K1 + K2), gbias ? gbias + n0 : nullptr, ws, rows, nc, st);
+      if (rc != MRG_OK) return rc;
+    }
+    return MRG_OK;
+  }
+  return launch_wgrad_one(gY, Nout, X1, X2, K1, K2, gW, gbias, ws, rows, Nout, st);
+}
+
+static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const float* X2, int K1, int K2, float* gW, float* gbias, void* ws,
+                           int64_t rows, int Nout, hipStream_t st) {
   const int K = K1 + K2;
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)Nout * K, st);
@@ -524,7 +546,7 @@ int launch_wgrad(const float* gY, const float* X1, const float* X2, int K1, int 
   WgradPlan p = wgrad_plan(rows, K, Nout, vec0);
   if (!p.ok) return MRG_E_SHAPE;
   WgradArgs a{};
-  a.gY = gY; a.Nout = Nout; a.X1 = X1; a.X2 = X2; a.K1 = K1; a.K2 = K2; a.ws = (float*)ws;
+  a.gY = gY; a.Nout = Nout; a.ldg = ldg; a.X1 = X1; a.X2 = X2; a.K1 = K1; a.K2 = K2; a.ws = (float*)ws;
   a.rows = rows; a.rows_per_block = p.rows_per_block; a.TM = p.TM; a.TN = p.TN; a.TNB = p.TNB;
   if (!X2 || K2 == 0) { a.X2 = X1; a.K2 = 0; }
   const bool vec = vec0;

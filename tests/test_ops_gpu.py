@@ -283,7 +283,8 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 200, 200), (40000, 200, 0, 200), (3000, 100, 100, 100), (517, 64, 0, 40),
-                                             (20000, 52, 0, 128), (259, 400, 0, 8), (16, 200, 200, 200), (0, 64, 64, 64)])
+                                             (20000, 52, 0, 128), (259, 400, 0, 8), (16, 200, 200, 200), (0, 64, 64, 64),
+                                             (5000, 256, 0, 256), (3001, 128, 128, 300), (777, 512, 0, 512)])
 def test_split_core_weight_gradient(rows, K1, K2, Nout):
     """gW = gY^T [X1 | X2], gb = column sums of gY on the split-bf16 core against the exact-f32 core, both against
     float64: ragged last row tile, 1 / 2 row-tile groups, 1..2 column blocks, bias column, empty input."""
