@@ -420,13 +420,31 @@ class GatherPlan:
     which is a segmented sum of the incoming gradient rows."""
 
     def __init__(self, idx, num_table_rows):
-        from .graph import dst_csr_plan
-        from .graph import span_meta, span_plan
+        self.idx = idx
         self.idx32 = idx.to(torch.int32).contiguous()
         self.rows = int(num_table_rows)
-        self.plan = dst_csr_plan(idx, self.rows)
-        self.sp = span_plan(idx, self.rows)
-        self.meta = span_meta(self.sp, torch.arange(idx.numel(), device=idx.device))
+        self._plan = self._sp = self._meta = None      # built on first use: a new step graph per step pays only for what it runs
+
+    @property
+    def plan(self):
+        if self._plan is None:
+            from .graph import dst_csr_plan
+            self._plan = dst_csr_plan(self.idx, self.rows)
+        return self._plan
+
+    @property
+    def sp(self):
+        if self._sp is None:
+            from .graph import span_plan
+            self._sp = span_plan(self.idx, self.rows)
+        return self._sp
+
+    @property
+    def meta(self):
+        if self._meta is None:
+            from .graph import span_meta
+            self._meta = span_meta(self.sp, torch.arange(self.idx.numel(), device=self.idx.device))
+        return self._meta
 
 
 class _Gather(torch.autograd.Function):
