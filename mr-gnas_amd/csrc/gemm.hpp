@@ -127,28 +127,40 @@ __device__ __forceinline__ float4 gemm_mask_a(float4 v, const GemmArgs& a, int64
 template <int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh,
                                               bool full) {
-  int64_t rowc[16];
+  if (rowbase >= a.rows) return;                           // wave-uniform: the whole 32-row strip is out of range
+  // One pointer per accumulator row (clamped to the last valid row) and per array, set up once; a column tile is then
+  // a constant 128-byte offset from it, i.e. an immediate of the load / store.  (Per-tile 64-bit address arithmetic
+  // made hipcc spill hundreds of addresses of the 224-accumulator kernels to scratch memory.)
+  const int last = (int)((a.rows - 1 - rowbase) < 31 ? (a.rows - 1 - rowbase) : 31);
+  const int colw = col0 + li < a.N ? col0 + li : a.N - 1;   // this lane's column in tile 0 (clamped: only lanes of a partial tile)
+  float* crow[16];
+  const float* srow[16];
+  float* xrow[16];
   float cs[16];
+  bool rok[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    rowc[r] = row < a.rows ? row : a.rows - 1;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int rc = row < last ? row : last;
+    rok[r] = row <= last;
+    crow[r] = a.C + (rowbase + rc) * a.ldc + colw;
+    if (EPI == EPI_GATE) srow[r] = a.S + (rowbase + rc) * a.ld_s + colw;
+    if (EPI == EPI_ACCUM) srow[r] = a.Cin + (rowbase + rc) * a.ld_cin + colw;
+    if (EPI == EPI_GATE) xrow[r] = a.aux ? a.aux + (rowbase + rc) * a.N + colw : nullptr;
     cs[r] = 1.0f;
-    if (EPI == EPI_GATE || EPI == EPI_SCALE) cs[r] = a.scale * (a.rowscale ? a.rowscale[rowc[r]] : 1.0f);
+    if (EPI == EPI_GATE || EPI == EPI_SCALE) cs[r] = a.scale * (a.rowscale ? a.rowscale[rowbase + rc] : 1.0f);
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = col0 + n * 32 + li;
+    // columns of this tile that exist; a lane beyond them re-reads its tile-0 column (never stored)
     const bool cok = col < a.N;
-    const int colc = cok ? col : a.N - 1;
-    const float bv = a.bias ? a.bias[colc] : 0.f;
+    const int off = cok ? n * 32 : 0;
+    const float bv = a.bias ? a.bias[cok ? col : colw] : 0.f;
     float in[16], v[16], g[16];
-    if (EPI == EPI_GATE) {
+    if (EPI == EPI_GATE || EPI == EPI_ACCUM) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) in[r] = a.S[rowc[r] * a.ld_s + colc];
-    } else if (EPI == EPI_ACCUM) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) in[r] = a.Cin[rowc[r] * a.ld_cin + colc];
+      for (int r = 0; r < 16; ++r) in[r] = srow[r][off];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -167,19 +179,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     if (full) {
       if (cok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.C[rowc[r] * a.ldc + col] = v[r];
+        for (int r = 0; r < 16; ++r) crow[r][n * 32] = v[r];
         if (EPI == EPI_GATE && a.aux) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a.aux[rowc[r] * a.N + col] = g[r];
+          for (int r = 0; r < 16; ++r) xrow[r][n * 32] = g[r];
         }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cok && row < a.rows) {
-          a.C[row * a.ldc + col] = v[r];
-          if (EPI == EPI_GATE && a.aux) a.aux[row * a.N + col] = g[r];
+        if (cok && rok[r]) {
+          crow[r][n * 32] = v[r];
+          if (EPI == EPI_GATE && a.aux) xrow[r][n * 32] = g[r];
         }
       }
     }
