@@ -131,7 +131,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   typedef float v4f __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int64_t roww = (int64_t)blockIdx.x * GBM + wave * WROWS;
   const int col0 = blockIdx.y * (NT * 32);
   const int K = a.K1 + a.K2;

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   const int tn0 = (int)(((int64_t)blockIdx.y * a.TN) / gridDim.y);
   const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wg = wave / KP, wp = wave % KP;
   const int m0 = wg * 4;
   const int an = a.TM - m0 < 4 ? (a.TM - m0 > 0 ? a.TM - m0 : 0) : 4;      // row tiles of this wave
@@ -410,17 +410,28 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
           u32x4 ah, am, al;
           frag(base + a_off + i * 128, std::integral_constant<int, WX_APITCH>{}, ah, am, al);
           const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (j < kn) {
-              const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[j]), Bm = __builtin_bit_cast(bf16x8, bm[j]), Bl = __builtin_bit_cast(bf16x8, bl[j]);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[i][j], 0, 0, 0);
-            }
+          const bf16x8 Bh0 = __builtin_bit_cast(bf16x8, bh[0]), Bm0 = __builtin_bit_cast(bf16x8, bm[0]), Bl0 = __builtin_bit_cast(bf16x8, bl[0]);
+          if (kn > 1) {                                    // two accumulators interleaved: no back-to-back dependent MFMAs
+            const bf16x8 Bh1 = __builtin_bit_cast(bf16x8, bh[1]), Bm1 = __builtin_bit_cast(bf16x8, bm[1]), Bl1 = __builtin_bit_cast(bf16x8, bl[1]);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[i][1], 0, 0, 0);
+          } else {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
           }
         }
       }
