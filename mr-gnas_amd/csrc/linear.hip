@@ -506,7 +506,7 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   int64_t tiles = (rows + WBR - 1) / WBR;
   // >= 16 row tiles per workgroup: every extra workgroup costs a TM*32 x TN*32 partial tile (372 KB at 200 x 400)
   // that the ordered reduction has to read back
-  int64_t G = (tiles + 15) / 16 < 512 ? (tiles + 15) / 16 : 512;
+  int64_t G = (tiles + 15) / 16 < 256 ? (tiles + 15) / 16 : 256;      // one workgroup per CU and column block
   if (G < 1) G = 1;
   int64_t tpb = (tiles + G - 1) / G;
   if (tpb < 1) tpb = 1;

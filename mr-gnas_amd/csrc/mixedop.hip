@@ -32,7 +32,25 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, i
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s1[q][j] = 0.0; s2[q][j] = 0.0; }
     if (y != nullptr) {
-      for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+      // four rows per trip: four independent loads in flight per lane (one load per trip left HBM latency exposed)
+      const int64_t step = (int64_t)gridDim.x * RPB;
+      int64_t r = (int64_t)blockIdx.x * RPB + rw;
+      for (; r + 3 * step < rows; r += 4 * step) {
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q) {
+          int c = sl + q * LPR;
+          if (c < dv) {
+            Vec<VEC> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Vec<VEC>::load(y + (r + u * step) * D + c * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) { double d = (double)v[u][j]; s1[q][j] += d; s2[q][j] += d * d; }
+          }
+        }
+      }
+      for (; r < rows; r += step) {
 #pragma unroll
         for (int q = 0; q < KMAX; ++q) {
           int c = sl + q * LPR;
