@@ -140,11 +140,18 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
       int c = sl + q * LPR;
       if (c < dv) {
         Vec<VEC> acc = Vec<VEC>::fill(0.f);
+        // phase 1: every branch's load is issued before any is used (a load consumed inside its own `if (k < K)`
+        // block leaves one 16-byte load in flight per lane)
+        Vec<VEC> vin[MRG_MIX_MAXK];
+#pragma unroll
+        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          vin[k] = Vec<VEC>::fill(0.f);
+          if (k < K && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+        }
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           if (k < K) {
-            const float* y = ys.p[k];
-            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            const Vec<VEC> v = vin[k];
             Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -187,11 +194,16 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
       int c = sl + q * LPR;
       if (c < dv) {
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+        Vec<VEC> vin[KB];                                  // all loads first (see mix_fwd_k)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          vin[k] = Vec<VEC>::fill(0.f);
+          if (k < K && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+        }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
           if (k < K) {
-            const float* y = ys.p[k];
-            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            const Vec<VEC> v = vin[k];
             const float* cf = lds + k * 4 * D + c * VEC;
             const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D), c3 = Vec<VEC>::load(cf + 3 * D);
 #pragma unroll
@@ -283,11 +295,16 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       int c = sl + q * LPR;
       if (c < dv) {
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+        Vec<VEC> vin[MRG_MIX_MAXK];                        // all loads first (see mix_fwd_k)
+#pragma unroll
+        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          vin[k] = Vec<VEC>::fill(0.f);
+          if (k < K && gys.p[k] != nullptr && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+        }
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           if (k < K && gys.p[k] != nullptr) {
-            const float* y = ys.p[k];
-            Vec<VEC> v = y ? Vec<VEC>::load(y + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+            const Vec<VEC> v = vin[k];
             const float* cf = lds + k * 6 * D + c * VEC;
             const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D),
                            c3 = Vec<VEC>::load(cf + 3 * D), c4 = Vec<VEC>::load(cf + 4 * D), c5 = Vec<VEC>::load(cf + 5 * D);
