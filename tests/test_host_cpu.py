@@ -212,3 +212,21 @@ def test_async_fill_kernels_do_not_spill():
                 seen += 1
                 assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} VGPRs"
     assert seen >= 20
+
+
+def test_fan_sums_reader_gradients_and_tolerates_unused_aliases():
+    """functional.Fan: aliases of one tensor for its readers; the gradient is the sum over the readers that were
+    used, unused aliases contribute nothing, and more readers than one batch of aliases chain correctly."""
+    from mr_gnas_amd import functional as K
+    x = torch.randn(5, 3, requires_grad=True)
+    fan = K.Fan(x, 40)
+    weights = [float(i + 1) for i in range(30)]            # 30 readers > Fan.BATCH: exercises the chained batches
+    total = sum(w * fan.take().sum() for w in weights)
+    fan.take()                                              # an alias nobody reads
+    total.backward()
+    assert torch.allclose(x.grad, torch.full_like(x, sum(weights)))
+    with pytest.raises(RuntimeError):
+        small = K.Fan(x, 2)
+        small.take(); small.take(); small.take()
+    y = torch.randn(4, 2)                                   # no gradient needed: the tensor itself is handed out
+    assert K.Fan(y, 8).take() is y
