@@ -28,6 +28,10 @@
 #ifndef MRG_X3_DBG
 #define MRG_X3_DBG 0
 #endif
+// cache policy of the streamed A operand's DMA (lab: 0 default, 2 = nt)
+#ifndef MRG_A_CPOL
+#define MRG_A_CPOL 0
+#endif
 
 namespace mrg {
 
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
       } else {
         p = arow1[i] + (k + 4 <= K ? k : K - 4);
       }
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(dst + 64 * i * 4), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(dst + 64 * i * 4), 16, 0, MRG_A_CPOL);
     }
   };
   const unsigned lds_ring = (unsigned)(size_t)(lds_ptr_t)ring;

@@ -35,6 +35,20 @@ def test_argument_errors_without_gpu():
     assert lib.mrg_compose_fwd(7, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 8, None) == -3
     assert lib.mrg_gate_fwd(ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), ctypes.c_void_p(16), 5, 3, 9, 8, 1.0, None) == -2
     assert lib.mrg_seg_reduce_fwd(9, *([None] * 7), 0, None, None, None, 0, 0, None, None, None, None, 0, 8, None) == -3
+    # the entry points added after the first path: shape / enum / NULL checks, size-0 calls succeed without a device
+    P = ctypes.c_void_p
+    assert lib.mrg_sum_buffers(None, 3, P(16), 8, 0, None) == -1                       # NULL pointer array
+    assert lib.mrg_sum_buffers((ctypes.c_void_p * 1)(16), 0, P(16), 8, 0, None) == -2  # K out of range
+    assert lib.mrg_sum_buffers((ctypes.c_void_p * 1)(16), 1, P(16), 0, 0, None) == 0   # nothing to do
+    assert lib.mrg_distmult_score(None, None, None, None, None, None, 0, 8, None) == 0
+    assert lib.mrg_distmult_score(None, P(16), P(16), P(16), P(16), P(16), 4, 8, None) == -1
+    assert lib.mrg_distmult_score(P(16), P(16), P(16), P(16), P(16), P(16), 4, 0, None) == -2
+    assert lib.mrg_gemm_set_mode(7) == -3 and lib.mrg_gemm_set_mode(0) == 0
+    assert lib.mrg_gemm_workspace_bytes(400, 200) >= 400 * 200 * 4 and lib.mrg_gemm_workspace_bytes(0, 200) == 0
+    assert lib.mrg_linear_fwd(P(16), P(16), None, P(16), None, 0, 8, 8, 0, None) == 0  # zero rows
+    assert lib.mrg_linear_fwd(None, P(16), None, P(16), None, 4, 8, 8, 0, None) == -1
+    assert lib.mrg_linear_fwd(P(16), P(16), None, P(16), None, 4, 8, 8, 5, None) == -3  # unknown activation
+    assert lib.mrg_linear_bwd_input(P(16), P(16), P(16), None, 4, 8, 8, 8, 0, None) == -4  # workspace is mandatory
     with pytest.raises(_lib.MrgnasError):
         _lib.check(-2, "x")
 
