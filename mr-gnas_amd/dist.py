@@ -333,9 +333,9 @@ def all_reduce_gradients(tensors, group=None):
     flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
-    for t in tensors:
+    for t in tensors:                                   # views of the one reduced buffer: no per-parameter copy
         n = t.numel()
-        t.grad = flat[off:off + n].view_as(t).clone()
+        t.grad = flat[off:off + n].view_as(t)
         off += n
 
 
