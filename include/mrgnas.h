@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 1
+#define MRG_ABI_VERSION 2   /* 2: GEMM entry points take a workspace (split matrix core), span_gcs ext_scal, new entry points */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */

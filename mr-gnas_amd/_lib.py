@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmrgnas_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -127,10 +127,15 @@ class KernelMeter:
 meter = KernelMeter()
 
 
+_FN = {}
+
+
 def call(name, args, nbytes=0, flops=0):
     """Invoke C-ABI function `name`; raise on a non-zero return code."""
-    fn = getattr(load(), name)
-    if meter.active(name):
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    if meter.names is not None and meter.active(name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         code = fn(*args)

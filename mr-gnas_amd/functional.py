@@ -27,8 +27,16 @@ def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+_WS_BYTES = {}
+
+
 def _ws_bytes(name, *args):
-    return getattr(_lib.load(), name)(*args)
+    """Workspace size queries are pure functions of the shape: asked once per (entry point, shape)."""
+    key = (name, args)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = getattr(_lib.load(), name)(*args)
+    return n
 
 
 # ---------------------------------------------------------------------------
