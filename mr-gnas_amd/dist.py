@@ -231,23 +231,28 @@ class ShardedSupernet:
         """a_max / a_sum / a_mean on a shard: local partial over local edges -> all-reduce ->
         own node rows (+ residual self rows)  (reference models/operations_lp.py:223-264)."""
         s, E = self.s, self.s.num_edges()
+        hip = x.is_cuda and getattr(self.k, "linear_relu_partial", None) is not None
+        self_rows = None
         if name == "a_sum":
-            part = self.k.seg_reduce("sum", x[:E], None, s)
+            if hip:                                       # one autograd node for the edge part and the residual rows
+                part, self_rows = self.k.sum_partial(x, s)
+            else:
+                part = self.k.seg_reduce("sum", x[:E], None, s)
             h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
             h = op.drop_sum(h)
         else:
-            fused = getattr(self.k, "linear_relu_partial", None)       # HIP: one autograd node (ReLU mask inside the reducer's backward)
-            if fused is not None and x.is_cuda:
-                part = fused("max" if name == "a_max" else "sum", x, op.linear.weight, op.linear.bias, s)
+            kind = "max" if name == "a_max" else "sum"
+            if hip:
+                part, self_rows = self.k.linear_relu_partial(kind, x, op.linear.weight, op.linear.bias, s)
             else:
                 m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
-                part = self.k.seg_reduce("max" if name == "a_max" else "sum", m, None, s)
+                part = self.k.seg_reduce(kind, m, None, s)
             if name == "a_max":
                 h = _AllReduceMax.apply(part, self.group)[s.node_lo:s.node_hi]
             else:
                 h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
                 h = h * self._inv_degree()
-        return h + x[E:]
+        return h + (self_rows if self_rows is not None else x[E:])
 
     def _inv_degree(self):
         """1 / max(in-degree, 1) of the own node rows over the WHOLE graph, [n_own, 1] (computed once)."""

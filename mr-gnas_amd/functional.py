@@ -342,18 +342,21 @@ class _LinReluPartial(torch.autograd.Function):
             out, arg = span_gcs("copy", y, None, meta, sp), None
         ctx.mode, ctx.graph = mode, graph
         ctx.save_for_backward(x, W, y, *((arg,) if arg is not None else ()))
-        return out
+        return out, x[E:].clone()                       # the residual self rows leave through the same node
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gself):
         x, W, y, *rest = ctx.saved_tensors
         arg = rest[0] if rest else None
         graph, mode = ctx.graph, ctx.mode
-        g = f32c(g)
         E, D = graph.num_edges(), x.shape[1]
+        g = f32c(g) if g is not None else torch.zeros(graph.number_of_nodes(), D, dtype=torch.float32, device=x.device)
         st = stream_of(x)
         gx = torch.empty_like(x)
-        gx[E:].zero_()
+        if gself is not None:
+            gx[E:] = gself
+        else:
+            gx[E:].zero_()
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
         _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)            # gy masked by ReLU
         work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
@@ -367,8 +370,43 @@ class _LinReluPartial(torch.autograd.Function):
 
 
 def linear_relu_partial(kind, x, W, b, graph):
-    """kind "max" or "sum" (a_mean: the caller divides the all-reduced sum by the global in-degree)."""
+    """kind "max" or "sum" (a_mean: the caller divides the all-reduced sum by the global in-degree).
+    Returns (partial [N, D], self rows x[E:] [n_own, D]); both gradients return through one [M, D] write."""
     return _LinReluPartial.apply(REDUCE[kind], x, W, b, graph)
+
+
+class _SumPartial(torch.autograd.Function):
+    """a_sum on one relation block: (partial sums over the LOCAL in-edges for all N nodes, self rows x[E:]).
+    One node, so the backward writes the [M, D] gradient once instead of two zero-padded slice gradients."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        x = f32c(x)
+        require_hip(x)
+        E = graph.num_edges()
+        sp, meta = graph.agg_plan("sum")
+        ctx.graph = graph
+        ctx.shape = x.shape
+        return span_gcs("copy", x, None, meta, sp), x[E:].clone()
+
+    @staticmethod
+    def backward(ctx, g, gself):
+        graph = ctx.graph
+        E, D = graph.num_edges(), ctx.shape[1]
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=(g if g is not None else gself).device)
+        if gself is not None:
+            gx[E:] = gself
+        else:
+            gx[E:].zero_()
+        if g is not None:
+            _seg_bwd(0, f32c(g), graph, None, gx, None)          # rows [0, E) of gx: g[dst(e)]
+        else:
+            gx[:E].zero_()
+        return gx, None
+
+
+def sum_partial(x, graph):
+    return _SumPartial.apply(x, graph)
 
 
 # ---------------------------------------------------------------------------
