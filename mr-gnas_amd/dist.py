@@ -35,6 +35,7 @@ import torch.nn.functional as F
 
 from . import functional as K
 from . import operations_lp as OPS
+from .supernet import _tsum
 from .graph import RelGraph
 
 
@@ -285,13 +286,13 @@ class ShardedSupernet:
         h_in = fan(self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M))
         states, off = [h_in], 0
         for _ in range(cell.n_first):
-            sN = sum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
+            sN = _tsum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
             off += len(states)
             states.append(fan(sN))
         states = [fan(self._mixed_middle(cell.cell_middle._ops[i], wm[i], states[1 + i], N)) for i in range(cell.n_first)]
         off = 0
         for _ in range(cell.n_last):
-            sN = sum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
+            sN = _tsum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
             off += len(states)
             states.append(fan(sN))
         states = [t.take() if isinstance(t, K.Fan) else t for t in states]

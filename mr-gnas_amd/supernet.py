@@ -38,6 +38,15 @@ def xavier_init_(module):
     return module
 
 
+def _tsum(tensors):
+    """Sum of tensors without Python's `0 + first` (which is a full-size elementwise kernel and a copy)."""
+    it = iter(tensors)
+    total = next(it)
+    for t in it:
+        total = total + t
+    return total
+
+
 def _xavier_param(*shape):
     p = nn.Parameter(torch.empty(*shape))
     nn.init.xavier_normal_(p, gain=nn.init.calculate_gain('relu'))
@@ -129,7 +138,7 @@ class SuperCell(nn.Module):
     def _dense_stage(self, stage, states, weights, g, h_in, steps):
         off = 0
         for _ in range(steps):
-            s = sum(stage._ops[off + j](weights[off + j], g, h, h_in) for j, h in enumerate(states))
+            s = _tsum(stage._ops[off + j](weights[off + j], g, h, h_in) for j, h in enumerate(states))
             off += len(states)
             states.append(self._fan(s))
         return states
@@ -303,7 +312,7 @@ class FixedCell(nn.Module):
         zero_out = self._ops[0][0][0](g, src_emb, hr)
         states = [src_emb, zero_out]
         for n in range(1, self._nb):
-            states.append(sum(self._ops[n][i][0](g, states[i], zero_out) for i in range(n + 1) if len(self._ops[n][i])))
+            states.append(_tsum(self._ops[n][i][0](g, states[i], zero_out) for i in range(n + 1) if len(self._ops[n][i])))
         h = self.concat(torch.cat([states[i] for i in self._concat_node], dim=1))
         return F.relu(self.batchnorm_h(h))
 
