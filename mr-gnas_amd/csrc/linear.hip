@@ -506,7 +506,11 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   int64_t tiles = (rows + WBR - 1) / WBR;
   // >= 16 row tiles per workgroup: every extra workgroup costs a TM*32 x TN*32 partial tile (372 KB at 200 x 400)
   // that the ordered reduction has to read back
-  int64_t G = (tiles + 15) / 16 < 256 ? (tiles + 15) / 16 : 256;      // one workgroup per CU and column block
+  // ... and about one workgroup per CU: 256 / (column blocks of the split-core kernel) row blocks (the figure depends on
+  // the shape only, never on the kernel chosen: the workspace query and the launch must agree)
+  const int ny = (p.TN + (p.TM <= 4 ? 16 : 8) - 1) / (p.TM <= 4 ? 16 : 8);
+  const int64_t gmax = 256 / ny > 32 ? 256 / ny : 32;
+  int64_t G = (tiles + 15) / 16 < gmax ? (tiles + 15) / 16 : gmax;
   if (G < 1) G = 1;
   int64_t tpb = (tiles + G - 1) / G;
   if (tpb < 1) tpb = 1;
