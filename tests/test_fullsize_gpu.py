@@ -165,3 +165,35 @@ def test_distmult_full_batch_checksum(kg):
         ref_abs += float(sc.abs().sum())
         assert float((score[lo:lo + (1 << 19)].double() - sc).abs().max()) <= 1e-4 * max(1.0, float(sc.abs().max()))
     assert abs(float(score.double().sum()) - ref_sum) <= 1e-6 * ref_abs
+
+
+@pytest.mark.parametrize("fn_", ["sub", "mul"])
+def test_comp_graph_conv_full_graph(kg, fn_):
+    """CompGraphConv (reference models/compgcn.py:48-113) on the full graph, batch norm off, dropout off, against the
+    same layer written with torch indexing / index_add_ in float64 on the device (every edge, both directions,
+    self loop, the 1/3 scale and tanh)."""
+    from mr_gnas_amd import compgcn as C
+    N, E, R = kg["N"], kg["E"], kg["R"]
+    g = G.RelGraph(N, kg["src"], kg["dst"], device=DEV)
+    b0, _ = kg["g"].bounds()
+    in_mask = torch.arange(E, device=DEV) < b0
+    g.edata.update(etype=kg["etype"], norm=kg["g"].edata["norm"].view(-1), in_edges_mask=in_mask, out_edges_mask=~in_mask)
+    layer = C.CompGraphConv(D, D, comp_fn=fn_, batchnorm=False, dropout=0.0).to(DEV)
+    layer.train()
+    n_in = kg["rnd"](N, D) * 0.5
+    r_in = kg["rnd"](2 * R, D) * 0.5
+    with torch.no_grad():
+        n_out, r_out = layer(g, n_in, r_in)
+        r_all = torch.cat((r_in, layer.loop_rel), 0).double()
+        h = n_in.double()
+        comp = (lambda a, b: a - b) if fn_ == "sub" else (lambda a, b: a * b)
+        ef = r_all[kg["etype"].long()] * g.edata["norm"].double().view(-1, 1)
+        msg = comp(h[kg["src"].long()], ef)
+        msg = torch.where(in_mask.view(-1, 1), msg @ layer.W_I.weight.double().t() + layer.W_I.bias.double(),
+                          msg @ layer.W_O.weight.double().t() + layer.W_O.bias.double())
+        agg = torch.zeros(N, D, dtype=torch.float64, device=DEV).index_add_(0, kg["dst"].long(), msg)
+        self_msg = comp(h, r_all[-1:].expand(N, D)) @ layer.W_S.weight.double().t() + layer.W_S.bias.double()
+        ref_n = torch.tanh((agg + self_msg) / 3.0)
+        ref_r = (r_all @ layer.W_R.weight.double().t() + layer.W_R.bias.double())[:-1]
+    assert float((n_out.double() - ref_n).abs().max()) <= 1e-4
+    assert float((r_out.double() - ref_r).abs().max()) <= 1e-4 * max(1.0, float(ref_r.abs().max()))
