@@ -61,7 +61,7 @@ def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
 
 import os as _os
 
-SPAN_ELEMS = int(_os.environ.get("MRG_SPAN", "64"))      # sorted elements reduced by one lane group in the span kernels
+SPAN_ELEMS = int(_os.environ.get("MRG_SPAN", "96"))      # sorted elements reduced by one lane group in the span kernels
 
 
 def span_plan(seg, nseg, span=None):
