@@ -225,13 +225,23 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
 // ======================================================================================
 namespace mrg {
 
+// prefetch depth per mode (measured on the FB15k-237 shape, D = 200): two gathers per element (sub / mul) want 8
+// elements in flight, one gather (copy / negs) 4 -- deeper costs occupancy, shallower exposes the gather latency
+#ifndef MRG_SPAN_U1
+#define MRG_SPAN_U1 4
+#endif
+#ifndef MRG_SPAN_UM
+#define MRG_SPAN_UM 4
+#endif
+template <int MODE> struct SPAN_U { static constexpr int value = MODE == MRG_GCS_SUB ? 8 : (MODE == MRG_GCS_MUL ? MRG_SPAN_UM : MRG_SPAN_U1); };
+
 template <int VEC, int LPR, int KMAX, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict__ X, const float* __restrict__ Y,
                                                         const int4* __restrict__ meta, const float* __restrict__ ext_scal,
                                                         int64_t E, int span, const int32_t* __restrict__ span_slot,
                                                         int64_t n_spans, float* __restrict__ out, float* __restrict__ ws_val, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  constexpr int U = 8;
+  constexpr int U = SPAN_U<MODE>::value;      // elements whose row gathers are in flight per lane group
   constexpr bool NY = NeedsY<MODE>::value;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
