@@ -7,7 +7,9 @@
 
 #define MRG_WAVE 64
 #define MRG_BLOCK 256            // 4 waves per workgroup, one per SIMD
+#ifndef MRG_MAX_GRID
 #define MRG_MAX_GRID 2048        // 256 CUs x 8 blocks: streaming kernels grid-stride past this
+#endif
 
 #define MRG_LAUNCH_CHECK()                                  \
   do {                                                      \
