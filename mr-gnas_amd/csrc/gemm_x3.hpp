@@ -32,6 +32,10 @@
 #ifndef MRG_A_CPOL
 #define MRG_A_CPOL 0
 #endif
+// VALU instructions the scheduler may place after each MFMA of a tile (lab sweep: 2 / 3 / 4 / 6)
+#ifndef MRG_X3_VPM
+#define MRG_X3_VPM 3
+#endif
 
 namespace mrg {
 
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
 #pragma unroll
       for (int i = 0; i < 6 * MT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MRG_X3_VPM, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (has_next && !((MRG_X3_DBG & 32) && s > 0)) load_b(n, s + 1);
