@@ -16,14 +16,18 @@ import torch
 import torch.nn as nn
 
 from . import functional as K
+from .graph import cached_on
 
 
 def _layer_plans(g, n_rel_rows):
-    """Index structures of a graph for CompGraphConv, cached on the graph object."""
-    key = "_mrg_compgcn_plans"
-    cached = getattr(g, key, None)
-    if cached is not None and cached["n_rel_rows"] == n_rel_rows:
-        return cached
+    """Index structures of a graph for CompGraphConv, cached on the graph object for as long as the edge
+    tensors they derive from (masks, norm, etype) are the same unmodified objects."""
+    src, dst, _ = g.edges(form='all')
+    deps = (src, dst, g.edata['in_edges_mask'], g.edata['out_edges_mask'], g.edata['norm'], g.edata['etype'])
+    return cached_on(g, "_mrg_compgcn_plans", deps, n_rel_rows, lambda: _build_layer_plans(g, n_rel_rows))
+
+
+def _build_layer_plans(g, n_rel_rows):
     src, dst, _ = g.edges(form='all')
     N, dev = g.number_of_nodes(), src.device
     in_m = g.edata['in_edges_mask'].bool()
@@ -36,9 +40,7 @@ def _layer_plans(g, n_rel_rows):
     counts = torch.bincount(seg, minlength=2 * N).view(N, 2).float()
     ar = torch.arange(N, device=dev)
     loop = K.ComposePlan(ar, torch.full((N,), n_rel_rows - 1, dtype=torch.long, device=dev), ar, None, N, n_rel_rows, N)
-    cached = {"n_rel_rows": n_rel_rows, "edges": edges, "counts": counts, "loop": loop}
-    setattr(g, key, cached)
-    return cached
+    return {"n_rel_rows": n_rel_rows, "edges": edges, "counts": counts, "loop": loop}
 
 
 class CompGraphConv(nn.Module):

@@ -36,7 +36,7 @@ import torch.nn.functional as F
 from . import functional as K
 from . import operations_lp as OPS
 from .supernet import _tsum
-from .graph import RelGraph
+from .graph import RelGraph, cached_on
 
 
 # ---------------------------------------------------------------------------
@@ -185,7 +185,10 @@ class _SyncBatchNorm(torch.autograd.Function):
 
 def sync_batch_norm(x, bn, total_rows, group):
     """F.batch_norm(training=True) semantics of module `bn` (nn.BatchNorm1d) over rows that are
-    partitioned across `group`; updates bn.running_* like torch does (unbiased variance)."""
+    partitioned across `group`; updates bn.running_* like torch does (unbiased variance).
+    In eval mode (running statistics present) it normalises with them, like nn.BatchNorm1d: no collective."""
+    if not bn.training and bn.track_running_stats and bn.running_mean is not None:
+        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
     y, mean, var = _SyncBatchNorm.apply(x, bn.weight, bn.bias, total_rows, bn.eps, group)
     if bn.training and bn.track_running_stats:
         with torch.no_grad():
@@ -321,11 +324,9 @@ class ShardedSupernet:
         """This rank's share of the mean BCE (reference models/model_search_lp.py:181-188):
         the ranks' values add up to the reference loss."""
         if ent.is_cuda:
-            key = (samples_local.data_ptr(), tuple(samples_local.shape), samples_local._version)
-            if getattr(self, "_score_key", None) != key:
-                self._score_plan = K.ScorePlan(samples_local, ent.shape[0], rel.shape[0])
-                self._score_key = key
-            score = K.distmult_score(ent, rel, self._score_plan)
+            plan = cached_on(self, "_score_cache", (samples_local,), (ent.shape[0], rel.shape[0]),
+                             lambda: K.ScorePlan(samples_local, ent.shape[0], rel.shape[0]))
+            score = K.distmult_score(ent, rel, plan)
         else:
             t = samples_local.long()
             score = torch.sum(ent[t[:, 0]] * rel[t[:, 1]] * ent[t[:, 2]], dim=1)

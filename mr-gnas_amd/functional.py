@@ -46,7 +46,9 @@ class _Compose(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, s, hr):
         s, hr = f32c(s), f32c(hr)
-        if hr.shape != s.shape:
+        ctx.hr_shape = None
+        if hr.shape != s.shape:                 # the reference's `src_emb - hr` broadcasts (e.g. hr [1, D])
+            ctx.hr_shape = tuple(hr.shape)
             hr = hr.expand_as(s).contiguous()
         require_hip(s, hr)
         out = torch.empty_like(s)
@@ -66,6 +68,8 @@ class _Compose(torch.autograd.Function):
         rows, D = g.shape
         nb = 4 * D * rows * (1 + (2 if ctx.op == 0 else 1) * (int(need_s) + int(need_hr)))
         call("mrg_compose_bwd", (ctx.op, ptr(g), ptr(s), ptr(hr), ptr(gs), ptr(ghr), rows, D, stream_of(g)), nbytes=nb)
+        if ghr is not None and ctx.hr_shape is not None:
+            ghr = ghr.sum_to_size(ctx.hr_shape)
         return None, gs, ghr
 
 

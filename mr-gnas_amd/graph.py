@@ -27,6 +27,20 @@ import torch
 CHUNK_EDGES = 64     # in-edges reduced by one wave-group before the list is split
 
 
+def cached_on(obj, key, deps, extra, build):
+    """Value derived from the tensors `deps` (and the hashable `extra`), cached on `obj` under attribute
+    `key`.  The cache entry keeps the tensors themselves, so an entry can only be hit by the SAME tensor
+    objects at the same in-place version (``t._version``): a different tensor that happens to reuse a freed
+    address, a reassigned ``g.edata[...]`` entry or an in-place edit all rebuild."""
+    slot = getattr(obj, key, None)
+    if slot is not None and slot[1] == extra and len(slot[0]) == len(deps) and \
+            all(a is b and (b is None or v == b._version) for (a, v), b in zip(slot[0], deps)):
+        return slot[2]
+    val = build()
+    setattr(obj, key, ([(d, None if d is None else d._version) for d in deps], extra, val))
+    return val
+
+
 def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
     """CSR-by-destination + chunk plan for mrg_seg_reduce_fwd (include/mrgnas.h).
 
@@ -212,12 +226,10 @@ class RelGraph:
 
     def i32(self, name):
         """int32 copy of 'src' / 'dst' / an integer edata field, cached."""
-        if name not in self._i32:
-            t = {"src": self._src, "dst": self._dst}.get(name)
-            if t is None:
-                t = self.edata[name]
-            self._i32[name] = t.to(torch.int32).contiguous()
-        return self._i32[name]
+        t = {"src": self._src, "dst": self._dst}.get(name)
+        if t is None:
+            t = self.edata[name]                 # may be reassigned / edited by the caller: tracked by identity + version
+        return cached_on(self, "_i32c_" + name, (t,), None, lambda: t.to(torch.int32).contiguous())
 
     def bounds(self):
         """(b0, b1): rows [0, b0) are original-direction edges, [b0, b1) inverse edges.

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import functional as K
 from . import operations_lp as OPS
+from .graph import cached_on
 
 Genotype = collections.namedtuple('Genotype', 'alpha_cell concat_node score_func')   # reference configs/genotypes.py:3
 
@@ -97,8 +98,13 @@ class MixedOp(nn.Module):
             if isinstance(op, OPS.f_zero_op):
                 ys.append(None)
                 continue
-            with torch.cuda.stream(fork.stream(k)):
-                y = op(g, fh.take(), fi.take())
+            side = fork.stream(k)
+            a, b = fh.take(), fi.take()
+            if side is not fork.main:                  # h / h_in live in main-stream blocks and are read (forward and,
+                a.record_stream(side)                  # through the saved tensors, backward) on the side stream: the
+                b.record_stream(side)                  # allocator must not recycle them before that stream is done
+            with torch.cuda.stream(side):
+                y = op(g, a, b)
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
@@ -177,7 +183,6 @@ class SearchNetwork(nn.Module):
         self._arch_parameters = [mk(zero_nodes, len(OPS.PRE_OPS)), mk(self.n_first_edges, len(OPS.FIRST_OPS)),
                                  mk(first_nodes, len(OPS.MIDDLE_OPS)), mk(self.n_last_edges, len(OPS.LAST_OPS)),
                                  (1e-3 * torch.randn(1, len(OPS.SF_OPS), device=device)).requires_grad_(True)]
-        self._gather_cache = {}
 
     def arch_parameters(self):
         return self._arch_parameters
@@ -191,19 +196,21 @@ class SearchNetwork(nn.Module):
         sl = lambda t, n: F.softmax(t[l * n:(l + 1) * n], dim=1)
         return sl(a[0], self.nz), sl(a[1], self.n_first_edges), sl(a[2], self.nf), sl(a[3], self.n_last_edges)
 
-    def _plans(self, g, node_id, src_in, edge_type):
-        """Gather indices of a step graph (computed once per graph object, cached on it)."""
-        key = "_mrg_search_plans"
-        if getattr(g, key, None) is None:
+    def prepare(self, g, node_id, src_in, edge_type):
+        """Gather indices of a step graph: (ent plan, rel plan, layer>=2 plan).  Cached on the graph object
+        for as long as the SAME index tensors are passed unmodified (identity + in-place version); anything
+        else rebuilds, so a reused graph object with new node_id / src_in / edge_type never sees stale plans."""
+        def build():
             n = g.number_of_nodes()
             dev = src_in.device
             src_in_f = torch.cat((src_in.long(), torch.arange(n, device=dev)))
             ent_idx = node_id.view(-1).long()[src_in_f]
             rel_idx = torch.cat((edge_type.long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
             # layer >= 2 reads cat(ent[src_in], ent): one gather with the index cat(src_in, arange(n)), no torch.cat
-            setattr(g, key, (K.GatherPlan(ent_idx, self._num_ent), K.GatherPlan(rel_idx, self._num_rel),
-                             K.GatherPlan(src_in_f, n)))
-        return getattr(g, key)
+            return (K.GatherPlan(ent_idx, self._num_ent), K.GatherPlan(rel_idx, self._num_rel), K.GatherPlan(src_in_f, n))
+        return cached_on(g, "_mrg_search_plans", (node_id, src_in, edge_type), (self._num_ent, self._num_rel, g.number_of_nodes()), build)
+
+    _plans = prepare
 
     def forward(self, g_train, node_id, src_in, edge_type):
         ent_all = self.linear_e(self.embedding_h.weight)
@@ -221,21 +228,27 @@ class SearchNetwork(nn.Module):
         return ent, rel
 
     def _score_plan(self, ent, rel, triplets):
-        """Index plan of a scoring batch, cached per triplet tensor (bench / search drivers reuse the batch)."""
-        key = (triplets.data_ptr(), tuple(triplets.shape), triplets._version, ent.shape[0], rel.shape[0])
-        if self._gather_cache.get("key") != key:
-            self._gather_cache = {"key": key, "plan": K.ScorePlan(triplets, ent.shape[0], rel.shape[0])}
-        return self._gather_cache["plan"]
+        """Index plan of a scoring batch.  Reused only for the SAME triplets tensor object at the same in-place
+        version (the cache holds the tensor, so its address cannot be recycled under it); a new batch -- the
+        reference driver builds one per epoch, search/mr_lp_search.py:187-255 -- always gets a new plan."""
+        return cached_on(self, "_score_cache", (triplets,), (ent.shape[0], rel.shape[0]),
+                         lambda: K.ScorePlan(triplets, ent.shape[0], rel.shape[0]))
 
-    def calc_score(self, ent, rel, triplets):
+    def calc_score(self, ent, rel, triplets, plan=None):
         """DistMult (reference models/model_search_lp.py:169-176) in one fused HIP kernel: no [T, D]
-        gathers are materialised; the backward is three balanced segmented-sum launches."""
+        gathers are materialised; the backward is three balanced segmented-sum launches.  `plan`: an explicit
+        functional.ScorePlan of `triplets` (callers that keep a batch across steps may build it once)."""
         if not ent.is_cuda:
             t = triplets.long()
             return torch.sum(ent[t[:, 0]] * rel[t[:, 1]] * ent[t[:, 2]], dim=1)
-        return K.distmult_score(ent, rel, self._score_plan(ent, rel, triplets))
+        return K.distmult_score(ent, rel, plan if plan is not None else self._score_plan(ent, rel, triplets))
 
     def get_loss(self, g_train, ent, rel, triplets, labels):
+        return F.binary_cross_entropy_with_logits(self.calc_score(ent, rel, triplets), labels)
+
+    def _loss(self, g_train, node_id, src_in, edge_type, triplets, labels):
+        """What the reference's Architect calls (models/model_search_lp.py:190-194, models/architect_lp.py:50)."""
+        ent, rel = self.forward(g_train, node_id, src_in, edge_type)
         return F.binary_cross_entropy_with_logits(self.calc_score(ent, rel, triplets), labels)
 
     def show_genotype(self, l):
@@ -334,14 +347,15 @@ class FixedNetwork(nn.Module):
         self.w_rel = _xavier_param(feature_dim, feature_dim)
 
     def _plans(self, g):
-        key = "_mrg_fixed_plans"
-        if getattr(g, key, None) is None:
-            src, _, _ = g.edges(form='all')
+        src, _, _ = g.edges(form='all')
+        etype = g.edata['e_type']
+
+        def build():
             n, dev = g.number_of_nodes(), src.device
             ent_idx = torch.cat((src, torch.arange(n, device=dev)))
-            rel_idx = torch.cat((g.edata['e_type'].long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
-            setattr(g, key, (K.GatherPlan(ent_idx, n), K.GatherPlan(rel_idx, self._num_rel)))
-        return getattr(g, key)
+            rel_idx = torch.cat((etype.long(), torch.full((n,), self._num_rel - 1, dtype=torch.long, device=dev)))
+            return (K.GatherPlan(ent_idx, n), K.GatherPlan(rel_idx, self._num_rel))
+        return cached_on(g, "_mrg_fixed_plans", (src, etype), (self._num_rel, g.number_of_nodes()), build)
 
     def forward(self, g, subj, rel):
         ent = self.linear_e(self.embedding_h.weight)

@@ -48,7 +48,7 @@ def comp_graph_conv(g, P, n_in, r_in, in_mask, comp_fn="sub", batchnorm=True, dr
     comp = compose(comp_fn, n_in[g.src], e_feat, corr)                         # :62-69
     in_idx = torch.nonzero(in_mask, as_tuple=False).squeeze(-1)                # :74
     out_idx = torch.nonzero(~in_mask, as_tuple=False).squeeze(-1)              # :75
-    new = torch.zeros(comp.shape[0], p("W_O.weight").shape[0])
+    new = torch.zeros(comp.shape[0], p("W_O.weight").shape[0], dtype=comp.dtype, device=comp.device)
     new = new.index_put((out_idx,), F.linear(comp[out_idx], p("W_O.weight"), p("W_O.bias")))   # :77,81
     new = new.index_put((in_idx,), F.linear(comp[in_idx], p("W_I.weight"), p("W_I.bias")))     # :78,82
     comp_edge = seg_sum(new, g.dst, g.n)                                        # :87

@@ -21,6 +21,15 @@ class OGraph:
         self.etype = torch.as_tensor(etype, dtype=torch.long)
         self.norm = torch.as_tensor(norm, dtype=torch.float32)
 
+    def to(self, device=None, dtype=None):
+        """Copy on another device / with the norm in another float type: the GPU tests run this same
+        restatement in float64 on the device as the full-size checker (tests only)."""
+        g = OGraph.__new__(OGraph)
+        g.n = self.n
+        g.src, g.dst, g.etype = (t.to(device) for t in (self.src, self.dst, self.etype))
+        g.norm = self.norm.to(device=device, dtype=dtype or self.norm.dtype)
+        return g
+
     @property
     def E(self):
         return int(self.src.numel())
@@ -74,10 +83,10 @@ class _SegMax(torch.autograd.Function):
     def forward(ctx, m, dst, n):
         E, D = m.shape
         idx = dst.view(-1, 1).expand(E, D)
-        h = torch.zeros(n, D, dtype=m.dtype).scatter_reduce(0, idx, m, reduce="amax", include_self=False)
-        eid = torch.arange(E).view(-1, 1).expand(E, D)
+        h = torch.zeros(n, D, dtype=m.dtype, device=m.device).scatter_reduce(0, idx, m, reduce="amax", include_self=False)
+        eid = torch.arange(E, device=m.device).view(-1, 1).expand(E, D)
         cand = torch.where(m == h[dst], eid, torch.full_like(eid, E))
-        arg = torch.full((n, D), E, dtype=torch.long).scatter_reduce(0, idx, cand, reduce="amin", include_self=True)
+        arg = torch.full((n, D), E, dtype=torch.long, device=m.device).scatter_reduce(0, idx, cand, reduce="amin", include_self=True)
         ctx.save_for_backward(arg)
         ctx.E = E
         ctx.mark_non_differentiable(arg)
@@ -86,7 +95,7 @@ class _SegMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _):
         (arg,) = ctx.saved_tensors
-        gm = torch.zeros(ctx.E + 1, arg.shape[1], dtype=g.dtype)
+        gm = torch.zeros(ctx.E + 1, arg.shape[1], dtype=g.dtype, device=g.device)
         gm.scatter_(0, arg, g)
         return gm[: ctx.E], None, None
 
@@ -99,7 +108,7 @@ def seg_max(m, dst, n, return_arg=False):
 
 
 def seg_sum(m, dst, n):
-    return torch.zeros(n, m.shape[1], dtype=m.dtype).index_add(0, dst, m)
+    return torch.zeros(n, m.shape[1], dtype=m.dtype, device=m.device).index_add(0, dst, m)
 
 
 def seg_mean(m, dst, n):

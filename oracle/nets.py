@@ -59,8 +59,9 @@ def fixed_cell(g, S, prefix, genotype, x, hr):
 def fixed_net_forward(g, S, genotypes, subj, rel, num_rel_rows, gamma=40.0):
     """Reference models/model_lp.py:123-137. Returns the score matrix [B, N]."""
     ent, rel_emb = _embed_tables(S)
-    src_f = torch.cat((g.src, torch.arange(g.n)))
-    et_f = torch.cat((g.etype, torch.full((g.n,), num_rel_rows - 1, dtype=torch.long)))
+    dev = g.src.device
+    src_f = torch.cat((g.src, torch.arange(g.n, device=dev)))
+    et_f = torch.cat((g.etype, torch.full((g.n,), num_rel_rows - 1, dtype=torch.long, device=dev)))
     for i, geno in enumerate(genotypes):
         ent = fixed_cell(g, S, f"cells.{i}.", geno, ent[src_f], rel_emb[et_f])
         rel_emb = torch.matmul(rel_emb, S["w_rel"])
@@ -75,7 +76,8 @@ def mixed_op(g, S, prefix, names, w, a, b):
     out = 0
     for k, name in enumerate(names):
         h = O.OPS[name](g, _sub(S, f"{prefix}_ops.{k}.0."), a, b)
-        out = out + w[k] * F.relu(_bn(S, f"{prefix}_ops.{k}.1.", h.float()))
+        h = h if h.dtype == torch.float64 else h.float()      # reference: `.float()`; kept float64 when the tests run the checker in float64
+        out = out + w[k] * F.relu(_bn(S, f"{prefix}_ops.{k}.1.", h))
     return out
 
 
@@ -105,9 +107,10 @@ def supernet_forward(g, S, alphas, node_id, src_in, edge_type, num_rel_rows, lay
     """Reference models/model_search_lp.py:131-163 (+ show_weights :196-213)."""
     ent_all, rel_emb = _embed_tables(S)
     n = g.n
-    src_in_f = torch.cat((src_in, torch.arange(n)))
+    dev = src_in.device
+    src_in_f = torch.cat((src_in, torch.arange(n, device=dev)))
     src_id_f = node_id.view(-1)[src_in_f]
-    et_f = torch.cat((edge_type, torch.full((n,), num_rel_rows - 1, dtype=torch.long)))
+    et_f = torch.cat((edge_type, torch.full((n,), num_rel_rows - 1, dtype=torch.long, device=dev)))
     nfe = sum(nzero + i for i in range(nfirst))
     nle = sum(nfirst + i for i in range(nlast))
     ent = None

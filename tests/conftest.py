@@ -30,6 +30,80 @@ def load_golden(name):
     return out
 
 
+def seeded(name, shape, seed, std=1.0, mean=0.0):
+    """float32 tensor from a numpy PCG64 stream keyed by (seed, name): the fixture generator
+    (tests/golden/make_golden.py) and the tests rebuild identical large inputs / parameters instead of
+    storing them, so big-shape reference fixtures stay small."""
+    import zlib
+    rng = np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+    return torch.from_numpy((rng.standard_normal(tuple(shape)) * std + mean).astype(np.float32))
+
+
+def seeded_param(name, shape, seed):
+    """Seeded value of a network parameter: xavier-normal matrices (what the reference drivers apply,
+    utils/utils.py:121-125), N(0,1) embeddings, BatchNorm gains around 1 and biases around 0 (non-zero so that
+    they are exercised)."""
+    if len(shape) >= 2:
+        std = 1.0 if name.startswith("embedding_") else (2.0 / (shape[0] + shape[1])) ** 0.5
+        return seeded(name, shape, seed, std)
+    if name.endswith(".weight"):
+        return seeded(name, shape, seed, 0.1, 1.0)
+    return seeded(name, shape, seed, 0.05)
+
+
+def grad_sample_index(name, numel, seed, k=4096):
+    import zlib
+    rng = np.random.default_rng([int(seed), zlib.crc32(name.encode()), 1])
+    return torch.from_numpy(np.sort(rng.choice(numel, size=min(k, numel), replace=False)))
+
+
+def ops_inputs(z):
+    """(x, x_in, hr, xn, gM, gN) of an ops_* fixture: stored, or rebuilt from the fixture's seed."""
+    if "x" in z:
+        return z["x"], z["x_in"], z["hr"], z["xn"], z["gM"], z["gN"]
+    M, N, D, seed = z["src"].numel() + z["N"], z["N"], z["D"], z["input_seed"]
+    mk = lambda nm, rows: seeded(nm, (rows, D), seed)
+    return mk("x", M), mk("x_in", M), mk("hr", M), mk("xn", N), mk("gM", M), mk("gN", N)
+
+
+def net_params(z):
+    """{state_dict key: tensor} of a network fixture: stored, or rebuilt from the fixture's seed."""
+    if "param_seed" in z:
+        return {k: seeded_param(k, tuple(int(i) for i in shp), z["param_seed"]) for k, shp in sub(z, "pshape/").items()}
+    return sub(z, "param/")
+
+
+def net_grad_names(z):
+    return sorted(set(sub(z, "gparam/")) | set(sub(z, "gsample/")))
+
+
+def assert_param_grad(z, name, got, rtol, atol, what=""):
+    """Gradient of parameter `name` against the fixture: the full tensor, or (big parameters of seeded
+    fixtures) a seeded element sample plus the sum and the sum of squares over ALL elements."""
+    got = (got if got is not None else torch.zeros(1)).detach().cpu()
+    if "gparam/" + name in z:
+        ref = z["gparam/" + name]
+        if got.numel() == 1 and ref.numel() != 1:
+            got = torch.zeros_like(ref)
+        scale = max(float(ref.abs().max()), 1e-6)
+        err = float((got - ref).abs().max())
+        assert err <= rtol * scale + atol, f"{what} grad {name}: err {err:.3e} scale {scale:.3e}"
+        return
+    ref = z["gsample/" + name]
+    idx = grad_sample_index(name, got.numel(), z["param_seed"])
+    scale = max(float(ref.abs().max()), 1e-6)
+    diff = got.reshape(-1)[idx] - ref
+    err, rms_err, rms = float(diff.abs().max()), float(diff.square().mean().sqrt()), float(ref.square().mean().sqrt())
+    # a 4096-element sample's max understates the tensor's max: bound the rms error by rtol and the worst element by 5x
+    assert rms_err <= rtol * max(rms, 1e-6) + atol, f"{what} grad {name} (sample): rms err {rms_err:.3e} rms {rms:.3e}"
+    assert err <= 5 * rtol * scale + atol, f"{what} grad {name} (sample): err {err:.3e} scale {scale:.3e}"
+    s1, s2 = (float(v) for v in z["gsums/" + name])
+    g64 = got.double()
+    l1 = float(g64.abs().sum())
+    assert abs(float(g64.sum()) - s1) <= rtol * l1 + atol * got.numel(), f"{what} grad {name}: sum {float(g64.sum())} vs {s1}"
+    assert abs(float((g64 ** 2).sum()) - s2) <= 2 * rtol * max(s2, 1e-12) + atol, f"{what} grad {name}: sum of squares"
+
+
 def sub(d, prefix):
     n = len(prefix)
     return {k[n:]: v for k, v in d.items() if k.startswith(prefix)}

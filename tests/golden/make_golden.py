@@ -41,7 +41,9 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("MRG_GOLDEN_OUT", os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conftest import grad_sample_index, seeded, seeded_param  # noqa: E402  (shared with the tests: big inputs are rebuilt, not stored)
 
 
 # --------------------------------------------------------------------------
@@ -283,9 +285,11 @@ def run_op(store, tag, op, g, a, b, gout):
 STAR = {"pre_sub", "pre_mult", "f_sparse_comp", "f_sparse_last", "a_max", "a_sum", "a_mean"}
 
 
-def case_ops(name, N, T, R, D, order, seed, star_only=False):
+def case_ops(name, N, T, R, D, order, seed, star_only=False, seeded_inputs=False, skip=()):
+    """seeded_inputs: the [M, D] inputs / upstream gradients come from conftest.seeded and are NOT stored
+    (the tests rebuild them), so a planned SURVEY 8(c) shape such as (300, 2000, 11, 64) stays a few MB."""
     import models.operations_lp as O
-    keep = (lambda nm: nm in STAR) if star_only else (lambda nm: True)
+    keep = (lambda nm: nm in STAR and nm not in skip) if star_only else (lambda nm: nm not in skip)
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     tri = make_triples(N, T, R, rng)
@@ -295,10 +299,15 @@ def case_ops(name, N, T, R, D, order, seed, star_only=False):
     M = E + N
     st = {"N": N, "R": R, "D": D, "src": src, "dst": dst, "etype": g.edata["e_type"],
           "norm": g.edata["norm"], "triples": tri}
-    x, x_in, hr = torch.randn(M, D), torch.randn(M, D), torch.randn(M, D)
-    xn = torch.randn(N, D)
-    gM, gN = torch.randn(M, D), torch.randn(N, D)
-    st.update(x=x, x_in=x_in, hr=hr, xn=xn, gM=gM, gN=gN)
+    if seeded_inputs:
+        mk = lambda nm, rows: seeded(nm, (rows, D), seed)
+        x, x_in, hr, xn, gM, gN = mk("x", M), mk("x_in", M), mk("hr", M), mk("xn", N), mk("gM", M), mk("gN", N)
+        st["input_seed"] = seed
+    else:
+        x, x_in, hr = torch.randn(M, D), torch.randn(M, D), torch.randn(M, D)
+        xn = torch.randn(N, D)
+        gM, gN = torch.randn(M, D), torch.randn(N, D)
+        st.update(x=x, x_in=x_in, hr=hr, xn=xn, gM=gM, gN=gN)
     args = {"feature_dim": D, "drop_aggr": 0.0}
     for nm in filter(keep, PRE):
         run_op(st, nm, O.MIXED_OPS[nm](args), g, x, hr, gM)
@@ -447,9 +456,12 @@ def case_fixed_net(name, N, T, R, D, D0, nbase, seed):
     print("wrote fixednet_%s loss=%.6f" % (name, float(loss)))
 
 
-def case_supernet(name, Nall, T, R, D, D0, nbase, layers, sample, seed):
+def case_supernet(name, Nall, T, R, D, D0, nbase, layers, sample, seed, seeded_params=False):
     """One search step's forward/backward (reference search/mr_lp_search.py:187-245
-    without the optimiser), on a sub-sampled graph in the search driver's edge order."""
+    without the optimiser), on a sub-sampled graph in the search driver's edge order.
+    seeded_params: parameters come from conftest.seeded_param (rebuilt by the tests, not stored) and the
+    gradients of big parameters are stored as a seeded 4096-element sample + (sum, sum of squares): the
+    D = 200 default-size search step of SURVEY 8(c) then fits in ~1 MB instead of ~50 MB."""
     import models.model_search_lp as MS
     import utils.utils as UU
     import utils.utils_rgcn as ur
@@ -467,6 +479,10 @@ def case_supernet(name, Nall, T, R, D, D0, nbase, layers, sample, seed):
     g.edata["norm"] = g2.edata["norm"]
     net = MS.Network("cpu", Nall, R, layers, 1, 2, 2, D, D0, nbase, 9.0, 0.0, 0.0)
     net.apply(UU.weights_init)
+    if seeded_params:
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                p.copy_(seeded_param(n, tuple(p.shape), seed))
     net.train()
     node_id_t = torch.from_numpy(node_id).view(-1, 1).long()
     src_in_t = torch.from_numpy(src_in)
@@ -480,10 +496,22 @@ def case_supernet(name, Nall, T, R, D, D0, nbase, layers, sample, seed):
           "src": src, "dst": dst, "norm": g.edata["norm"], "node_id": node_id, "src_in": src_in,
           "edge_type": edge_type, "data": data, "labels": labels, "ent": ent, "rel_out": relo, "loss": loss}
     for n, p in net.named_parameters():
-        st[f"param/{n}"] = p
-        st[f"gparam/{n}"] = p.grad if p.grad is not None else torch.zeros_like(p)
-    for n, b in net.named_buffers():
-        st[f"buffer/{n}"] = b
+        gp = p.grad if p.grad is not None else torch.zeros_like(p)
+        if seeded_params:
+            st[f"pshape/{n}"] = np.asarray(p.shape, dtype=np.int64)
+            if p.numel() > 8192:
+                st[f"gsample/{n}"] = gp.reshape(-1)[grad_sample_index(n, p.numel(), seed)]
+                st[f"gsums/{n}"] = np.asarray([float(gp.double().sum()), float((gp.double() ** 2).sum())])
+            else:
+                st[f"gparam/{n}"] = gp
+        else:
+            st[f"param/{n}"] = p
+            st[f"gparam/{n}"] = gp
+    if seeded_params:
+        st["param_seed"] = seed
+    else:
+        for n, b in net.named_buffers():
+            st[f"buffer/{n}"] = b
     for i, a in enumerate(net.arch_parameters()):
         st[f"alpha/{i}"] = a
         st[f"galpha/{i}"] = a.grad if a.grad is not None else torch.zeros_like(a)
@@ -521,6 +549,9 @@ def main():
     case_supernet("tiny", 80, 400, 5, 8, 6, 11, 2, 60, 31)
     case_supernet("d24", 150, 900, 9, 24, 12, 19, 2, 120, 32)
     case_graph_build("small", 64, 300, 6, 41)
+    # the two shapes SURVEY 8(c) planned and round 1 skipped (inputs / parameters rebuilt from seeds, not stored)
+    case_ops("r300_d64_search", 300, 2000, 11, 64, "search", 6, star_only=True, seeded_inputs=True, skip=("pre_mult", "pre_sub"))
+    case_supernet("d200_sampled", 14541, 60000, 237, 200, 100, 475, 2, 300, 33, seeded_params=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,389 @@
+"""Parity at the sizes of the BASELINE.json configs that round 1 left unexercised on the GPU:
+
+  C1  FB15k-237 shape, fixed README genotype (reference README.md:26, models/model_lp.py:123-137), D = 64
+      -- the LPR = 16 / four-rows-per-wave kernel path at M = 558 771 rows;
+  C2  FB15k-237 shape, 2-layer mixed-op supernet, D = 200 (the bench workload), whole step;
+  C3  WN18RR shape (N = 40 943, R = 11: two relations hold ~3/4 of the edges, reference
+      search/mr_lp_search.py:69), supernet, D = 200 -- the skew / hub case;
+  C4  the relation-block sharded step (mr-gnas_amd/dist.py) at FB15k-237 size through an RCCL group of one,
+      against the plain step;
+  C5  10 M edges / 1 M nodes / 512 relation ids, D = 256 (2.8e9 elements per [M, D] tensor: row offsets
+      beyond 2^31), kernel level.
+
+The checker for the whole-network cases is the oracle restatement (oracle/nets.py, pinned against the
+reference by tests/test_oracle_golden.py) executed in FLOAT64 ON THE DEVICE with plain torch ops -- at these
+sizes the CPU needs minutes and 64-128 GB per step; the 288 GB of HBM hold the float64 run next to the HIP
+path.  Tolerances: 1e-4 relative on outputs and loss (BASELINE.json north_star), 2e-3 of the largest
+gradient entry on gradients (the bound the reference-golden tests use), bit-exact for index / max work.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mr_gnas_amd
+from mr_gnas_amd import functional as K, graph as G, operations_lp as O, supernet as S, synth
+from oracle import nets as ON
+from oracle.graph import OGraph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+README_GENOTYPE = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2),
+                                          ('a_max', 5, 3), ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)],
+                              concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+
+
+def rel_err(got, ref):
+    ref = ref.double()
+    return float((got.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+
+
+def grad_err(got, ref):
+    ref = ref.double()
+    return float((got.double() - ref).abs().max()), float(ref.abs().max())
+
+
+def free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def step_inputs(ds, negative, seed=0):
+    N, R, T = synth.SHAPES[ds]
+    tri = synth.synth_kg(N, R, T, seed)
+    samples, labels = synth.negative_sampling(tri, N, negative, np.random.default_rng(seed + 1))
+    return N, R, tri, samples, labels
+
+
+def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels):
+    """The oracle restatement of one supernet step in float64 on the device; returns ent, rel, loss and
+    {name: grad}, [alpha grads]."""
+    src, dst, _ = g.edges(form="all")
+    og = OGraph(g.number_of_nodes(), src.cpu(), dst.cpu(), edge_type.cpu(), g.edata["norm"].cpu()).to(DEV, torch.float64)
+    P = {k: v.detach().double().requires_grad_(True) for k, v in model.named_parameters()}
+    al = [a.detach().double().requires_grad_(True) for a in model.arch_parameters()]
+    ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
+    loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
+    loss.backward()
+    out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
+               ga=[a.grad for a in al[:4]])
+    del og, P, al, ent, rel, loss
+    free()
+    return out
+
+
+def supernet_case(ds, D, negative):
+    """HIP supernet step (dropout off) + the float64 oracle step on the same inputs."""
+    N, R, tri, samples, labels = step_inputs(ds, negative)
+    g = G.build_search_graph(N, R, tri).to(DEV)
+    src, _, _ = g.edges(form="all")
+    node_id = torch.arange(N, device=DEV).view(-1, 1)
+    edge_type = g.edata["e_type"]
+    samples_t, labels_t = torch.from_numpy(samples).to(DEV), torch.from_numpy(labels).to(DEV)
+    torch.manual_seed(0)
+    model = S.SearchNetwork(DEV, N, R, 2, 1, 2, 2, D, 100, 2 * R + 1, 40.0, 0.0, 0.0).to(DEV)
+    S.xavier_init_(model)
+    with torch.no_grad():                                      # biases / BN affine away from their trivial values
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    model.train()
+    ent, rel = model(g, node_id, src, edge_type)
+    loss = model.get_loss(g, ent, rel, samples_t, labels_t)
+    loss.backward()
+    torch.cuda.synchronize()
+    hip = dict(ent=ent.detach().clone(), rel=rel.detach().clone(), loss=float(loss),
+               g={k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()},
+               ga=[a.grad.clone() for a in model.arch_parameters()[:4]])
+    del ent, rel, loss
+    model.zero_grad(set_to_none=True)
+    for a in model.arch_parameters():
+        a.grad = None
+    free()
+    ref = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t)
+    return dict(model=model, g=g, node_id=node_id, src=src, edge_type=edge_type, R=R, N=N, samples=samples_t, labels=labels_t,
+                samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref)
+
+
+def check_step(hip, ref, what):
+    assert np.isfinite(hip["loss"])
+    assert rel_err(hip["ent"], ref["ent"]) <= 1e-4, f"{what}: ent {rel_err(hip['ent'], ref['ent']):.3e}"
+    assert rel_err(hip["rel"], ref["rel"]) <= 1e-4, f"{what}: rel"
+    assert abs(hip["loss"] - ref["loss"]) <= 1e-4 * max(1.0, abs(ref["loss"])), f"{what}: loss {hip['loss']} vs {ref['loss']}"
+    for i, (a, b) in enumerate(zip(hip["ga"], ref["ga"])):
+        err, scale = grad_err(a, b)
+        assert err <= 2e-3 * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i}: {err:.3e} (scale {scale:.3e})"
+    worst = (0.0, None)
+    for k, b in ref["g"].items():
+        err, scale = grad_err(hip["g"][k], b)
+        assert err <= 2e-3 * max(scale, 1e-6) + 5e-6, f"{what}: grad {k}: {err:.3e} (scale {scale:.3e})"
+        worst = max(worst, (err / max(scale, 1e-6), k))
+    return worst
+
+
+# ---------------------------------------------------------------------------
+# C2 / C4: FB15k-237 supernet, D = 200, plain and sharded
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fb_case():
+    case = supernet_case("fb15k237", 200, negative=1)
+    yield case
+    case.clear()
+    free()
+
+
+def test_c2_fb15k237_supernet_step_matches_float64_oracle(fb_case):
+    check_step(fb_case["hip"], fb_case["ref"], "C2 FB15k-237 supernet D=200")
+
+
+def test_c4_sharded_step_world1_rccl_full_size(fb_case):
+    """mr-gnas_amd/dist.py at FB15k-237 size: relation-block shard (world = 1: the whole graph, re-ordered by
+    (relation, dst)), collectives through RCCL, SyncBN epilogues, flat gradient all-reduce -- against the plain
+    step and the float64 oracle."""
+    import torch.distributed as dist
+    from mr_gnas_amd import dist as MD
+    c = fb_case
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        model, g = c["model"], c["g"]
+        src, dst, _ = g.edges(form="all")
+        shard = MD.EdgeShard(c["N"], src, dst, c["edge_type"], g.edata["norm"], c["R"], 0, 1, DEV)
+        sn = MD.ShardedSupernet(model, shard, c["node_id"])
+        ent, rel = sn.forward()
+        loss = sn.loss(ent, rel, c["samples"], c["labels"], len(c["samples"]))
+        loss.backward()
+        MD.all_reduce_gradients(list(model.parameters()) + model.arch_parameters()[:4])
+        torch.cuda.synchronize()
+        got = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss),
+                   g={k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()},
+                   ga=[a.grad for a in model.arch_parameters()[:4]])
+        assert abs(got["loss"] - c["hip"]["loss"]) <= 1e-4 * max(1.0, abs(c["hip"]["loss"]))      # same loss as the plain step
+        assert rel_err(got["ent"], c["hip"]["ent"]) <= 1e-4
+        check_step(got, c["ref"], "C4 sharded world=1")
+    finally:
+        model.zero_grad(set_to_none=True)
+        for a in model.arch_parameters():
+            a.grad = None
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------
+# C3: WN18RR supernet, D = 200
+# ---------------------------------------------------------------------------
+def test_c3_wn18rr_supernet_step_matches_float64_oracle():
+    c = supernet_case("wn18rr", 200, negative=2)
+    try:
+        deg = torch.bincount(c["g"].edges()[1], minlength=c["N"])
+        assert int(deg.max()) > 2000                          # the hub rows the chunk / span plans must split
+        rel_hist = torch.bincount(c["edge_type"])
+        assert float(rel_hist.sort(descending=True).values[:4].sum()) / c["g"].num_edges() > 0.6   # skewed relations
+        check_step(c["hip"], c["ref"], "C3 WN18RR supernet D=200")
+    finally:
+        c.clear()
+        free()
+
+
+# ---------------------------------------------------------------------------
+# C1: FB15k-237, fixed README genotype, D = 64
+# ---------------------------------------------------------------------------
+def test_c1_fb15k237_fixed_genotype_d64_matches_float64_oracle():
+    N, R, T = synth.SHAPES["fb15k237"]
+    D, D0, nbase, B = 64, 64, 23, 256
+    tri = synth.synth_kg(N, R, T, 0)
+    g = G.build_train_graph(N, R, tri).to(DEV)                 # the train driver's un-sorted halves, norm [E]
+    rng = np.random.default_rng(5)
+    subj = torch.from_numpy(rng.integers(0, N, B)).to(DEV)
+    rel = torch.from_numpy(rng.integers(0, 2 * R, B)).to(DEV)
+    label = (torch.rand(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) < 0.01).float()
+    torch.manual_seed(1)
+    net = S.FixedNetwork(DEV, README_GENOTYPE, N, R, D, D0, nbase).to(DEV)
+    S.xavier_init_(net)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    net.train()
+    pred = net(g, subj, rel)
+    loss = F.binary_cross_entropy(pred, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert pred.shape == (B, N) and np.isfinite(float(loss))
+    # float64 oracle on the device
+    src, dst, _ = g.edges(form="all")
+    og = OGraph(N, src.cpu(), dst.cpu(), g.edata["e_type"].cpu(), g.edata["norm"].cpu()).to(DEV, torch.float64)
+    P = {k: v.detach().double().requires_grad_(True) for k, v in net.named_parameters()}
+    pred64 = ON.fixed_net_forward(og, P, README_GENOTYPE, subj, rel, 2 * R + 1, gamma=40.0)
+    loss64 = F.binary_cross_entropy(pred64, label.double())
+    loss64.backward()
+    assert float((pred.double() - pred64).abs().max()) <= 1e-4          # probabilities in [0, 1]
+    assert abs(float(loss) - float(loss64)) <= 1e-4 * max(1.0, float(loss64))
+    for k, p in net.named_parameters():
+        ref = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        err, scale = grad_err(p.grad if p.grad is not None else torch.zeros_like(p), ref)
+        assert err <= 2e-3 * max(scale, 1e-6) + 5e-6, f"C1 grad {k}: {err:.3e} (scale {scale:.3e})"
+    # per-operator float64 samples on the LPR = 16 path (D = 64 packs four rows per wave)
+    E, M = g.num_edges(), g.num_edges() + N
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x, x_in = torch.randn(M, D, device=DEV, generator=gen), torch.randn(M, D, device=DEV, generator=gen)
+    for name in ("f_sparse_comp", "a_max", "a_sum", "a_mean"):
+        op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+        from oracle import ops as OO
+        Pp = {k: v.detach().double() for k, v in op.state_dict().items()}
+        with torch.no_grad():
+            got = op(g, x, x_in)
+            ref = OO.OPS[name](og, Pp, x.double(), x_in.double())
+        assert rel_err(got, ref) <= 1e-4, f"C1 {name}: {rel_err(got, ref):.3e}"
+    del og, P
+    free()
+
+
+# ---------------------------------------------------------------------------
+# C5: 10 M edges / 1 M nodes / D = 256, kernel level
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c5():
+    N, R, T = synth.SHAPES["synthetic10m"]
+    tri = synth.synth_kg(N, R, T, 0)
+    g = G.build_search_graph(N, R, tri).to(DEV)
+    assert g.num_edges() == 10_000_000
+    yield dict(g=g, N=N, R=R, E=g.num_edges(), gen=torch.Generator(device=DEV).manual_seed(11))
+    free()
+
+
+def _segment_sample(seg, nseg, gen, k=4096):
+    """Segments to check: a random sample plus the 64 longest (the hub segments the span plan splits)."""
+    cnt = torch.bincount(seg, minlength=nseg)
+    pick = torch.unique(torch.cat((torch.randint(0, nseg, (k,), device=DEV, generator=gen), cnt.topk(64).indices)))
+    lut = torch.full((nseg,), -1, dtype=torch.long, device=DEV)
+    lut[pick] = torch.arange(pick.numel(), device=DEV)
+    elems = torch.nonzero(lut[seg] >= 0).view(-1)
+    return pick, lut, elems
+
+
+@pytest.mark.parametrize("kind", ["sub", "mul"])
+def test_c5_fused_gather_compose_scatter(c5, kind):
+    """mrg_span_gcs (the north-star kernel) at C5: out[(dst, dir)] = sum phi(ent[src], rel[etype] * norm) against
+    float64 on a segment sample that includes the longest segments; 1 GB node table, 1 M x 2 segments."""
+    D = 256
+    g, N, E, gen = c5["g"], c5["N"], c5["E"], c5["gen"]
+    src, dst, _ = g.edges(form="all")
+    et = g.edata["e_type"]
+    Rp = 2 * c5["R"] + 1
+    b0, _ = g.bounds()
+    seg = dst * 2 + (torch.arange(E, device=DEV) >= b0).long()
+    norm = g.norm_flat()
+    cp = K.ComposePlan(src, et, seg, norm, N, Rp, 2 * N)
+    ent = torch.randn(N, D, device=DEV, generator=gen)
+    rel = torch.randn(Rp, D, device=DEV, generator=gen)
+    out = K.span_gcs(kind, ent, rel, cp.m_fwd, cp.sp_seg)
+    assert out.shape == (2 * N, D)
+    pick, lut, elems = _segment_sample(seg, 2 * N, gen)
+    x = ent[src[elems]].double()
+    y = rel[et[elems]].double() * norm[elems].double().view(-1, 1)
+    msg = x - y if kind == "sub" else x * y
+    ref = torch.zeros(pick.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, lut[seg[elems]], msg)
+    err = float((out[pick].double() - ref).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"C5 span_gcs {kind}: {err:.3e}"
+    # segments without elements are written as zeros by the hub pass (no separate zero-fill)
+    empty = torch.nonzero(torch.bincount(seg, minlength=2 * N) == 0).view(-1)[:4096]
+    assert float(out[empty].abs().max() if empty.numel() else 0.0) == 0.0
+    del cp, out
+    free()
+
+
+def test_c5_segmented_max_and_gather_bit_exact(c5):
+    """mrg_seg_reduce_fwd (max + arg-max) over 10 M x 256 messages (2.56e9 elements: offsets beyond 2^31) bit-exact
+    against scatter_reduce(amax); the [E+N, 256] gather bit-exact against torch indexing."""
+    D = 256
+    g, N, E, gen = c5["g"], c5["N"], c5["E"], c5["gen"]
+    src, dst, _ = g.edges(form="all")
+    msg = torch.randn(E, D, device=DEV, generator=gen).relu_()
+    out = K.seg_reduce("max", msg, None, g)
+    cols = slice(0, 64)                                          # the reference formulation on a column block keeps the index expand small
+    ref = torch.zeros(N, 64, device=DEV).scatter_reduce(0, dst.view(-1, 1).expand(E, 64), msg[:, cols], "amax", include_self=False)
+    assert torch.equal(out[:, cols], ref)
+    ref = torch.zeros(N, 64, device=DEV).scatter_reduce(0, dst.view(-1, 1).expand(E, 64), msg[:, 192:], "amax", include_self=False)
+    assert torch.equal(out[:, 192:], ref)
+    del msg, out, ref
+    free()
+    ent = torch.randn(N, D, device=DEV, generator=gen)
+    idx = torch.cat((src, torch.arange(N, device=DEV)))
+    got = K.gather(ent, K.GatherPlan(idx, N))
+    assert got.shape == (E + N, D)
+    for lo in range(0, E + N, 1 << 21):                          # compare in blocks: no second 11 GB tensor
+        assert torch.equal(got[lo:lo + (1 << 21)], ent[idx[lo:lo + (1 << 21)]])
+    del got
+    free()
+
+
+def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
+    """The MixedOp epilogue, the K-way gradient sum and a dense filter at M = 11 M rows, D = 256 against float64 on
+    a row sample (first / last rows and random ones)."""
+    M, D = c5["E"] + c5["N"], 256
+    gen = c5["gen"]
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    rows = torch.cat((torch.arange(0, 2048, device=DEV), torch.arange(M - 2048, M, device=DEV),
+                      torch.randint(0, M, (2048,), device=DEV, generator=gen)))
+    xs = [rnd(M, D) for _ in range(3)]
+    tot = K.sum_buffers(xs)
+    ref = sum(x[rows].double() for x in xs)
+    assert float((tot[rows].double() - ref).abs().max()) <= 1e-5
+    del tot
+    bns = [torch.nn.BatchNorm1d(D).to(DEV) for _ in range(3)]
+    w = torch.softmax(rnd(3), 0).requires_grad_(True)
+    ys = [x.requires_grad_(True) for x in xs]
+    out = K.mixed_epilogue(ys, bns, w, None, None)
+    refo = 0
+    for k in range(3):
+        y64 = ys[k].detach()
+        mean = torch.stack([y64[lo:lo + (1 << 21)].double().sum(0) for lo in range(0, M, 1 << 21)]).sum(0) / M
+        var = torch.stack([((y64[lo:lo + (1 << 21)].double() - mean) ** 2).sum(0) for lo in range(0, M, 1 << 21)]).sum(0) / M
+        z = (y64[rows].double() - mean) / torch.sqrt(var + bns[k].eps) * bns[k].weight.double() + bns[k].bias.double()
+        refo = refo + w.detach().double()[k] * torch.relu(z)
+    assert float((out[rows].double() - refo).abs().max()) <= 1e-4
+    gup = rnd(M, D)
+    out.backward(gup)
+    assert all(bool(torch.isfinite(y.grad[rows]).all()) for y in ys) and bool(torch.isfinite(w.grad).all())
+    # dw_k = sum(g * relu(bn_k(y_k))): check one branch against float64 over all rows, in blocks
+    k = 1
+    y64 = ys[k].detach()
+    mean = torch.stack([y64[lo:lo + (1 << 21)].double().sum(0) for lo in range(0, M, 1 << 21)]).sum(0) / M
+    var = torch.stack([((y64[lo:lo + (1 << 21)].double() - mean) ** 2).sum(0) for lo in range(0, M, 1 << 21)]).sum(0) / M
+    dw = dw_abs = 0.0
+    for lo in range(0, M, 1 << 21):
+        z = (y64[lo:lo + (1 << 21)].double() - mean) / torch.sqrt(var + bns[k].eps) * bns[k].weight.double() + bns[k].bias.double()
+        t = gup[lo:lo + (1 << 21)].double() * torch.relu(z)
+        dw += float(t.sum())
+        dw_abs += float(t.abs().sum())
+    assert abs(float(w.grad[k]) - dw) <= 1e-5 * dw_abs                 # a sum of 2.8e9 random-sign terms
+    del out, gup, ys, xs
+    free()
+    s, s_in = rnd(M, D).requires_grad_(True), rnd(M, D).requires_grad_(True)
+    W = (rnd(D, 2 * D) / (2 * D) ** 0.5).requires_grad_(True)
+    b = rnd(D).requires_grad_(True)
+    o = K.dense_filter_single(s, s_in, W, b)
+    cat = torch.cat((s.detach()[rows], s_in.detach()[rows]), 1).double()
+    gate = torch.sigmoid(cat @ W.detach().double().t() + b.detach().double())
+    assert float((o[rows].double() - gate * s.detach()[rows].double()).abs().max()) <= 1e-4
+    go = rnd(M, D)
+    o.backward(go)
+    dz = go[rows].double() * s.detach()[rows].double() * gate * (1 - gate)
+    ref_gs = go[rows].double() * gate + dz @ W.detach().double()[:, :D]
+    ref_gin = dz @ W.detach().double()[:, D:]
+    assert float((s.grad[rows].double() - ref_gs).abs().max()) <= 1e-4 * max(1.0, float(ref_gs.abs().max()))
+    assert float((s_in.grad[rows].double() - ref_gin).abs().max()) <= 1e-4 * max(1.0, float(ref_gin.abs().max()))
+    assert bool(torch.isfinite(W.grad).all()) and bool(torch.isfinite(b.grad).all())
+    # bias gradient = column sums of dz over ALL rows: float64 in blocks
+    gb = torch.zeros(D, dtype=torch.float64, device=DEV)
+    for lo in range(0, M, 1 << 20):
+        sl = slice(lo, lo + (1 << 20))
+        cat = torch.cat((s.detach()[sl], s_in.detach()[sl]), 1).double()
+        gt = torch.sigmoid(cat @ W.detach().double().t() + b.detach().double())
+        gb += (go[sl].double() * s.detach()[sl].double() * gt * (1 - gt)).sum(0)
+    assert float((b.grad.double() - gb).abs().max()) <= 1e-3 * max(1.0, float(gb.abs().max()))

@@ -244,3 +244,63 @@ def test_fan_sums_reader_gradients_and_tolerates_unused_aliases():
         small.take(); small.take(); small.take()
     y = torch.randn(4, 2)                                   # no gradient needed: the tensor itself is handed out
     assert K.Fan(y, 8).take() is y
+
+
+def test_plan_caches_follow_tensor_identity_not_addresses():
+    """Advisor r1 (high / medium): index plans are cached by the identity + in-place version of the tensors they
+    were derived from.  A new same-shape batch that lands on a freed batch's address, a reassigned edata entry or
+    an in-place edit must all rebuild the plan."""
+    from mr_gnas_amd import supernet as S
+
+    built = []
+
+    class Holder:
+        pass
+
+    h = Holder()
+
+    def plan_for(t):
+        return G.cached_on(h, "_c", (t,), (7,), lambda: built.append(t.clone()) or len(built))
+
+    seen_ptrs = set()
+    for i in range(4):                                       # function-scoped batches: the allocator recycles the address
+        batch = torch.full((64, 3), i, dtype=torch.int64)
+        seen_ptrs.add(batch.data_ptr())
+        n = plan_for(batch)
+        assert n == i + 1 and int(built[-1][0, 0]) == i     # never the previous batch's plan
+        assert plan_for(batch) == n                          # same object, same version: hit
+        del batch
+    keep = torch.zeros(8, 3, dtype=torch.int64)
+    n = plan_for(keep)
+    keep[0, 0] = 5                                           # in-place edit bumps _version
+    assert plan_for(keep) == n + 1
+    assert G.cached_on(h, "_c", (keep,), (8,), lambda: "other-extra") == "other-extra"
+
+    # RelGraph.i32 follows a reassigned edata entry
+    g = G.RelGraph(4, [0, 1, 2], [1, 2, 3], etype=[0, 1, 0], norm=[1.0, 1.0, 1.0])
+    assert g.i32("e_type").tolist() == [0, 1, 0]
+    g.edata["e_type"] = torch.tensor([1, 1, 1])
+    assert g.i32("e_type").tolist() == [1, 1, 1]
+
+    # SearchNetwork.prepare: a graph object reused with other index tensors gets new gather plans
+    net = S.SearchNetwork("cpu", 10, 2, 1, 1, 2, 2, 8, 8, 5, 9.0, 0.0, 0.0)
+    nid = torch.arange(4).view(-1, 1)
+    src, _, _ = g.edges(form="all")
+    p1 = net.prepare(g, nid, src, g.edata["e_type"])
+    assert net.prepare(g, nid, src, g.edata["e_type"]) is p1
+    nid2 = torch.tensor([3, 2, 1, 0]).view(-1, 1)
+    p2 = net.prepare(g, nid2, src, g.edata["e_type"])
+    assert p2 is not p1 and p2[0].idx.tolist() != p1[0].idx.tolist()
+    assert hasattr(net, "_loss")                             # what the reference's Architect calls
+
+
+def test_sync_batch_norm_eval_uses_running_statistics():
+    """Advisor r1 (low): dist.sync_batch_norm must behave like nn.BatchNorm1d in eval mode (no batch statistics,
+    no collective)."""
+    from mr_gnas_amd import dist as MD
+    bn = torch.nn.BatchNorm1d(5)
+    bn.running_mean.copy_(torch.randn(5))
+    bn.running_var.copy_(torch.rand(5) + 0.5)
+    bn.eval()
+    x = torch.randn(7, 5)
+    torch.testing.assert_close(MD.sync_batch_norm(x, bn, 7, None), bn(x))

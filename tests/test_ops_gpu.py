@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, sub
+from conftest import load_golden, ops_inputs, sub
 import mr_gnas_amd
 from mr_gnas_amd import functional as K, graph as G, operations_lp as O
 from oracle import ops as OO
@@ -13,7 +13,7 @@ from oracle.graph import OGraph
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-OPS_CASES = ["ops_tiny_train", "ops_small_search", "ops_mid_train", "ops_d100_search", "ops_odd_train"]
+OPS_CASES = ["ops_tiny_train", "ops_small_search", "ops_mid_train", "ops_d100_search", "ops_odd_train", "ops_r300_d64_search"]
 
 
 def close(a, b, what, rtol=1e-4, atol=2e-5):
@@ -41,16 +41,17 @@ def test_ops_against_reference_golden(case):
     z = load_golden(case)
     g = dev_graph(z)
     tags = sorted({k.split("/")[0] for k in z if k.endswith("/out") and not k.startswith("sf_")})
+    x, x_in, hr, xn, gM, gN = ops_inputs(z)
     for tag in tags:
         name = tag.split("@")[0]
         if tag.endswith("@node"):
-            a, b, gout = z["xn"], z["xn"], z["gN"]
+            a, b, gout = xn, xn, gN
         elif name.startswith("a_"):
-            a, b, gout = z["x"], z["x_in"], z["gN"]
+            a, b, gout = x, x_in, gN
         elif name.startswith("pre_"):
-            a, b, gout = z["x"], z["hr"], z["gM"]
+            a, b, gout = x, hr, gM
         else:
-            a, b, gout = z["x"], z["x_in"], z["gM"]
+            a, b, gout = x, x_in, gM
         op = O.MIXED_OPS[name]({"feature_dim": z["D"], "drop_aggr": 0.0}).to(DEV)
         op.load_state_dict(sub(z, tag + "/param/"))          # reference state_dict loads unchanged
         out, ga, gb = run_module(op, g, a, b, gout)
@@ -310,3 +311,22 @@ def test_split_core_weight_gradient(rows, K1, K2, Nout):
     for i, scale in ((0, max(1.0, float(ref_w.abs().max()) if rows else 1.0)), (1, max(1.0, float(ref_b.abs().max()) if rows else 1.0))):
         assert errs[0][i] <= 1.5 * errs[1][i] + 2e-6 * scale, (errs, scale)
         assert errs[0][i] <= 2e-5 * scale
+
+
+def test_compose_broadcast_relation_row():
+    """Advisor r1: the reference's pre-ops broadcast (`src_emb - hr` with hr [1, D]); the gradient of a
+    broadcast hr must come back in hr's own shape."""
+    gen = torch.Generator().manual_seed(3)
+    s = torch.randn(50, 16, generator=gen)
+    hr = torch.randn(1, 16, generator=gen)
+    g_up = torch.randn(50, 16, generator=gen)
+    for kind, f in (("sub", lambda a, b: a - b), ("mult", lambda a, b: a * b), ("add", lambda a, b: a + b)):
+        a, b = s.clone().requires_grad_(True), hr.clone().requires_grad_(True)
+        f(a, b).backward(g_up)
+        ad, bd = s.to(DEV).requires_grad_(True), hr.to(DEV).requires_grad_(True)
+        out = K.compose(kind, ad, bd)
+        out.backward(g_up.to(DEV))
+        assert bd.grad.shape == hr.shape
+        close(out, f(s, hr), f"compose {kind} broadcast out")
+        close(ad.grad, a.grad, f"compose {kind} broadcast gs")
+        close(bd.grad, b.grad, f"compose {kind} broadcast ghr", rtol=1e-4, atol=1e-4)
