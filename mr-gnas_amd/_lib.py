@@ -128,6 +128,15 @@ meter = KernelMeter()
 
 
 _FN = {}
+TRACE = os.environ.get("MRG_TRACE") == "1"     # debugging aid: log every C-ABI call and synchronise after it,
+                                                # so a faulting kernel is the last line of the log
+
+
+def _trace(name, args):
+    import sys
+    shown = [hex(a.value) if isinstance(a, ctypes.c_void_p) and a.value else ("NULL" if isinstance(a, ctypes.c_void_p) or a is None else a)
+             for a in args]
+    print(f"[mrg] {name} {shown}", file=sys.stderr, flush=True)
 
 
 def call(name, args, nbytes=0, flops=0):
@@ -135,6 +144,13 @@ def call(name, args, nbytes=0, flops=0):
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(load(), name)
+    if TRACE:
+        _trace(name, args)
+        code = fn(*args)
+        torch.cuda.synchronize()
+        if code != 0:
+            check(code, name)
+        return
     if meter.names is not None and meter.active(name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

@@ -478,22 +478,25 @@ class GatherPlan:
     @property
     def plan(self):
         if self._plan is None:
-            from .graph import dst_csr_plan
+            from .graph import dst_csr_plan, settle
             self._plan = dst_csr_plan(self.idx, self.rows)
+            settle(self.idx.device)
         return self._plan
 
     @property
     def sp(self):
         if self._sp is None:
-            from .graph import span_plan
+            from .graph import span_plan, settle
             self._sp = span_plan(self.idx, self.rows)
+            settle(self.idx.device)
         return self._sp
 
     @property
     def meta(self):
         if self._meta is None:
-            from .graph import span_meta
+            from .graph import span_meta, settle
             self._meta = span_meta(self.sp, torch.arange(self.idx.numel(), device=self.idx.device))
+            settle(self.idx.device)          # built at first use (often inside a backward on a side stream), read on any stream
         return self._meta
 
 
@@ -585,8 +588,9 @@ class ComposePlan:
     def m_bx_unit(self):
         """metadata of gX[xi] <- G[seg] with unit scale (d/dx of x - y*s)."""
         if self._m_bx_unit is None:
-            from .graph import span_meta
+            from .graph import span_meta, settle
             self._m_bx_unit = span_meta(self.sp_x, self._raw[0], None, None)
+            settle(self.xi.device)
         return self._m_bx_unit
 
 

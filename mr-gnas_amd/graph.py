@@ -27,6 +27,35 @@ import torch
 CHUNK_EDGES = 64     # in-edges reduced by one wave-group before the list is split
 
 
+def settle(device):
+    """Host-wait for the CURRENT stream of `device` (no-op on CPU).  Every lazily built, cached index structure
+    ends with this: the candidates of a MixedOp run on several HIP streams (supernet.MixedOp), so a plan built
+    on one stream at its first use may be read on another stream next; once the host has seen the building
+    stream drain, the cached tensors are complete for every later launch on any stream.  (Building a plan
+    host-synchronises several times anyway -- bincount, sizes -- so this costs nothing extra.  Found by the
+    WN18RR full-size test: a cold first step read half-written int32 indices on a sibling stream.)"""
+    device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+
+
+def _device_of(val):
+    if torch.is_tensor(val):
+        return val.device
+    if isinstance(val, dict):
+        val = list(val.values())
+    if isinstance(val, (list, tuple)):
+        for v in val:
+            d = _device_of(v)
+            if d is not None:
+                return d
+    for attr in ("idx", "xi", "s32"):                      # GatherPlan / ComposePlan / ScorePlan
+        t = getattr(val, attr, None)
+        if torch.is_tensor(t):
+            return t.device
+    return None
+
+
 def cached_on(obj, key, deps, extra, build):
     """Value derived from the tensors `deps` (and the hashable `extra`), cached on `obj` under attribute
     `key`.  The cache entry keeps the tensors themselves, so an entry can only be hit by the SAME tensor
@@ -37,6 +66,11 @@ def cached_on(obj, key, deps, extra, build):
             all(a is b and (b is None or v == b._version) for (a, v), b in zip(slot[0], deps)):
         return slot[2]
     val = build()
+    dev = _device_of(val)
+    if dev is None:
+        dev = next((d.device for d in deps if d is not None), None)
+    if dev is not None:
+        settle(dev)
     setattr(obj, key, ([(d, None if d is None else d._version) for d in deps], extra, val))
     return val
 
@@ -209,6 +243,7 @@ class RelGraph:
         """CSR-by-destination chunk plan (built once, cached)."""
         if self._plan is None:
             self._plan = dst_csr_plan(self._dst, self._n)
+            settle(self.device)
         return self._plan
 
     def agg_plan(self, kind):
@@ -221,6 +256,7 @@ class RelGraph:
             if kind == "mean":
                 scal = (1.0 / self.in_degrees().clamp(min=1).float())[self._dst]
             meta = span_meta(sp, torch.arange(self.num_edges(), device=self.device), None, scal)
+            settle(self.device)
             self._i32[key] = (sp, meta)
         return self._i32[key]
 

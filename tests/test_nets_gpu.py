@@ -115,3 +115,18 @@ def test_sharded_step_world1_on_hip():
         grads_close(net, z, 2e-3, "sharded world=1")
     finally:
         dist.destroy_process_group()
+
+
+def test_cold_first_step_with_side_streams_matches_reference(monkeypatch):
+    """The FIRST step on a new graph builds its cached index plans lazily, possibly inside a candidate that runs on
+    a side HIP stream; a sibling candidate on another stream then reads them.  Regression test for the race the
+    WN18RR full-size test exposed (plans are now settled before they are cached): the allocator cache is seeded
+    with int32 ones of many sizes first, so a plan read before it is written yields in-bounds but wrong indices
+    and the comparison with the reference fails instead of the GPU faulting."""
+    from mr_gnas_amd import functional as K
+    monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+    for rep in range(4):
+        junk = [torch.ones(n, dtype=torch.int32, device=DEV) for n in (37, 120, 208, 480, 832, 1024, 4096, 20000, 70000) for _ in range(6)]
+        torch.cuda.synchronize()
+        del junk
+        _supernet_step("supernet_d24")          # a new RelGraph, new plans, side streams forced
