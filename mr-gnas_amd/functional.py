@@ -23,6 +23,16 @@ def gate_ld(D):
     return 2 * D + 4          # MRG_GATE_LD
 
 
+def same_rows(a, b):
+    """True when the two operands of an operator are the SAME rows (one tensor, or two aliases of one storage --
+    e.g. Fan views of the cell's h_in, which the first two MixedOps of a cell receive as both `src_emb` and
+    `src_emb_in`, reference models/cell_lp.py:95-104).  Then W [s ; s_in] = (W[:, :D] + W[:, D:]) s: the
+    operators fold the weight halves and run at half the inner dimension; the whole input gradient is returned
+    through the first operand."""
+    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                      and a.stride() == b.stride() and a.dtype == b.dtype)
+
+
 def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
@@ -101,28 +111,34 @@ class _Gate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
-        s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
+        tied = s_in is not None and same_rows(s, s_in)         # [s ; s] : u.s + v.s = (u + v).s -- one operand is streamed
+        s, s_in, norm = f32c(s), (None if tied else f32c(s_in)), f32c(norm)
         params = tuple(f32c(p) for p in params)
         require_hip(s, s_in, norm, *params)
         M, D = s.shape
         st = stream_of(s)
-        in_dim = 2 * D if s_in is not None else D
+        in_dim = 2 * D if (s_in is not None or tied) else D     # inner dimension of the nn.Linear parameters
         uvc = torch.zeros(3, gate_ld(D), dtype=torch.float32, device=s.device)
         for seg in range(3):
             W, b, a = params[3 * seg: 3 * seg + 3]
             if W is not None:
                 call("mrg_gate_collapse", (ptr(W), ptr(b), ptr(a), ptr(uvc[seg]), D, in_dim, st), nbytes=4 * D * in_dim)
+        if tied:
+            folded = torch.zeros_like(uvc)
+            torch.add(uvc[:, :D], uvc[:, D:2 * D], out=folded[:, :D])
+            folded[:, D] = uvc[:, 2 * D]                         # c sits at index D when there is no second operand
+            uvc = folded
         out = torch.empty_like(s)
         nb = 4 * D * M * (3 if s_in is not None else 2) + (4 * b1 if norm is not None else 0)
         call("mrg_gate_fwd", (ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(out), b0, b1, M, D, scale, st), nbytes=nb)
         ctx.save_for_backward(s, s_in, norm, uvc, *params)
-        ctx.cfg = (b0, b1, scale, in_dim)
+        ctx.cfg = (b0, b1, scale, in_dim, tied)
         return out
 
     @staticmethod
     def backward(ctx, g):
         s, s_in, norm, uvc, *params = ctx.saved_tensors
-        b0, b1, scale, in_dim = ctx.cfg
+        b0, b1, scale, in_dim, tied = ctx.cfg
         g = f32c(g)
         M, D = s.shape
         st = stream_of(s)
@@ -133,6 +149,12 @@ class _Gate(torch.autograd.Function):
         nb = 4 * D * M * (5 if s_in is not None else 3) + (4 * b1 if norm is not None else 0)
         call("mrg_gate_bwd", (ptr(g), ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(gs), ptr(gs_in), ptr(d_uvc), ptr(ws),
                               b0, b1, M, D, scale, st), nbytes=nb)
+        if tied:                                                 # d(u + v) goes to both halves; c moves back to index 2D
+            full = torch.empty_like(d_uvc)
+            full[:, :D] = d_uvc[:, :D]
+            full[:, D:2 * D] = d_uvc[:, :D]
+            full[:, 2 * D] = d_uvc[:, D]
+            d_uvc = full
         gparams = []
         for seg in range(3):
             W, b, a = params[3 * seg: 3 * seg + 3]
@@ -864,14 +886,47 @@ class _DenseFilter(torch.autograd.Function):
         return (None, gs, gs_in, None, None, None, None, None, *grads)
 
 
+class _FoldHalves(torch.autograd.Function):
+    """Wt_i = W_i[:, :D] + W_i[:, D:] for up to three nn.Linear(2D, D) weights (None passes through): the weight an
+    operator sees when both of its operands are the same rows.  Backward: gW_i = [gWt_i | gWt_i]."""
+
+    @staticmethod
+    def forward(ctx, *Ws):
+        present = [W is not None for W in Ws]
+        ref = next(W for W in Ws if W is not None)
+        D = ref.shape[0]
+        buf = torch.empty(sum(present), D, D, dtype=ref.dtype, device=ref.device)
+        outs, j = [], 0
+        for W in Ws:
+            if W is None:
+                outs.append(None)
+                continue
+            torch.add(W[:, :D], W[:, D:], out=buf[j])
+            outs.append(buf[j])
+            j += 1
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return tuple(None if g is None else torch.cat((g, g), dim=1) for g in gs)
+
+
 def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_self, b_self, self_scale):
-    """f_dense_comp (kind 0, self_scale 1/3) / f_comp (kind 1, self_scale 1)."""
+    """f_dense_comp (kind 0, self_scale 1/3) / f_comp (kind 1, self_scale 1).  When `s` and `s_in` are the same rows
+    the three GEMMs run on folded [D, D] weights (half the flops forward, one input-gradient GEMM and a
+    half-width weight-gradient GEMM backward)."""
+    if s_in is not None and same_rows(s, s_in):
+        W_in, W_out, W_self = _FoldHalves.apply(W_in, W_out, W_self)
+        s_in = None
     return _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
                               W_in, b_in, W_out, b_out, W_self, b_self)
 
 
 def dense_filter_single(s, s_in, W, b):
     """f_dense_last (s_in None) / f_dense: sigmoid(W [s ; s_in] + b) * s on all rows."""
+    if s_in is not None and same_rows(s, s_in):
+        (W,) = _FoldHalves.apply(W)
+        s_in = None
     return _DenseFilter.apply(0, s, s_in, None, 0, 0, 1.0, 1.0, None, None, None, None, W, b)
 
 

@@ -330,3 +330,42 @@ def test_compose_broadcast_relation_row():
         close(out, f(s, hr), f"compose {kind} broadcast out")
         close(ad.grad, a.grad, f"compose {kind} broadcast gs")
         close(bd.grad, b.grad, f"compose {kind} broadcast ghr", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,T,R,D,order", [(400, 5000, 9, 200, "search"), (120, 900, 4, 64, "train"), (90, 700, 4, 6, "train")])
+def test_filters_with_both_operands_the_same_rows(N, T, R, D, order):
+    """The first two MixedOps of a cell call every FIRST operator as op(g, h_in, h_in) (reference
+    models/cell_lp.py:95-104).  The HIP operators then fold the weight halves, W [s ; s] = (W[:, :D] + W[:, D:]) s, and
+    return the whole input gradient through the first operand; against the oracle's literal cat([s, s]) formulation,
+    once with the very same tensor object and once with two aliases of one storage (what functional.Fan hands out)."""
+    tri = synth(N, T, R, seed=N + D)
+    build = G.build_train_graph if order == "train" else G.build_search_graph
+    g_cpu = build(N, R, tri)
+    s, d, _ = g_cpu.edges(form="all")
+    og = OGraph(N, s, d, g_cpu.edata["e_type"], g_cpu.edata["norm"])
+    g = g_cpu.to(DEV)
+    E = g.num_edges()
+    gen = torch.Generator().manual_seed(D + 1)
+    x, gM = torch.randn(E + N, D, generator=gen), torch.randn(E + N, D, generator=gen)
+    for name in ("f_dense_comp", "f_sparse_comp", "f_comp", "f_dense", "f_sparse"):
+        P = OO.init_params(name, D, gen)
+        for k in P:
+            if k.endswith("bias"):
+                P[k] = torch.randn(P[k].shape, generator=gen) * 0.1
+        a = x.clone().requires_grad_(True)
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        ref = OO.OPS[name](og, Pr, a, a)
+        ref.backward(gM)
+        for how in ("same object", "aliases"):
+            op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+            op.load_state_dict(P)
+            xd = x.to(DEV).requires_grad_(True)
+            u, v = (xd, xd) if how == "same object" else (xd.view_as(xd), xd.view_as(xd))
+            assert K.same_rows(u, v)
+            out = op(g, u, v)
+            out.backward(gM.to(DEV))
+            close(out, ref.detach(), f"{name} ({how}) out")
+            close(xd.grad, a.grad, f"{name} ({how}) input grad")
+            for k, p in op.named_parameters():
+                close(p.grad, Pr[k].grad, f"{name} ({how}) grad {k}", rtol=3e-4, atol=1e-4)
+    assert not K.same_rows(x, gM) and not K.same_rows(x[:10], x[1:11])

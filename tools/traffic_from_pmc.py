@@ -1,67 +1,113 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, with --kernel-trace) into
-per-launch HBM bytes of the C-ABI entry points, applying the gfx950 corrections of
-MI355X_MICROARCH.md (section HBM): both counters are in KiB; FETCH_SIZE reads exactly half the bytes
-of a wide (16 B/lane) coalesced stream, so it is doubled.
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes: the
+two counters do not fit one pass) into HBM-side bytes PER DISPATCH of every device kernel and of the C-ABI
+entry points, with the guide's gfx950 corrections: both counters are in KiB; FETCH_SIZE counts a 128-B request as
+64 B for wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact.
 
-    python tools/traffic_from_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r1_traffic.json
+    python tools/traffic_from_pmc.py gpurun_out/TAG/pmc_fetch gpurun_out/TAG/pmc_write profiles/r2_traffic.json [D M]
+
+Counter rows are first summed per Dispatch_Id (a dispatch may be reported in several rows), then averaged over the
+dispatches of a kernel; kernels are keyed by (name, grid size) so the two north-star passes (FB15k-237 and C5
+shapes launch the same template) stay apart.  Self-check: `compose_fwd_k` must come out at 12*D*M bytes.
 """
 import collections
 import csv
 import glob
 import json
+import re
 import sys
 
-# C-ABI entry point -> substrings of the device kernels it launches (one of each per call)
+# C-ABI entry point -> substrings of the device kernels ONE call launches (each once); missing kernels are skipped
 ENTRY_KERNELS = {
     "mrg_linear_bwd_weight": ["wgrad_x3_k", "wgrad_reduce_k"],
-    "mrg_linear_bwd_input": ["bsplit_k", "rowgemm_x3_k<7, 2, 0"],        # EPI_BIAS_ACT instances (shared with mrg_linear_fwd)
-    "mrg_dense_filter_fwd": ["bsplit_k", "rowgemm_x3_k<7, 2, 1"],        # EPI_GATE
+    "mrg_linear_bwd_input": ["rowgemm_x3_k<7, 2, 0"],
+    "mrg_linear_bwd_input2": ["rowgemm_x3_k<7, 2, 4"],
+    "mrg_dense_filter_fwd": ["rowgemm_x3_k<7, 2, 1"],
     "mrg_sum_buffers": ["sum_k"],
     "mrg_distmult_score": ["distmult_k"],
-    "mrg_span_gcs": ["span_gcs_k"],
     "mrg_mix_bwd_apply": ["mix_bwd_apply_k"],
     "mrg_mix_fwd": ["mix_fwd_k"],
+    "mrg_mix_colstats": ["mix_colstats_k"],
+    "mrg_mix_bwd_reduce": ["mix_bwd_reduce_k"],
     "mrg_gate_fwd": ["gate_fwd_k"],
+    "mrg_gate_bwd": ["gate_bwd_k"],
     "mrg_compose_fwd": ["compose_fwd_k"],
+    "mrg_compose_bwd": ["compose_bwd_k"],
+    "mrg_seg_reduce_bwd": ["seg_bwd_k"],
+    "mrg_dense_filter_dz": ["dense_dz_k"],
 }
+NORTH_STAR = "span_gcs_k<4, 64, 1, 0>"            # MODE = SUB only runs in bench.py's north-star passes
 
 
-def per_kernel(dirpath, counter):
-    files = glob.glob(dirpath + "/*/*counter_collection.csv")
-    tot, cnt = collections.Counter(), collections.Counter()
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter:
-                tot[r["Kernel_Name"]] += float(r["Counter_Value"])
-                cnt[r["Kernel_Name"]] += 1
-    return {k: tot[k] / cnt[k] for k in tot}, cnt
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^mrg::", "", name)
+    return name.split("(")[0][:100]
+
+
+def per_dispatch(dirpath, counter):
+    """{(kernel, grid): [bytes of each dispatch]} in KiB as reported."""
+    disp = {}
+    for f in glob.glob(dirpath + "/**/*counter_collection.csv", recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                key = (f, r["Dispatch_Id"])
+                name, grid, val = disp.get(key, (r["Kernel_Name"], int(r["Grid_Size"]), 0.0))
+                disp[key] = (name, grid, val + float(r["Counter_Value"]))
+    out = collections.defaultdict(list)
+    for name, grid, val in disp.values():
+        out[(short(name), grid)].append(val)
+    return out
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
-    fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
-    write, _ = per_kernel(write_dir, "WRITE_SIZE")
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1`",
-           "correction": "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
+    fetch = per_dispatch(fetch_dir, "FETCH_SIZE")
+    write = per_dispatch(write_dir, "WRITE_SIZE")
+    mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
+    kern = {}
+    for key in sorted(set(fetch) | set(write)):
+        fb, wb = 2.0 * 1024 * mean(fetch.get(key, [])), 1024.0 * mean(write.get(key, []))
+        kern[key] = {"dispatches": len(fetch.get(key, write.get(key, []))), "fetch_bytes": int(fb), "write_bytes": int(wb),
+                     "bytes_per_dispatch": int(fb + wb)}
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, with --kernel-trace) over "
+                     "`python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`",
+           "correction": "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 per dispatch (MI355X_MICROARCH.md: counters in KiB; "
+                         "gfx950 FETCH_SIZE tallies 128-B requests as 64 B)",
+           "note": "FETCH_SIZE counts requests that leave L2, Infinity-Cache hits included: it is an upper bound of DRAM reads",
            "per_launch_bytes": {}, "device_kernels": {}}
-    for name in fetch:
-        res["device_kernels"][name[:120]] = {"launches_profiled": nf[name], "fetch_bytes": int(2 * fetch[name] * 1024),
-                                             "write_bytes": int(write.get(name, 0.0) * 1024)}
+    for (name, grid), v in kern.items():
+        if name.startswith(("mrg::", "span_", "seg_", "mix_", "gate_", "compose_", "rowgemm", "wgrad", "sum_k", "dense_", "distmult",
+                            "gather_", "bsplit", "ordered_reduce", "plan_", "graph_", "sample_", "score_", "rank_", "linrelu")) or "mrg" in name:
+            res["device_kernels"][f"{name} [grid {grid}]"] = v
     for entry, subs in ENTRY_KERNELS.items():
-        total = 0.0
+        total, found = 0.0, False
         for sub in subs:
-            # a C-ABI call launches each listed kernel once; several template instances may exist -> weighted mean
-            names = [k for k in fetch if sub in k]
-            if not names:
+            keys = [k for k in kern if sub in k[0]]
+            if not keys:
                 continue
-            w = sum(nf[k] for k in names)
-            total += sum((2 * fetch[k] + write.get(k, 0.0)) * 1024 * nf[k] for k in names) / w
-        if total:
+            found = True
+            w = sum(kern[k]["dispatches"] for k in keys)
+            total += sum(kern[k]["bytes_per_dispatch"] * kern[k]["dispatches"] for k in keys) / max(w, 1)
+        if found:
             res["per_launch_bytes"][entry] = int(total)
-    json.dump(res, open(out, "w"), indent=1)
+    ns = sorted((k for k in kern if NORTH_STAR in k[0]), key=lambda k: k[1])
+    if ns:
+        res["per_launch_bytes"]["north_star:fb15k237"] = kern[ns[0]]["bytes_per_dispatch"]
+        if len(ns) > 1:
+            res["per_launch_bytes"]["north_star:c5_synthetic10m"] = kern[ns[-1]]["bytes_per_dispatch"]
+    if len(sys.argv) >= 6:                                         # self-check against a known byte count
+        D, M = int(sys.argv[4]), int(sys.argv[5])
+        got, want = res["per_launch_bytes"].get("mrg_compose_fwd"), 12 * D * M
+        res["calibration"] = {"kernel": "compose_fwd_k", "expected_bytes": want, "measured_bytes": got,
+                              "ratio": round(got / want, 4) if got else None}
+        print("calibration compose_fwd_k:", res["calibration"])
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
     for k, v in res["per_launch_bytes"].items():
-        print(f"{k:28s} {v / 1e6:10.1f} MB per launch")
+        print(f"{k:34s} {v / 1e6:10.1f} MB per launch")
 
 
 if __name__ == "__main__":
