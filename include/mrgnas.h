@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 2   /* 2: GEMM entry points take a workspace (split matrix core), span_gcs ext_scal, new entry points */
+#define MRG_ABI_VERSION 3   /* 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -274,6 +274,50 @@ int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const floa
  * mrg_linear_bwd_weight (gW = dz^T [s | s_in], gbias = column sums of dz). */
 int mrg_dense_filter_dz(int kind, const float *g, const float *s, const float *gate, const float *rowscale,
                         float scale, float *dz, float *gs, int64_t rows, int D, void *stream);
+
+/* ---- f2: graph construction, edge ordering and index plans on the device ------------------
+ * build_graph_from_triplets + comp_deg_norm  reference utils/utils_rgcn.py:120-158
+ * node_norm_to_edge_norm                     reference search/mr_lp_search.py:30-36
+ * build_graph                                reference train/mr_lp_train.py:77-89
+ * Integer work: bit-exact with the reference's numpy formulation.
+ *
+ * mrg_build_graph: triples [T][3] int64 (s, r, o) -> E = 2T directed edges (e < T: s -> o with relation r; e >= T:
+ * o -> s with r + R).  sorted != 0: edges ordered by (relation, dst, src) like `sorted(zip(rel, dst, src))`
+ * (utils_rgcn.py:151); sorted == 0: the train driver's un-sorted halves.  in_degree [N] counts edges per destination.
+ * norm[e] = deg_norm_table[in_degree[dst]] * deg_norm_table[in_degree[src]] where the HOST supplies
+ * deg_norm_table[d] = float32(d) ** float32(-0.5), 0 for d = 0 (numpy's own values: a device pow / rsqrt may differ
+ * in the last bit); the caller must make table_len exceed the largest in-degree (max_degree [1] reports it).
+ * src32 / dst32 / etype32 (NULL ok): int32 copies for the kernels.  norm NULL skips the norm (and the int32 copies). */
+int64_t mrg_build_graph_workspace_bytes(int64_t T);
+int mrg_build_graph(const int64_t *triples, int64_t T, int64_t N, int R, int sorted,
+                    const float *deg_norm_table, int64_t table_len,
+                    int64_t *src, int64_t *dst, int64_t *etype, float *norm, int32_t *in_degree,
+                    int32_t *src32, int32_t *dst32, int32_t *etype32, int32_t *max_degree,
+                    void *ws, int64_t ws_bytes, void *stream);
+
+/* Span plan of mrg_span_gcs for segment ids seg [E] in [0, nseg): perm [E] = stable argsort, seg_sorted [E],
+ * seg_len [nseg], span_slot [2 * n_spans] (n_spans = ceil(E / span)), hub_seg / hub_first / hub_count with capacity
+ * 2 * n_spans + nseg, counts [2] = {n_hubs, n_slots} (device memory; the host reads it once).  Same results as the
+ * tensor formulation it replaces (mr-gnas_amd/graph.py:span_plan), which stays as the test's cross-check. */
+int64_t mrg_plan_workspace_bytes(int64_t E, int64_t nseg, int span);
+int mrg_span_plan_build(const int32_t *seg, int64_t E, int64_t nseg, int span,
+                        int32_t *perm, int32_t *seg_sorted, int32_t *seg_len, int32_t *span_slot,
+                        int32_t *hub_seg, int32_t *hub_first, int32_t *hub_count, int32_t *counts,
+                        void *ws, int64_t ws_bytes, void *stream);
+/* meta[j] = {seg_sorted[j], xi[perm[j]] (perm[j] if xi NULL), yi[perm[j]] (0 if NULL), w} with w = float bits of
+ * scal[perm[j]] (1.0f if scal NULL), or perm[j] itself when w_is_index != 0 (external per-call scales). */
+int mrg_span_meta_pack(const int32_t *perm, const int32_t *seg_sorted, const int32_t *xi, const int32_t *yi,
+                       const float *scal, int w_is_index, void *meta, int64_t E, void *stream);
+
+/* Chunk plan of mrg_seg_reduce_fwd / mrg_fused_gcs (CSR by destination, lists cut into chunks of `chunk`):
+ * eid [E], rowptr [N + 1], in_degree [N], chunk_* with capacity N + E / chunk + 1, hub_* with capacity
+ * E / chunk + 1, counts [3] = {n_chunks, n_hubs, n_slots}. */
+int64_t mrg_chunk_plan_workspace_bytes(int64_t E, int64_t N);
+int mrg_chunk_plan_build(const int32_t *dst, int64_t E, int64_t N, int chunk,
+                         int32_t *eid, int32_t *rowptr, int32_t *in_degree,
+                         int32_t *chunk_node, int32_t *chunk_start, int32_t *chunk_end, int32_t *chunk_slot,
+                         int32_t *hub_node, int32_t *hub_first, int32_t *hub_count, int32_t *counts,
+                         void *ws, int64_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmrgnas_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -63,6 +63,13 @@ SIGNATURES = {
     "mrg_linear_bwd_input": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "mrg_linear_bwd_weight_workspace_bytes": (_L, [_L, _I, _I]),
     "mrg_linear_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "mrg_build_graph_workspace_bytes": (_L, [_L]),
+    "mrg_build_graph": (_I, [_P, _L, _L, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mrg_plan_workspace_bytes": (_L, [_L, _L, _I]),
+    "mrg_span_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mrg_span_meta_pack": (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "mrg_chunk_plan_workspace_bytes": (_L, [_L, _L]),
+    "mrg_chunk_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
 }
 
 _lib = None

@@ -517,7 +517,7 @@ class GatherPlan:
     def meta(self):
         if self._meta is None:
             from .graph import span_meta, settle
-            self._meta = span_meta(self.sp, torch.arange(self.idx.numel(), device=self.idx.device))
+            self._meta = span_meta(self.sp, None)           # xi = the element's own index
             settle(self.idx.device)          # built at first use (often inside a backward on a side stream), read on any stream
         return self._meta
 
@@ -584,36 +584,53 @@ def span_gcs(mode, X, Y, meta, plan, ext_scal=None):
 
 class ComposePlan:
     """Index structure of one compose-and-aggregate: element e reads node row xi[e] and relation
-    row yi[e], is scaled by scal[e] and summed into segment seg[e].  Holds the three chunk plans
-    (by segment for the forward, by node row and by relation row for the backward)."""
+    row yi[e], is scaled by scal[e] and summed into segment seg[e].  The span plans / packed metadata of the
+    forward (by segment) and of the backward (by node row, by relation row), and the chunk plans the O(D^2)
+    ccorr kernels use, are each built at first use (HIP plan builders) and settled before they are cached."""
 
     def __init__(self, xi, yi, seg, scal, n_x, n_y, n_seg):
-        from .graph import dst_csr_plan
         i32 = lambda t: t.to(torch.int32).contiguous()
         self.xi, self.yi, self.seg = i32(xi), i32(yi), i32(seg)
         self.scal = None if scal is None else scal.float().contiguous()
         self.n_x, self.n_y, self.n_seg = int(n_x), int(n_y), int(n_seg)
-        self.by_seg = dst_csr_plan(seg, n_seg)
-        self.by_x = dst_csr_plan(xi, n_x)
-        self.by_y = dst_csr_plan(yi, n_y)
-        # balanced span plans + packed per-element metadata for the elementwise modes
-        from .graph import span_meta, span_plan
-        self.sp_seg = span_plan(seg, n_seg)
-        self.sp_x = span_plan(xi, n_x)
-        self.sp_y = span_plan(yi, n_y)
-        self.m_fwd = span_meta(self.sp_seg, xi, yi, scal)             # out[seg] <- X[xi] (op) Y[yi]*s
-        self.m_bx = span_meta(self.sp_x, seg, yi, scal)               # gX[xi]   <- G[seg] (op) Y[yi]*s
-        self.m_by_g = span_meta(self.sp_y, seg, xi, scal)             # gY[yi]   <- G[seg] (op) X[xi]*s
-        self._m_bx_unit = None
-        self._raw = (seg, xi)
+        self._c = {}
+
+    def _lazy(self, key, build):
+        v = self._c.get(key)
+        if v is None:
+            from .graph import settle
+            v = self._c[key] = build()
+            settle(self.xi.device)
+        return v
+
+    def _span(self, which):
+        from .graph import span_plan
+        keys = {"seg": (self.seg, self.n_seg), "x": (self.xi, self.n_x), "y": (self.yi, self.n_y)}[which]
+        return self._lazy("sp_" + which, lambda: span_plan(*keys))
+
+    def _chunk(self, which):
+        from .graph import dst_csr_plan
+        keys = {"seg": (self.seg, self.n_seg), "x": (self.xi, self.n_x), "y": (self.yi, self.n_y)}[which]
+        return self._lazy("by_" + which, lambda: dst_csr_plan(*keys))
+
+    sp_seg = property(lambda self: self._span("seg"))
+    sp_x = property(lambda self: self._span("x"))
+    sp_y = property(lambda self: self._span("y"))
+    by_seg = property(lambda self: self._chunk("seg"))
+    by_x = property(lambda self: self._chunk("x"))
+    by_y = property(lambda self: self._chunk("y"))
+
+    def _meta(self, key, plan, a, b, scal):
+        from .graph import span_meta
+        return self._lazy(key, lambda: span_meta(plan, a, b, scal))
+
+    m_fwd = property(lambda self: self._meta("m_fwd", self.sp_seg, self.xi, self.yi, self.scal))      # out[seg] <- X[xi] (op) Y[yi]*s
+    m_bx = property(lambda self: self._meta("m_bx", self.sp_x, self.seg, self.yi, self.scal))          # gX[xi]   <- G[seg] (op) Y[yi]*s
+    m_by_g = property(lambda self: self._meta("m_by_g", self.sp_y, self.seg, self.xi, self.scal))      # gY[yi]   <- G[seg] (op) X[xi]*s
 
     def m_bx_unit(self):
         """metadata of gX[xi] <- G[seg] with unit scale (d/dx of x - y*s)."""
-        if self._m_bx_unit is None:
-            from .graph import span_meta, settle
-            self._m_bx_unit = span_meta(self.sp_x, self._raw[0], None, None)
-            settle(self.xi.device)
-        return self._m_bx_unit
+        return self._meta("m_bx_unit", self.sp_x, self.seg, None, None)
 
 
 class _ComposeAggregate(torch.autograd.Function):
@@ -947,8 +964,8 @@ class ScorePlan:
         self.s32, self.r32, self.o32 = (x.to(torch.int32).contiguous() for x in (s, r, o))
 
         def packed(plan, xi, yi):
-            perm = plan["perm"]
-            return torch.stack((plan["seg_sorted"].long(), xi[perm], yi[perm], perm), dim=1).to(torch.int32).contiguous()
+            from .graph import span_meta
+            return span_meta(plan, xi, yi, None, w_is_index=True)
         self.by_s, self.by_o, self.by_r = span_plan(s, n_ent), span_plan(o, n_ent), span_plan(r, n_rel)
         self.m_s = packed(self.by_s, o, r)        # g_ent[s] += g_t * ent[o] * rel[r]
         self.m_o = packed(self.by_o, s, r)        # g_ent[o] += g_t * ent[s] * rel[r]

@@ -20,6 +20,7 @@ direction edges, [E/2, E) inverse edges (both reference builders guarantee
 this: train/mr_lp_train.py:80-87, utils/utils_rgcn.py:138-152).
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -75,11 +76,62 @@ def cached_on(obj, key, deps, extra, build):
     return val
 
 
-def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
-    """CSR-by-destination + chunk plan for mrg_seg_reduce_fwd (include/mrgnas.h).
+class _Plan(dict):
+    """A plan dict whose data-dependent sizes stay in a small device tensor until someone asks for them: the HIP
+    builders only enqueue work, the one device-to-host read happens at the first use of the plan."""
 
-    Pure tensor code (runs on the tensors' device; CPU works too, used by the
-    CPU tests).  Returns a dict of int32 tensors and python ints."""
+    def __init__(self, items, counts, names):
+        super().__init__(items)
+        self._counts, self._names = counts, names
+
+    def _resolve(self):
+        if self._counts is not None:
+            for n, v in zip(self._names, self._counts.tolist()):        # the only host synchronisation of a plan build
+                dict.__setitem__(self, n, int(v))
+            self._counts = None
+
+    def __getitem__(self, k):
+        if self._counts is not None and k in self._names:
+            self._resolve()
+        return dict.__getitem__(self, k)
+
+
+def _hip_ready(t):
+    return t.is_cuda and os.environ.get("MRG_TORCH_PLANS") != "1"
+
+
+def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
+    """CSR-by-destination + chunk plan for mrg_seg_reduce_fwd (include/mrgnas.h): built by the HIP plan builder
+    (mrg_chunk_plan_build) for device tensors, by the tensor formulation below on the CPU (CPU tests, and the
+    cross-check of the GPU tests; MRG_TORCH_PLANS=1 forces it everywhere)."""
+    if _hip_ready(dst):
+        return _hip_chunk_plan(dst, num_nodes, chunk)
+    return dst_csr_plan_torch(dst, num_nodes, chunk)
+
+
+def _hip_chunk_plan(dst, num_nodes, chunk):
+    from ._lib import call, load, ptr, stream_of
+    dev, E, N = dst.device, int(dst.numel()), int(num_nodes)
+    d32 = dst if dst.dtype == torch.int32 else dst.to(torch.int32)
+    d32 = d32.contiguous()
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    cap_c, cap_h = N + E // chunk + 1, E // chunk + 1
+    eid, rowptr, deg = i32(E), i32(N + 1), i32(N)
+    cn, cs, ce, csl = i32(cap_c), i32(cap_c), i32(cap_c), i32(cap_c)
+    hn, hf, hc = i32(cap_h), i32(cap_h), i32(cap_h)
+    counts = torch.zeros(3, dtype=torch.int32, device=dev)
+    nb = load().mrg_chunk_plan_workspace_bytes(E, N)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    call("mrg_chunk_plan_build", (ptr(d32), E, N, int(chunk), ptr(eid), ptr(rowptr), ptr(deg), ptr(cn), ptr(cs), ptr(ce), ptr(csl),
+                                  ptr(hn), ptr(hf), ptr(hc), ptr(counts), ptr(ws), nb, stream_of(dst)))
+    return _Plan({"eid": eid[:E], "rowptr": rowptr, "in_degree": deg[:N], "chunk_node": cn, "chunk_start": cs, "chunk_end": ce,
+                  "chunk_slot": csl, "hub_node": hn, "hub_first": hf, "hub_count": hc, "_ws": ws},
+                 counts, ("n_chunks", "n_hubs", "n_slots"))
+
+
+def dst_csr_plan_torch(dst, num_nodes, chunk=CHUNK_EDGES):
+    """The tensor formulation of the chunk plan (pure torch ops; runs on the tensors' device, CPU included).
+    Returns a dict of int32 tensors and python ints."""
     dev = dst.device
     dst = dst.long()
     N = int(num_nodes)
@@ -107,16 +159,42 @@ def dst_csr_plan(dst, num_nodes, chunk=CHUNK_EDGES):
     }
 
 
-import os as _os
-
-SPAN_ELEMS = int(_os.environ.get("MRG_SPAN", "96"))      # sorted elements reduced by one lane group in the span kernels
+SPAN_ELEMS = int(os.environ.get("MRG_SPAN", "96"))      # sorted elements reduced by one lane group in the span kernels
 
 
 def span_plan(seg, nseg, span=None):
     """Plan for mrg_span_gcs (include/mrgnas.h): elements sorted by segment, cut into spans of
     `span` consecutive sorted elements.  Only the first / last run of a span can be a partial
     segment; those get consecutive workspace slots (numbered in span order, so the slots of one
-    segment are consecutive and in list order) that the hub pass adds up.  Pure tensor code."""
+    segment are consecutive and in list order) that the hub pass adds up.  Device tensors go through the HIP
+    builder (mrg_span_plan_build: histogram -> scan -> stable sort -> marking kernels), CPU tensors through the
+    tensor formulation span_plan_torch."""
+    if _hip_ready(seg):
+        return _hip_span_plan(seg, nseg, SPAN_ELEMS if span is None else span)
+    return span_plan_torch(seg, nseg, span)
+
+
+def _hip_span_plan(seg, nseg, span):
+    from ._lib import call, load, ptr, stream_of
+    dev, E, nseg = seg.device, int(seg.numel()), int(nseg)
+    s32 = (seg if seg.dtype == torch.int32 else seg.to(torch.int32)).contiguous()
+    n_spans = (E + span - 1) // span
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    perm, seg_s, seg_len, span_slot = i32(E), i32(E), i32(nseg), i32(2 * n_spans)
+    cap = 2 * n_spans + nseg
+    hs, hf, hc = i32(cap), i32(cap), i32(cap)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    nb = load().mrg_plan_workspace_bytes(E, nseg, int(span))
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    call("mrg_span_plan_build", (ptr(s32), E, nseg, int(span), ptr(perm), ptr(seg_s), ptr(seg_len), ptr(span_slot), ptr(hs), ptr(hf), ptr(hc),
+                                 ptr(counts), ptr(ws), nb, stream_of(seg)))
+    return _Plan({"perm": perm[:E], "seg_sorted": seg_s[:E], "seg_len": seg_len[:nseg], "span": int(span), "n_spans": int(n_spans),
+                  "span_slot": span_slot, "hub_seg": hs, "hub_first": hf, "hub_count": hc, "E": E, "nseg": nseg},
+                 counts, ("n_hubs", "n_slots"))
+
+
+def span_plan_torch(seg, nseg, span=None):
+    """The tensor formulation of the span plan (pure torch ops; any device)."""
     dev = seg.device
     seg = seg.long()
     span = SPAN_ELEMS if span is None else span
@@ -157,13 +235,30 @@ def span_plan(seg, nseg, span=None):
             "n_hubs": int(hub_seg.numel()), "n_slots": int(slot_seg.numel()), "E": E, "nseg": nseg}
 
 
-def span_meta(plan, xi, yi=None, scal=None):
-    """int32x4 {seg, xi, yi, float bits of scal} per sorted element (one 16-byte load each)."""
+def span_meta(plan, xi, yi=None, scal=None, w_is_index=False):
+    """int32x4 {seg, xi, yi, w} per sorted element (one 16-byte load each); w = float bits of scal (1.0 when absent),
+    or the element's own index when `w_is_index` (per-call external scales: mrg_span_gcs ext_scal).  xi None = the
+    element's own index."""
     perm = plan["perm"]
-    xi_s = xi.long()[perm]
+    if _hip_ready(perm) and perm.dtype == torch.int32:
+        from ._lib import call, ptr, stream_of
+        E = int(perm.numel())
+        c32 = lambda t: None if t is None else (t if t.dtype == torch.int32 else t.to(torch.int32)).contiguous()
+        xi32, yi32 = c32(xi), c32(yi)
+        sc = None if scal is None else scal.float().reshape(-1).contiguous()
+        meta = torch.empty(max(E, 1), 4, dtype=torch.int32, device=perm.device)
+        call("mrg_span_meta_pack", (ptr(perm), ptr(plan["seg_sorted"]), ptr(xi32), ptr(yi32), ptr(sc), int(bool(w_is_index)), ptr(meta), E,
+                                    stream_of(perm)))
+        return meta[:E]
+    perm = perm.long()
+    xi_s = xi.long()[perm] if xi is not None else perm
     yi_s = yi.long()[perm] if yi is not None else torch.zeros_like(xi_s)
-    sc = scal.float().reshape(-1)[perm] if scal is not None else torch.ones(perm.numel(), dtype=torch.float32, device=perm.device)
-    return torch.stack((plan["seg_sorted"].long(), xi_s, yi_s, sc.contiguous().view(torch.int32).long()), dim=1).to(torch.int32).contiguous()
+    if w_is_index:
+        w = perm
+    else:
+        sc = scal.float().reshape(-1)[perm] if scal is not None else torch.ones(perm.numel(), dtype=torch.float32, device=perm.device)
+        w = sc.contiguous().view(torch.int32).long()
+    return torch.stack((plan["seg_sorted"].long(), xi_s, yi_s, w), dim=1).to(torch.int32).contiguous()
 
 
 class RelGraph:
@@ -255,7 +350,7 @@ class RelGraph:
             scal = None
             if kind == "mean":
                 scal = (1.0 / self.in_degrees().clamp(min=1).float())[self._dst]
-            meta = span_meta(sp, torch.arange(self.num_edges(), device=self.device), None, scal)
+            meta = span_meta(sp, None, None, scal)
             settle(self.device)
             self._i32[key] = (sp, meta)
         return self._i32[key]
@@ -291,10 +386,63 @@ def _deg_norm(in_deg):
     return norm.astype(np.float32)
 
 
+_DEG_NORM_TABLES = {}
+
+
+def _deg_norm_table(device, need):
+    """deg_norm_table[d] = float32(d) ** float32(-0.5) (0 for d = 0) on `device`, at least `need` entries: numpy's own
+    values (reference utils/utils_rgcn.py:120-127), so the device edge norms are the reference's bit for bit."""
+    key = str(device)
+    tab = _DEG_NORM_TABLES.get(key)
+    if tab is None or tab.numel() < need:
+        n = max(int(need), 1 << 16, 2 * (tab.numel() if tab is not None else 0))
+        tab = torch.from_numpy(_deg_norm(np.arange(n, dtype=np.int64))).to(device)
+        _DEG_NORM_TABLES[key] = tab
+    return tab
+
+
+def build_graph_on_device(num_nodes, num_rels, triples, sorted_edges, norm_2d, device=None):
+    """mrg_build_graph: the directed-edge list, its (relation, dst, src) ordering, in-degrees and edge norms computed on
+    the device from a [T, 3] int64 triple tensor (host arrays are uploaded first).  Returns a RelGraph."""
+    from ._lib import call, load, ptr, stream_of
+    if torch.is_tensor(triples):
+        tri = triples.to(device if device is not None else triples.device).long().contiguous()
+    else:
+        tri = torch.from_numpy(np.ascontiguousarray(np.asarray(triples, dtype=np.int64))).to(device)
+    dev, T, N = tri.device, int(tri.shape[0]), int(num_nodes)
+    E = 2 * T
+    i64 = lambda: torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    src, dst, et = i64(), i64(), i64()
+    norm = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    deg, s32, d32, e32, mx = i32(N), i32(E), i32(E), i32(E), i32(1)
+    tab = _deg_norm_table(dev, E + 1)                    # an in-degree never exceeds the number of directed edges
+    nb = load().mrg_build_graph_workspace_bytes(T)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    call("mrg_build_graph", (ptr(tri), T, N, int(num_rels), int(bool(sorted_edges)), ptr(tab), int(tab.numel()), ptr(src), ptr(dst), ptr(et),
+                             ptr(norm), ptr(deg), ptr(s32), ptr(d32), ptr(e32), ptr(mx), ptr(ws), nb, stream_of(tri)))
+    g = RelGraph(N, src[:E], dst[:E], et[:E], norm[:E].view(-1, 1) if norm_2d else norm[:E], device=dev)
+    # the int32 copies the kernels read were produced by the same launch
+    cached_on(g, "_i32c_src", (g._src,), None, lambda: s32[:E])
+    cached_on(g, "_i32c_dst", (g._dst,), None, lambda: d32[:E])
+    cached_on(g, "_i32c_e_type", (g.edata["e_type"],), None, lambda: e32[:E])
+    g._in_degree32 = deg[:N]
+    return g
+
+
+def _is_device(device, triples):
+    if device is not None:
+        return torch.device(device).type == "cuda"
+    return torch.is_tensor(triples) and triples.is_cuda
+
+
 def build_train_graph(num_nodes, num_rels, triples, device=None):
     """Graph of the fixed-genotype training driver (reference train/mr_lp_train.py:77-89):
-    original edges then inverse edges, un-sorted; norm[e] = d_in(dst)^-1/2 * d_in(src)^-1/2, shape [E]."""
-    t = np.asarray(triples, dtype=np.int64)
+    original edges then inverse edges, un-sorted; norm[e] = d_in(dst)^-1/2 * d_in(src)^-1/2, shape [E].
+    With a HIP `device` (or device triples) the whole construction runs on the GPU (mrg_build_graph)."""
+    if _is_device(device, triples) and os.environ.get("MRG_TORCH_PLANS") != "1":
+        return build_graph_on_device(num_nodes, num_rels, triples, False, False, device)
+    t = np.asarray(triples.cpu() if torch.is_tensor(triples) else triples, dtype=np.int64)
     src = np.concatenate([t[:, 0], t[:, 2]])
     dst = np.concatenate([t[:, 2], t[:, 0]])
     etype = np.concatenate([t[:, 1], t[:, 1] + num_rels])
@@ -304,8 +452,11 @@ def build_train_graph(num_nodes, num_rels, triples, device=None):
 
 def build_search_graph(num_nodes, num_rels, triples, device=None):
     """Graph of the search driver (reference utils/utils_rgcn.py:129-158: inverse edges
-    appended, then sorted by (rel, dst, src); search/mr_lp_search.py:30-36: norm shape [E,1])."""
-    t = np.asarray(triples, dtype=np.int64)
+    appended, then sorted by (rel, dst, src); search/mr_lp_search.py:30-36: norm shape [E,1]).
+    With a HIP `device` (or device triples) the whole construction runs on the GPU (mrg_build_graph)."""
+    if _is_device(device, triples) and os.environ.get("MRG_TORCH_PLANS") != "1":
+        return build_graph_on_device(num_nodes, num_rels, triples, True, True, device)
+    t = np.asarray(triples.cpu() if torch.is_tensor(triples) else triples, dtype=np.int64)
     src = np.concatenate([t[:, 0], t[:, 2]])
     dst = np.concatenate([t[:, 2], t[:, 0]])
     rel = np.concatenate([t[:, 1], t[:, 1] + num_rels])
