@@ -60,6 +60,7 @@ extern "C" {
 /* activation codes for mrg_linear_fwd */
 #define MRG_ACT_NONE     0
 #define MRG_ACT_RELU     1
+#define MRG_ACT_SIGMOID  2   /* the [B, N] score functions: sigmoid((sub * rel) all_ent^T) */
 
 int mrg_abi_version(void);
 const char *mrg_error_string(int code);
@@ -318,6 +319,40 @@ int mrg_chunk_plan_build(const int32_t *dst, int64_t E, int64_t N, int chunk,
                          int32_t *chunk_node, int32_t *chunk_start, int32_t *chunk_end, int32_t *chunk_slot,
                          int32_t *hub_node, int32_t *hub_first, int32_t *hub_count, int32_t *counts,
                          void *ws, int64_t ws_bytes, void *stream);
+
+/* ---- f4: sampling-side data preparation on the device ----------------------------------------
+ * Random draws are inputs (the host draws them on the device; tests replay numpy's), so each call is deterministic and
+ * bit-exact with the reference for the same draws.
+ *
+ * negative_sampling, reference utils/utils_rgcn.py:191-204: samples [(rate+1) B][3]: rows [0, B) = pos (label 1), row
+ * B + j = pos[j % B] with the subject (choices[j] > 0.5) or the object replaced by values[j] (label 0). */
+int mrg_negative_sampling(const int64_t *pos, int64_t B, int rate, const int64_t *values, const double *choices,
+                          int64_t *samples, float *labels, void *stream);
+/* `uniq_v, edges = np.unique((src, dst), return_inverse=True)`, reference utils/utils_rgcn.py:97-101: uniq [<= min(2n,
+ * num_nodes)] = the distinct node ids in ascending order, new_src / new_dst their ranks, count [1] (device) = len(uniq). */
+int64_t mrg_relabel_workspace_bytes(int64_t num_nodes);
+int mrg_relabel_nodes(const int64_t *src, const int64_t *dst, int64_t n, int64_t num_nodes, int64_t *uniq,
+                      int64_t *new_src, int64_t *new_dst, int32_t *count, void *ws, int64_t ws_bytes, void *stream);
+/* Dense targets of a (subject, relation) batch: process() + TrainDataset / TestDataset.get_label (+ label smoothing),
+ * reference utils/process_data.py:4-31, utils/data_set.py:15-33.  keys [U] ascending = subject * (2R) + relation of the
+ * known pairs, rowptr [U + 1] / objs = their object lists; out [B][num_ent] = v_zero everywhere, v_one at the objects of
+ * query[b] (a query without a list gives an all-v_zero row). */
+int mrg_multi_hot_labels(const int64_t *keys, const int32_t *rowptr, const int32_t *objs, const int64_t *query,
+                         int64_t B, int64_t U, int64_t num_ent, float v_zero, float v_one, float *out, void *stream);
+
+/* ---- f3: filtered ranking and the [B, N] score functions ---------------------------------------------
+ * predict(), reference train/mr_lp_train.py:290-299: entries with a non-zero label are pushed to -1e7, the target keeps
+ * its score; ranks[b] = 1 + #(greater) + #(equal at a lower index)  (the position in a stable descending sort). */
+int mrg_rank_filtered(const float *pred, const float *labels, const int64_t *obj, int64_t B, int64_t N,
+                      int64_t *ranks, void *stream);
+/* sf_TransE_op.forward, reference models/operations_lp.py:101-112:
+ *   score[b, n] = sigmoid(gamma - sum_c |sub[b, c] + rel[b, c] - ent[n, c]|)
+ * backward: gobj [B][D] (the gradient of both sub and rel) and gent [N][D]; either may be NULL.
+ * (sf_DisMult_op, :115-127, is mrg_compose_fwd(MULT) + mrg_linear_fwd(act = MRG_ACT_SIGMOID).) */
+int mrg_transe_score_fwd(const float *ent, const float *sub, const float *rel, float gamma, float *score,
+                         int64_t B, int64_t N, int D, void *stream);
+int mrg_transe_score_bwd(const float *ent, const float *sub, const float *rel, const float *gscore, const float *score,
+                         float *gent, float *gobj, int64_t B, int64_t N, int D, void *stream);
 
 #ifdef __cplusplus
 }

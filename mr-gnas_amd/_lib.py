@@ -70,6 +70,13 @@ SIGNATURES = {
     "mrg_span_meta_pack": (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "mrg_chunk_plan_workspace_bytes": (_L, [_L, _L]),
     "mrg_chunk_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mrg_negative_sampling": (_I, [_P, _L, _I, _P, _P, _P, _P, _P]),
+    "mrg_relabel_workspace_bytes": (_L, [_L]),
+    "mrg_relabel_nodes": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "mrg_multi_hot_labels": (_I, [_P, _P, _P, _P, _L, _L, _L, _F, _F, _P, _P]),
+    "mrg_rank_filtered": (_I, [_P, _P, _P, _L, _L, _P, _P]),
+    "mrg_transe_score_fwd": (_I, [_P, _P, _P, _F, _P, _L, _L, _I, _P]),
+    "mrg_transe_score_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
 }
 
 _lib = None

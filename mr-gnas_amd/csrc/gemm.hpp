@@ -166,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     for (int r = 0; r < 16; ++r) {
       float x = acc[n][r] + bv;
       if (EPI == EPI_BIAS_ACT) {
-        v[r] = (a.act == MRG_ACT_RELU) ? (x > 0.f ? x : 0.f) : x;
+        v[r] = (a.act == MRG_ACT_RELU) ? (x > 0.f ? x : 0.f) : (a.act == MRG_ACT_SIGMOID ? sigmoidf_fast(x) : x);
       } else if (EPI == EPI_GATE) {
         g[r] = sigmoidf_fast(x);
         v[r] = g[r] * in[r] * cs[r];

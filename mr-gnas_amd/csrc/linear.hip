@@ -631,7 +631,7 @@ extern "C" int mrg_gemm_set_mode(int mode) {
 extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias, float* Y, void* ws, int64_t rows, int K, int Nout,
                               int act, void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;
-  if (act != MRG_ACT_NONE && act != MRG_ACT_RELU) return MRG_E_ENUM;
+  if (act != MRG_ACT_NONE && act != MRG_ACT_RELU && act != MRG_ACT_SIGMOID) return MRG_E_ENUM;
   if (rows == 0) return MRG_OK;
   if (!X || !W || !Y) return MRG_E_NULLPTR;
   GemmArgs a{};

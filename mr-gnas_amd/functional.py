@@ -16,7 +16,7 @@ from ._lib import ptr_array, call, f32c, ptr, require_hip, stream_of
 
 COMPOSE = {"mult": 0, "sub": 1, "add": 2}
 REDUCE = {"sum": 0, "mean": 1, "max": 2}
-ACT = {None: 0, "none": 0, "relu": 1}
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
 
 
 def gate_ld(D):
@@ -452,7 +452,7 @@ class _Linear(torch.autograd.Function):
         call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), rows, K, Nout, act, stream_of(x)),
              nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
         ctx.act, ctx.has_b = act, b is not None
-        ctx.save_for_backward(x, W, y if act == 1 else None)
+        ctx.save_for_backward(x, W, y if act != 0 else None)
         return y
 
     @staticmethod
@@ -461,6 +461,8 @@ class _Linear(torch.autograd.Function):
         g = f32c(g)
         if ctx.act == 1:
             g = g * (y > 0)           # ReLU mask (elementwise; folded into the fused kernel later)
+        elif ctx.act == 2:
+            g = g * y * (1 - y)       # sigmoid
         rows, K = x.shape
         Nout = W.shape[0]
         st = stream_of(x)
@@ -473,8 +475,18 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             gW = torch.empty_like(W)
             gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-            ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K, Nout), x)
-            call("mrg_linear_bwd_weight", (ptr(g), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), rows, K, 0, Nout, st), **work)
+            if Nout > 1024:
+                # a wide, short product ([B, N] scores against the whole entity table: Nout = N >> rows): the split-over-rows
+                # weight-gradient kernel keeps all of gW's row tiles in registers and does not cover this shape; here
+                # gW = g^T x is itself a tall-skinny row GEMM over the transposed operands
+                gT, xT = g.t().contiguous(), x.t().contiguous()
+                gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", rows, K), x)
+                call("mrg_linear_fwd", (ptr(gT), ptr(xT), None, ptr(gW), ptr(gws), Nout, rows, K, 0, st), **work)
+                if gb is not None:
+                    gb = g.sum(0)
+            else:
+                ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K, Nout), x)
+                call("mrg_linear_bwd_weight", (ptr(g), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), rows, K, 0, Nout, st), **work)
         return gx, gW, gb, None
 
 
@@ -1000,6 +1012,46 @@ def distmult_score(ent, rel, sp):
     """sum_c ent[s] * rel[r] * ent[o] per triple (reference models/model_search_lp.py:169-176)."""
     return _DistMult.apply(ent, rel, sp)
 
+
+
+# ---------------------------------------------------------------------------
+# [B, N] score functions (the step after the path in the fixed-genotype driver)
+# ---------------------------------------------------------------------------
+def distmult_scores_all(all_ent, sub_emb, rel_emb):
+    """sf_DisMult_op (reference models/operations_lp.py:115-127): sigmoid((sub * rel) all_ent^T) as the compose kernel +
+    the MFMA row GEMM with a sigmoid epilogue (all_ent [N, D] is the GEMM's weight operand: no transpose, no [B, N]
+    pre-activation tensor)."""
+    return linear(compose("mult", sub_emb, rel_emb), all_ent, None, "sigmoid")
+
+
+class _TransE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, all_ent, sub, rel, gamma):
+        all_ent, sub, rel = f32c(all_ent), f32c(sub), f32c(rel)
+        require_hip(all_ent, sub, rel)
+        B, D = sub.shape
+        N = all_ent.shape[0]
+        score = torch.empty(B, N, dtype=torch.float32, device=sub.device)
+        call("mrg_transe_score_fwd", (ptr(all_ent), ptr(sub), ptr(rel), float(gamma), ptr(score), B, N, D, stream_of(sub)),
+             nbytes=4 * (B * N + (N + 2 * B) * D))
+        ctx.save_for_backward(all_ent, sub, rel, score)
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        all_ent, sub, rel, score = ctx.saved_tensors
+        g = f32c(g)
+        B, D = sub.shape
+        N = all_ent.shape[0]
+        gent = torch.empty_like(all_ent) if ctx.needs_input_grad[0] else None
+        gobj = torch.empty_like(sub) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        call("mrg_transe_score_bwd", (ptr(all_ent), ptr(sub), ptr(rel), ptr(g), ptr(score), ptr(gent), ptr(gobj), B, N, D, stream_of(sub)))
+        return gent, gobj, gobj, None
+
+
+def transe_scores_all(all_ent, sub_emb, rel_emb, gamma):
+    """sf_TransE_op (reference models/operations_lp.py:101-112): sigmoid(gamma - ||sub + rel - ent||_1) for all entities."""
+    return _TransE.apply(all_ent, sub_emb, rel_emb, gamma)
 
 
 # ---------------------------------------------------------------------------

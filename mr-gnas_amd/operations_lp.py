@@ -197,15 +197,14 @@ class a_sum_op(nn.Module):
         return K.aggregate_rows("sum", src_emb, block, add_self=True, keep=keep)
 
 
-# ---- score functions (the step after the path; dense) ---------------------------------------
+# ---- score functions (the step after the path): HIP kernels as well (compose + MFMA GEMM with a sigmoid epilogue; L1 kernel) ----
 class sf_TransE_op(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.gamma = args.get('gamma', 40)
 
     def forward(self, all_ent, sub_emb, rel_emb):
-        obj = sub_emb + rel_emb
-        return torch.sigmoid(self.gamma - torch.cdist(obj, all_ent, p=1))
+        return K.transe_scores_all(all_ent, sub_emb, rel_emb, self.gamma)
 
 
 class sf_DisMult_op(nn.Module):
@@ -213,7 +212,7 @@ class sf_DisMult_op(nn.Module):
         super().__init__()
 
     def forward(self, all_ent, sub_emb, rel_emb):
-        return torch.sigmoid(torch.mm(sub_emb * rel_emb, all_ent.t()))
+        return K.distmult_scores_all(all_ent, sub_emb, rel_emb)
 
 
 class sf_ConvE_op(nn.Module):

@@ -1,0 +1,124 @@
+"""Search-step sampling, negative sampling and label construction on the device -- the data preparation around the
+hot path that the reference does in numpy on the host for every step:
+
+* ``generate_sampled_graph_and_labels`` / ``sample_edge_uniform`` / ``negative_sampling``
+  (reference utils/utils_rgcn.py:73-118, 191-204): same names, same return values, tensors instead of numpy arrays;
+* ``LabelIndex`` (reference utils/process_data.py:4-31 + utils/data_set.py:6-59): the ``sr2o`` dictionaries as a
+  sorted key / CSR pair in HBM and the dense (label-smoothed) ``[B, num_ent]`` targets of a batch.
+
+Everything integer runs in the HIP kernels of ``csrc/sampling.hip`` / ``csrc/plans.hip`` behind the C ABI.  Random
+draws come from torch's device generator (the reference uses numpy's global generator; bit-equal streams are not
+possible across generators), but every function takes the draws as optional arguments and is bit-exact with the
+reference for the same draws -- that is what the tests replay.  The neighbourhood-expansion sampler
+(utils_rgcn.py:30-71, inherently sequential, not the reference's default) is not provided.
+"""
+import numpy as np
+import torch
+
+from . import graph as G
+from ._lib import call, load, ptr, require_hip, stream_of
+
+
+def sample_edge_uniform(n_triplets, sample_size, device, generator=None):
+    """`np.random.choice(n_triplets, sample_size, replace=False)` (reference utils/utils_rgcn.py:73-76)."""
+    return torch.randperm(int(n_triplets), device=device, generator=generator)[: int(sample_size)]
+
+
+def negative_sampling(pos_samples, num_entity, negative_rate, values=None, choices=None, generator=None):
+    """Reference utils/utils_rgcn.py:191-204.  pos_samples [B, 3] int64 on the device; returns (samples
+    [(rate+1) B, 3] int64, labels float32).  `values` (int64 [B * rate] in [0, num_entity)) and `choices` (float64
+    [B * rate] in [0, 1)) are the reference's two random draws; drawn on the device when absent."""
+    pos = pos_samples.long().contiguous()
+    require_hip(pos)
+    B, n = int(pos.shape[0]), int(pos.shape[0]) * int(negative_rate)
+    dev = pos.device
+    if values is None:
+        values = torch.randint(0, int(num_entity), (n,), device=dev, generator=generator)
+    if choices is None:
+        choices = torch.rand(n, device=dev, dtype=torch.float64, generator=generator)
+    values, choices = values.to(dev).long().contiguous(), choices.to(dev).double().contiguous()
+    if values.numel() != n or choices.numel() != n:
+        raise ValueError(f"negative_sampling needs {n} draws, got {values.numel()} / {choices.numel()}")
+    samples = torch.empty(B * (negative_rate + 1), 3, dtype=torch.int64, device=dev)
+    labels = torch.empty(B * (negative_rate + 1), dtype=torch.float32, device=dev)
+    call("mrg_negative_sampling", (ptr(pos), B, int(negative_rate), ptr(values), ptr(choices), ptr(samples), ptr(labels), stream_of(pos)))
+    return samples, labels
+
+
+def relabel_nodes(src, dst, num_nodes):
+    """`uniq_v, edges = np.unique((src, dst), return_inverse=True)` (reference utils/utils_rgcn.py:97-101):
+    returns (uniq_v ascending, new_src, new_dst)."""
+    src, dst = src.long().contiguous(), dst.long().contiguous()
+    require_hip(src, dst)
+    dev, n = src.device, int(src.numel())
+    cap = max(min(2 * n, int(num_nodes)), 1)
+    uniq = torch.empty(cap, dtype=torch.int64, device=dev)
+    ns, nd = torch.empty_like(src), torch.empty_like(dst)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    nb = load().mrg_relabel_workspace_bytes(int(num_nodes))
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    call("mrg_relabel_nodes", (ptr(src), ptr(dst), n, int(num_nodes), ptr(uniq), ptr(ns), ptr(nd), ptr(count), ptr(ws), nb, stream_of(src)))
+    return uniq[: int(count.item())], ns, nd
+
+
+def generate_sampled_graph_and_labels(triplets, sample_size, split_size, num_rels, negative_rate, num_nodes, sampler="uniform",
+                                      draws=None, generator=None):
+    """One search-step sample (reference utils/utils_rgcn.py:79-118).  `triplets` [T, 3] int64 on the device.
+    Returns ``(g, uniq_v, src, rel, node_norm, samples, labels)`` like the reference, with ``g`` a RelGraph that
+    already carries ``edata['e_type']`` and the edge norm ``edata['norm']`` [E, 1] (what the search driver computes
+    next with node_norm_to_edge_norm, search/mr_lp_search.py:30-36,214), everything resident in HBM.
+    `draws`: optional dict(edges, values, choices, split) replaying the reference's four random draws."""
+    if sampler != "uniform":
+        raise ValueError("Sampler type must be 'uniform' (the neighbourhood sampler is sequential host code)")
+    draws = draws or {}
+    dev = triplets.device
+    T = int(triplets.shape[0])
+    pick = draws.get("edges")
+    pick = sample_edge_uniform(T, sample_size, dev, generator) if pick is None else torch.as_tensor(pick).to(dev).long()
+    edges = triplets[pick].long()
+    uniq_v, src, dst = relabel_nodes(edges[:, 0], edges[:, 2], num_nodes)
+    rel = edges[:, 1].contiguous()
+    relabeled = torch.stack((src, rel, dst), dim=1)
+    samples, labels = negative_sampling(relabeled, int(uniq_v.numel()), negative_rate, draws.get("values"), draws.get("choices"), generator)
+    n_split = int(sample_size * split_size)
+    split = draws.get("split")
+    split = torch.randperm(int(sample_size), device=dev, generator=generator)[:n_split] if split is None else torch.as_tensor(split).to(dev).long()
+    g = G.build_search_graph(int(uniq_v.numel()), num_rels, relabeled[split], device=dev)
+    src_o, _, _ = g.edges(form="all")
+    deg = g._in_degree32.long()
+    node_norm = G._deg_norm_table(dev, int(g.num_edges()) + 1)[deg]
+    return g, uniq_v, src_o, g.edata["e_type"], node_norm, samples, labels
+
+
+class LabelIndex:
+    """``sr2o`` of process() (reference utils/process_data.py:4-31) resident in HBM: for every (subject, relation) pair
+    -- relations r and r + num_rel for the inverse direction -- the set of known objects, as ascending keys
+    ``subject * 2R + relation`` with a CSR of object ids.  ``labels(subj, rel)`` is TrainDataset / TestDataset.get_label
+    for a batch (reference utils/data_set.py:21-33), optionally label-smoothed like TrainDataset.__getitem__ (:21-23)."""
+
+    def __init__(self, triples, num_rel, num_ent, device):
+        t = torch.as_tensor(np.asarray(triples) if not torch.is_tensor(triples) else triples).to(device).long()
+        s, r, o = t[:, 0], t[:, 1], t[:, 2]
+        self.num_rel, self.num_ent = int(num_rel), int(num_ent)
+        key = torch.cat((s * (2 * num_rel) + r, o * (2 * num_rel) + r + num_rel))
+        obj = torch.cat((o, s))
+        pair = torch.unique(key * num_ent + obj)                          # the sets of sr2o: duplicates collapse; ascending
+        key_s, obj_s = pair // num_ent, pair % num_ent
+        self.keys, counts = torch.unique_consecutive(key_s, return_counts=True)
+        rowptr = torch.zeros(self.keys.numel() + 1, dtype=torch.int64, device=t.device)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        self.rowptr, self.objs = rowptr.to(torch.int32).contiguous(), obj_s.to(torch.int32).contiguous()
+        G.settle(t.device)
+
+    def labels(self, subj, rel, label_smooth=0.0):
+        subj, rel = subj.long(), rel.long()
+        q = (subj * (2 * self.num_rel) + rel).contiguous()
+        require_hip(q)
+        B = int(q.numel())
+        out = torch.empty(B, self.num_ent, dtype=torch.float32, device=q.device)
+        v = torch.tensor([0.0, 1.0])
+        if label_smooth != 0.0:                                             # the reference's own float32 expression (data_set.py:23)
+            v = (1.0 - label_smooth) * v + (1.0 / self.num_ent)
+        call("mrg_multi_hot_labels", (ptr(self.keys), ptr(self.rowptr), ptr(self.objs), ptr(q), B, int(self.keys.numel()), self.num_ent,
+                                      float(v[0]), float(v[1]), ptr(out), stream_of(q)))
+        return out

@@ -534,6 +534,112 @@ def case_graph_build(name, N, T, R, seed):
     print("wrote graph_%s" % name)
 
 
+# --------------------------------------------------------------------------
+# data preparation either side of the hot path: sampler, negative sampling, labels, ranking
+# --------------------------------------------------------------------------
+def case_sampling(name, Nall, T, R, sample, neg, seed):
+    """Reference utils/utils_rgcn.py:79-118 and :191-204 with numpy's global generator seeded; the four random draws
+    are replayed (same seed, same call order) and stored so the device functions can be checked draw for draw."""
+    import utils.utils_rgcn as ur
+    rng = np.random.default_rng(seed)
+    tri = make_triples(Nall, T, R, rng, dup=0)
+    adj, deg = ur.get_adj_and_degrees(Nall, tri)
+    np.random.seed(seed)
+    with np.errstate(divide="ignore"):
+        g, uniq_v, src_o, rel, node_norm, samples, labels = ur.generate_sampled_graph_and_labels(tri, sample, 0.5, R, adj, deg, neg, "uniform")
+    np.random.seed(seed)                                   # replay: choice(edges) -> randint(values) -> uniform(choices) -> choice(split)
+    edges = np.random.choice(np.arange(len(tri)), sample, replace=False)
+    values = np.random.randint(len(uniq_v), size=sample * neg)
+    choices = np.random.uniform(size=sample * neg)
+    split = np.random.choice(np.arange(sample), size=int(sample * 0.5), replace=False)
+    e = tri[edges]
+    uv, inv = np.unique((e[:, 0], e[:, 2]), return_inverse=True)
+    assert np.array_equal(uv, uniq_v) and np.array_equal(np.stack((inv.reshape(2, -1)[0], e[:, 1], inv.reshape(2, -1)[1])).T, samples[:sample])
+    s_, d_, _ = g.edges(form="all")
+    st = {"Nall": Nall, "R": R, "sample": sample, "neg": neg, "triples": tri, "draw_edges": edges, "draw_values": values,
+          "draw_choices": choices, "draw_split": split, "uniq_v": uniq_v, "src_o": src_o, "rel": rel, "node_norm": node_norm,
+          "samples": samples, "labels": labels, "g_src": s_, "g_dst": d_}
+    # negative_sampling on its own, another rate
+    pos = samples[:sample]
+    np.random.seed(seed + 1)
+    s2, l2 = ur.negative_sampling(pos, len(uniq_v), 3)
+    np.random.seed(seed + 1)
+    st.update({"ns_pos": pos, "ns_values": np.random.randint(len(uniq_v), size=sample * 3), "ns_choices": np.random.uniform(size=sample * 3),
+               "ns_samples": s2, "ns_labels": l2, "ns_num_entity": len(uniq_v)})
+    np.savez_compressed(os.path.join(OUT, f"sampling_{name}.npz"), **npify(st))
+    print("wrote sampling_%s: n=%d samples=%d" % (name, len(uniq_v), len(samples)))
+
+
+def _install_train_driver_standins():
+    """train/mr_lp_train.py imports three modules this image (and, for `dataloader`, the reference itself) lacks;
+    none of them is touched by predict()."""
+    tbx = types.ModuleType("tensorboardX")
+    tbx.SummaryWriter = object
+    contrib = types.ModuleType("dgl.contrib")
+    cdata = types.ModuleType("dgl.contrib.data")
+    cdata.load_data = None
+    contrib.data = cdata
+    dl = types.ModuleType("dataloader")
+    dl.get_dataset = None
+    sys.modules.update({"tensorboardX": tbx, "dgl.contrib": contrib, "dgl.contrib.data": cdata, "dataloader": dl})
+    sys.modules["dgl"].contrib = contrib
+    sys.path.insert(0, os.path.join(REF, "train"))
+
+
+def case_labels_and_ranking(name, N, T, R, B, seed):
+    """process() + TrainDataset / TestDataset labels (reference utils/process_data.py:4-31, utils/data_set.py) and the
+    filtered ranking of predict() (reference train/mr_lp_train.py:269-314) run as they are, with a stand-in model that
+    returns prepared scores."""
+    from utils.process_data import process
+    from utils.data_set import TestDataset, TrainDataset
+    _install_train_driver_standins()
+    import mr_lp_train as TR
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    tri = make_triples(N, T, R, rng, dup=2)
+    n_tr, n_va = int(T * 0.7), int(T * 0.15)
+    ds = {"train": tri[:n_tr], "valid": tri[n_tr:n_tr + n_va], "test": tri[n_tr + n_va:]}
+    trip = process(ds, R)
+    params = types.SimpleNamespace(lbl_smooth=0.1)
+    tr = TrainDataset(trip["train"], N, params)
+    te = TestDataset(trip["test_tail"] + trip["test_head"], N, params)
+    st = {"N": N, "R": R, "train": ds["train"], "valid": ds["valid"], "test": ds["test"]}
+    idx = rng.choice(len(tr), size=min(B, len(tr)), replace=False)
+    st["train_triples"] = torch.stack([tr[i][0] for i in idx])
+    st["train_labels"] = torch.stack([tr[i][1] for i in idx])                 # label-smoothed, float32
+    tidx = rng.choice(len(te), size=min(B, len(te)), replace=False)
+    t_trip = torch.stack([te[i][0] for i in tidx])
+    t_lab = torch.stack([te[i][1] for i in tidx])
+    st["test_triples"], st["test_labels"] = t_trip, t_lab
+    # predict(): prepared scores in (0, 1) without ties among the unfiltered entities
+    pred = torch.sigmoid(torch.randn(len(tidx), N) * 2)
+    st["pred"] = pred
+
+    class FakeModel:
+        def eval(self):
+            pass
+
+        def __call__(self, g, subj, rel):
+            return self.rows.pop(0)
+
+    model = FakeModel()
+    bs = 16
+    loader = [(t_trip[i:i + bs], t_lab[i:i + bs]) for i in range(0, len(tidx), bs)]
+    model.rows = [pred[i:i + bs].clone() for i in range(0, len(tidx), bs)]
+    res, loss = TR.predict(loader, None, model, "cpu")
+    for k, v in res.items():
+        st["res/" + k] = np.float64(v)
+    st["res_loss"] = np.float64(loss)
+    ranks = []
+    for i in range(len(tidx)):                                               # one row per call: results['mr'] is that row's rank
+        model.rows = [pred[i:i + 1].clone()]
+        r1, _ = TR.predict([(t_trip[i:i + 1], t_lab[i:i + 1])], None, model, "cpu")
+        ranks.append(int(r1["mr"]))
+    st["ranks"] = np.asarray(ranks, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, f"labels_ranking_{name}.npz"), **npify(st))
+    print("wrote labels_ranking_%s: train pairs=%d test rows=%d mrr=%.4f" % (name, len(tr), len(te), res["mrr"] / res["count"]))
+
+
 def main():
     _install_standins()
     torch.set_num_threads(1)
@@ -552,6 +658,8 @@ def main():
     # the two shapes SURVEY 8(c) planned and round 1 skipped (inputs / parameters rebuilt from seeds, not stored)
     case_ops("r300_d64_search", 300, 2000, 11, 64, "search", 6, star_only=True, seeded_inputs=True, skip=("pre_mult", "pre_sub"))
     case_supernet("d200_sampled", 14541, 60000, 237, 200, 100, 475, 2, 300, 33, seeded_params=True)
+    case_sampling("small", 400, 3000, 7, 200, 10, 51)
+    case_labels_and_ranking("small", 150, 1200, 5, 64, 52)
 
 
 if __name__ == "__main__":

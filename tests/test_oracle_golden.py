@@ -2,6 +2,7 @@
 (tests/golden/make_golden.py).  CPU only."""
 import collections
 
+import numpy as np
 import pytest
 import torch
 
@@ -160,3 +161,33 @@ def test_supernet_step(case):
     assert sorted(S) == net_grad_names(z)
     for k, v in S.items():
         assert_param_grad(z, k, v.grad if v.grad is not None else torch.zeros_like(v), 1e-3, 2e-6, case)
+
+
+def test_data_preparation_oracle_matches_reference():
+    """oracle/dataprep.py against what the reference's own functions produced (tests/golden/make_golden.py:
+    case_sampling, case_labels_and_ranking)."""
+    from oracle import dataprep as OD
+    z = load_golden("sampling_small")
+    draws = {"edges": z["draw_edges"].numpy(), "values": z["draw_values"].numpy(), "choices": z["draw_choices"].numpy(),
+             "split": z["draw_split"].numpy()}
+    g, uniq_v, src_o, rel, node_norm, samples, labels = OD.sampled_graph_and_labels(z["triples"].numpy(), z["sample"], 0.5, z["R"], z["neg"], draws)
+    assert np.array_equal(uniq_v, z["uniq_v"].numpy()) and np.array_equal(src_o, z["src_o"].numpy()) and np.array_equal(rel, z["rel"].numpy())
+    assert np.array_equal(node_norm, z["node_norm"].numpy())
+    assert np.array_equal(samples, z["samples"].numpy()) and np.array_equal(labels, z["labels"].numpy())
+    assert torch.equal(g.src, z["g_src"]) and torch.equal(g.dst, z["g_dst"])
+    s2, l2 = OD.negative_sampling(z["ns_pos"].numpy(), z["ns_num_entity"], 3, z["ns_values"].numpy(), z["ns_choices"].numpy())
+    assert np.array_equal(s2, z["ns_samples"].numpy()) and np.array_equal(l2, z["ns_labels"].numpy())
+
+    z = load_golden("labels_ranking_small")
+    tr = OD.sr2o(z["train"].numpy(), z["R"])
+    al = OD.sr2o(torch.cat((z["train"], z["valid"], z["test"])).numpy(), z["R"])
+    t = z["train_triples"]
+    assert torch.equal(OD.dense_labels(tr, t[:, 0], t[:, 1], z["N"], 0.1), z["train_labels"])
+    t = z["test_triples"]
+    assert torch.equal(OD.dense_labels(al, t[:, 0], t[:, 1], z["N"]), z["test_labels"])
+    ranks = OD.filtered_ranks(z["pred"], z["test_labels"], t[:, 2])
+    assert torch.equal(ranks, z["ranks"])
+    assert int(z["res/count"]) == len(ranks) and float(z["res/mr"]) == float(ranks.sum())
+    assert abs(float(z["res/mrr"]) - float((1.0 / ranks.float()).sum())) < 1e-3
+    for k in (1, 3, 10):
+        assert int(z[f"res/hits@{k}"]) == int((ranks <= k).sum())
