@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=30000, help="graph_batch_size of the CPU-baseline sample")
     ap.add_argument("--no-c5", action="store_true", help="skip the north-star kernel pass at the C5 shape (10 M edges, D = 256)")
     ap.add_argument("--no-exact-f32-leg", action="store_true", help="skip the extra timed steps on the exact-f32 matrix core")
+    ap.add_argument("--resample", action="store_true",
+                    help="sampled workloads only: draw a NEW step graph inside every timed step (device sampler, negative "
+                         "sampling, graph build, index plans: reference search/mr_lp_search.py:187-214), so `value` pays for it")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -104,8 +107,33 @@ class Step:
         self.opt = torch.optim.SGD(self.model.parameters(), 1e-3, momentum=0.9, weight_decay=0.0)
         self.clip = 5.0
         self.last_loss = None
+        self._args = args
+        self.sample_size = 0
+        if getattr(args, "resample", False):
+            size = args.workload.split("_")[2]
+            if size == "full":
+                raise SystemExit("--resample needs a sampled workload (fb15k237_supernet_30k / _300)")
+            self.sample_size = {"30k": 30000, "300": 300}[size]
+
+    def resample(self, sample_size, negative):
+        """A new search-step sample on the device (mr_gnas_amd.sampler: reference utils/utils_rgcn.py:79-118)."""
+        from mr_gnas_amd import sampler as SM
+        if getattr(self, "_kg", None) is None:
+            from mr_gnas_amd import synth
+            ds = self._args.workload.split("_")[0]
+            N, R, T = synth.SHAPES[ds]
+            self._kg = (torch.from_numpy(synth.synth_kg(N, R, T, self._args.seed)).to(self.samples.device), N, R)
+            self._gen = torch.Generator(device=self.samples.device).manual_seed(self._args.seed + 7)
+        tri, N, R = self._kg
+        g, uniq_v, src_o, rel, _, samples, labels = SM.generate_sampled_graph_and_labels(tri, sample_size, 0.5, R, negative, N,
+                                                                                        generator=self._gen)
+        self.g, self.E = g, g.num_edges()
+        self.node_id, self.src_in, self.edge_type = uniq_v.view(-1, 1), src_o, rel
+        self.samples, self.labels = samples, labels
 
     def __call__(self):
+        if self.sample_size:
+            self.resample(self.sample_size, self._args.negative)
         ent, rel = self.model(self.g, self.node_id, self.src_in, self.edge_type)
         loss = self.model.get_loss(self.g, ent, rel, self.samples, self.labels)
         loss.backward()
@@ -322,6 +350,8 @@ def main():
     dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
 
     run_step = step
+    if args.resample and (args.hip_graph or sharded):
+        raise SystemExit("--resample is a single-GPU eager mode")
     if args.hip_graph and sharded:
         # measured: capturing a step with RCCL collectives kills the watchdog thread (hipErrorStreamCaptureUnsupported) in the
         # default capture mode and segfaults in thread_local mode on the full graph
@@ -379,7 +409,9 @@ def main():
                                    "f32 via 3-way bf16 split: 6 cross terms on v_mfma_f32_32x32x16_bf16, f32 accumulate "
                                    "(error vs float64 pinned <= 1.5x the exact-f32 core in tests)"),
                    "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL",
-                   "launch": "hip graph replay" if args.hip_graph else "eager"},
+                   "launch": "hip graph replay" if args.hip_graph else "eager",
+                   "step_graph": ("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
+                                  "inside the timed region)" if args.resample else "resident, built before timing")},
         "loss": float(step.last_loss) if step.last_loss is not None else None,
     }
     if dominant and dominant in dom_stats:

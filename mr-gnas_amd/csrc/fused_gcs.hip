@@ -33,6 +33,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_k(const float* __restrict__ X, 
   const int dv = D / VEC;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
+    if (v < 0) continue;                                    // padding beyond the plan's real chunks
     const int j0 = chunk_start[ch], j1 = chunk_end[ch];
     const int slot = chunk_slot[ch];
     Vec<VEC> acc[KMAX];
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
   float* ly = lx + WIDTH;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
+    if (v < 0) continue;                                    // padding beyond the plan's real chunks
     const int j0 = chunk_start[ch], j1 = chunk_end[ch];
     const int slot = chunk_slot[ch];
     Vec<VEC> acc[KMAX];

@@ -240,6 +240,8 @@ extern "C" int64_t mrg_plan_workspace_bytes(int64_t E, int64_t nseg, int span) {
   return (int64_t)b;
 }
 
+// hub_seg is filled with -1 over its whole capacity (2 * n_spans + nseg) first: a consumer may launch with the CAPACITY as
+// the hub count (no device-to-host read of `counts`), the hub pass skips negative entries.
 extern "C" int mrg_span_plan_build(const int32_t* seg, int64_t E, int64_t nseg, int span, int32_t* perm, int32_t* seg_sorted,
                                    int32_t* seg_len, int32_t* span_slot, int32_t* hub_seg, int32_t* hub_first, int32_t* hub_count,
                                    int32_t* counts, void* ws, int64_t ws_bytes, void* stream) {
@@ -270,6 +272,7 @@ extern "C" int mrg_span_plan_build(const int32_t* seg, int64_t E, int64_t nseg, 
   MRG_HIP(hipMemsetAsync(scal, 0, 64, st));
   MRG_HIP(hipMemsetAsync(counts, 0, 8, st));
   if (nseg == 0) return MRG_OK;
+  MRG_HIP(hipMemsetAsync(hub_seg, 0xFF, (size_t)(cap + nseg) * 4, st));
   MRG_HIP(hipMemsetAsync(seg_len, 0, (size_t)nseg * 4, st));
   if (E > 0) {
     hipLaunchKernelGGL(hist_k, dim3(blocks_for(E)), dim3(256), 0, st, seg, E, seg_len);
@@ -341,6 +344,8 @@ extern "C" int mrg_chunk_plan_build(const int32_t* dst, int64_t E, int64_t N, in
   int32_t* hub_idx = A.take<int32_t>(N + 1);
   if (!A.ok()) return MRG_E_WORKSPACE;
   MRG_HIP(hipMemsetAsync(in_degree, 0, (size_t)N * 4, st));
+  MRG_HIP(hipMemsetAsync(chunk_node, 0xFF, (size_t)(N + E / chunk + 1) * 4, st));     // capacity-sized launches skip the -1 padding
+  MRG_HIP(hipMemsetAsync(hub_node, 0xFF, (size_t)(E / chunk + 1) * 4, st));
   if (E > 0) {
     hipLaunchKernelGGL(hist_k, dim3(blocks_for(E)), dim3(256), 0, st, dst, E, in_degree);
     hipLaunchKernelGGL(iota_k, dim3(blocks_for(E)), dim3(256), 0, st, iota, E);

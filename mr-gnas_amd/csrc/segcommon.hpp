@@ -86,7 +86,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
   for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-    const int v = hub_node[h], s0 = hub_first[h], cnt = hub_count[h];
+    const int v = hub_node[h];
+    if (v < 0) continue;                                    // block-uniform: padding beyond the plan's real hubs (capacity-sized launch)
+    const int s0 = hub_first[h], cnt = hub_count[h];
     const int per = (cnt + RPB - 1) / RPB;
     const int q0 = rw * per < cnt ? rw * per : cnt, q1 = q0 + per < cnt ? q0 + per : cnt;
     Acc<VEC, LPR, KMAX, IS_MAX> acc;

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict
   const int dv = D / VEC;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
+    if (v < 0) continue;                                    // padding beyond the plan's real chunks (capacity-sized launch, see plans.hip)
     const int j0 = chunk_start[ch], j1 = chunk_end[ch];
     const int slot = chunk_slot[ch];
     Acc<VEC, LPR, KMAX, IS_MAX> acc;

@@ -33,6 +33,13 @@ def same_rows(a, b):
                       and a.stride() == b.stride() and a.dtype == b.dtype)
 
 
+def _cnt(plan, name):
+    """Launch-side count of a plan: the host-known capacity when the plan has one (HIP-built plans pad with -1 and the
+    kernels skip the padding: no device-to-host read), else the exact number."""
+    cap = "cap_" + name
+    return plan[cap] if cap in plan else plan["n_" + name]
+
+
 def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
@@ -186,12 +193,13 @@ def _seg_fwd(mode, msg, self_rows, p, N, D, want_arg=True):
     """Launch mrg_seg_reduce_fwd over plan p (graph.dst_csr_plan); returns (out, arg)."""
     out = torch.empty(N, D, dtype=torch.float32, device=msg.device)
     arg = torch.empty(N, D, dtype=torch.int32, device=msg.device) if mode == 2 else None
-    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", p["n_slots"], D), msg) if p["n_slots"] > 0 else None
+    n_chunks, n_hubs, n_slots = _cnt(p, "chunks"), _cnt(p, "hubs"), _cnt(p, "slots")
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), msg) if n_slots > 0 else None
     E = int(p["eid"].numel())
     nb = 4 * D * E + 4 * E + 4 * D * N * (1 + (self_rows is not None) + (mode == 2))
     call("mrg_seg_reduce_fwd", (mode, ptr(msg), ptr(self_rows), ptr(p["eid"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
-                                ptr(p["chunk_end"]), ptr(p["chunk_slot"]), p["n_chunks"], ptr(p["hub_node"]),
-                                ptr(p["hub_first"]), ptr(p["hub_count"]), p["n_hubs"], p["n_slots"], ptr(p["in_degree"]),
+                                ptr(p["chunk_end"]), ptr(p["chunk_slot"]), n_chunks, ptr(p["hub_node"]),
+                                ptr(p["hub_first"]), ptr(p["hub_count"]), n_hubs, n_slots, ptr(p["in_degree"]),
                                 ptr(out), ptr(arg), ptr(ws), N, D, stream_of(msg)), nbytes=nb)
     return out, arg
 
@@ -567,14 +575,15 @@ def fused_gcs(mode, X, xi, Y, yi, scal, plan, nseg):
     require_hip(X, Y, scal, xi, yi)
     D = X.shape[1]
     out = torch.empty(nseg, D, dtype=torch.float32, device=X.device)
-    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
+    n_chunks, n_hubs, n_slots = _cnt(plan, "chunks"), _cnt(plan, "hubs"), _cnt(plan, "slots")
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), X) if n_slots > 0 else None
     E = int(plan["eid"].numel())
     rows_y = Y.shape[0] if Y is not None else 0
     nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)
     call("mrg_fused_gcs", (GCS[mode], ptr(X), ptr(xi), ptr(Y), ptr(yi), ptr(scal), ptr(plan["eid"]), ptr(plan["chunk_node"]),
-                           ptr(plan["chunk_start"]), ptr(plan["chunk_end"]), ptr(plan["chunk_slot"]), plan["n_chunks"],
-                           ptr(plan["hub_node"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), plan["n_hubs"],
-                           plan["n_slots"], ptr(plan["in_degree"]), ptr(out), ptr(ws), nseg, D, stream_of(X)),
+                           ptr(plan["chunk_start"]), ptr(plan["chunk_end"]), ptr(plan["chunk_slot"]), n_chunks,
+                           ptr(plan["hub_node"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), n_hubs,
+                           n_slots, ptr(plan["in_degree"]), ptr(out), ptr(ws), nseg, D, stream_of(X)),
          nbytes=nb, flops=(2 * E * D * D if mode in ("ccorr", "cconv") else 0))
     return out
 
@@ -585,11 +594,12 @@ def span_gcs(mode, X, Y, meta, plan, ext_scal=None):
     require_hip(X, Y, meta, ext_scal)
     D, nseg, E = X.shape[1], plan["nseg"], plan["E"]
     out = torch.empty(nseg, D, dtype=torch.float32, device=X.device)     # every row is written: runs, hubs, empty segments
-    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", plan["n_slots"], D), X) if plan["n_slots"] > 0 else None
+    n_hubs, n_slots = _cnt(plan, "hubs"), _cnt(plan, "slots")
+    ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), X) if n_slots > 0 else None
     rows_y = Y.shape[0] if Y is not None else 0
     nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)
     call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), ptr(ext_scal), E, plan["span"], ptr(plan["span_slot"]), plan["n_spans"],
-                          ptr(plan["hub_seg"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), plan["n_hubs"], plan["n_slots"],
+                          ptr(plan["hub_seg"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), n_hubs, n_slots,
                           ptr(plan["seg_len"]), ptr(out), ptr(ws), nseg, D, stream_of(X)), nbytes=nb)
     return out
 
@@ -818,7 +828,10 @@ class Fork:
         while len(pool) < n - 1:
             pool.append(torch.cuda.Stream(device=device))
         self.side = pool[:max(n - 1, 0)]
+        from .graph import register_stream
+        register_stream(self.main)
         for st in self.side:
+            register_stream(st)
             st.wait_stream(self.main)
 
     def stream(self, i):

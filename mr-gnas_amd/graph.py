@@ -28,16 +28,35 @@ import torch
 CHUNK_EDGES = 64     # in-edges reduced by one wave-group before the list is split
 
 
+KNOWN_STREAMS = {}      # device index -> set of HIP streams this package launches on (functional.Fork registers them)
+
+
+def register_stream(stream):
+    KNOWN_STREAMS.setdefault(stream.device.index, set()).add(stream)
+
+
 def settle(device):
-    """Host-wait for the CURRENT stream of `device` (no-op on CPU).  Every lazily built, cached index structure
-    ends with this: the candidates of a MixedOp run on several HIP streams (supernet.MixedOp), so a plan built
-    on one stream at its first use may be read on another stream next; once the host has seen the building
-    stream drain, the cached tensors are complete for every later launch on any stream.  (Building a plan
-    host-synchronises several times anyway -- bincount, sizes -- so this costs nothing extra.  Found by the
-    WN18RR full-size test: a cold first step read half-written int32 indices on a sibling stream.)"""
+    """Order every stream this package launches on after the work enqueued so far on the CURRENT stream of `device`
+    (no-op on CPU).  Every lazily built, cached index structure ends with this: the candidates of a MixedOp run on
+    several HIP streams (supernet.MixedOp), so a plan built on one stream at its first use may be read on a sibling
+    stream next (found by the WN18RR full-size test: a cold first step read half-written int32 indices).  An event
+    is recorded behind the build and every other known stream waits for it on the device -- no host
+    synchronisation, so a launch-bound step that rebuilds its plans (a new sampled graph per step) keeps its queue
+    full.  Streams created later are ordered through Fork's wait on the main stream."""
     device = torch.device(device)
-    if device.type == "cuda":
-        torch.cuda.current_stream(device).synchronize()
+    if device.type != "cuda":
+        return
+    cur = torch.cuda.current_stream(device)
+    register_stream(cur)
+    others = [st for st in KNOWN_STREAMS.get(cur.device.index, ()) if st != cur]
+    dflt = torch.cuda.default_stream(device)
+    if dflt != cur and dflt not in others:
+        others.append(dflt)
+    if others:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for st in others:
+            st.wait_event(ev)
 
 
 def _device_of(val):
@@ -124,8 +143,11 @@ def _hip_chunk_plan(dst, num_nodes, chunk):
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     call("mrg_chunk_plan_build", (ptr(d32), E, N, int(chunk), ptr(eid), ptr(rowptr), ptr(deg), ptr(cn), ptr(cs), ptr(ce), ptr(csl),
                                   ptr(hn), ptr(hf), ptr(hc), ptr(counts), ptr(ws), nb, stream_of(dst)))
+    # cap_*: host-known upper bounds; the builders pad chunk_node / hub_node with -1 and the kernels skip the padding, so a
+    # launch may use the capacities and never wait for the exact counts (which stay available, lazily, under n_*)
     return _Plan({"eid": eid[:E], "rowptr": rowptr, "in_degree": deg[:N], "chunk_node": cn, "chunk_start": cs, "chunk_end": ce,
-                  "chunk_slot": csl, "hub_node": hn, "hub_first": hf, "hub_count": hc, "_ws": ws},
+                  "chunk_slot": csl, "hub_node": hn, "hub_first": hf, "hub_count": hc, "_ws": ws,
+                  "cap_chunks": cap_c, "cap_hubs": cap_h, "cap_slots": cap_c},
                  counts, ("n_chunks", "n_hubs", "n_slots"))
 
 
@@ -189,7 +211,8 @@ def _hip_span_plan(seg, nseg, span):
     call("mrg_span_plan_build", (ptr(s32), E, nseg, int(span), ptr(perm), ptr(seg_s), ptr(seg_len), ptr(span_slot), ptr(hs), ptr(hf), ptr(hc),
                                  ptr(counts), ptr(ws), nb, stream_of(seg)))
     return _Plan({"perm": perm[:E], "seg_sorted": seg_s[:E], "seg_len": seg_len[:nseg], "span": int(span), "n_spans": int(n_spans),
-                  "span_slot": span_slot, "hub_seg": hs, "hub_first": hf, "hub_count": hc, "E": E, "nseg": nseg},
+                  "span_slot": span_slot, "hub_seg": hs, "hub_first": hf, "hub_count": hc, "E": E, "nseg": nseg,
+                  "cap_hubs": cap, "cap_slots": 2 * n_spans},
                  counts, ("n_hubs", "n_slots"))
 
 
