@@ -242,7 +242,8 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  *     mrg_gemm_set_mode(1).
  * ws: NULL, or mrg_gemm_workspace_bytes(K, Nout) bytes of device memory private to this call. */
 int64_t mrg_gemm_workspace_bytes(int K, int Nout);
-/* 0 (default): split core where possible; 1: exact-f32 core only (process-wide). */
+/* 0 (default): split core where possible; 1: exact-f32 core only; 3: split core on the persistent
+ * transposed-accumulator kernel (comparison point, measured equal).  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);

@@ -345,37 +345,4 @@ inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st) {
   return e == hipSuccess ? MRG_OK : (int)e;
 }
 
-// ---- dispatch between the two cores ---------------------------------------------------------------
-// mode 0 (default): split-bf16 core whenever the operands qualify and a workspace was given;
-// mode 1: exact-f32 core only (v_mfma_f32_32x32x2_f32) -- the comparison point of the tests and of bench.py.
-inline int& gemm_mode() { static int m = 0; return m; }
-
-inline size_t gemm_workspace_bytes(int K, int N) {
-  const size_t split = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
-  const size_t transp = (size_t)K * N * sizeof(float);
-  return split > transp ? split : transp;
-}
-
-// B(n, k) = a.B[n * b_sn + k * b_sk] (a.ldb is ignored).  ws: gemm_workspace_bytes(K, N) bytes, may be NULL
-// when b_sk == 1 (then only the exact-f32 core is available).
-template <int EPI>
-inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStream_t st) {
-  if (a.rows <= 0) return MRG_OK;
-  if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
-  const int K = a.K1 + a.K2;
-  if (ws && gemm_mode() == 0 && x3_eligible(a)) {
-    launch_bsplit(a.B, b_sn, b_sk, a.N, K, gemm_pick_nt(a.N), ws, st);
-    return launch_rowgemm_x3<EPI>(a, ws, st);
-  }
-  if (b_sk != 1) {                                   // present B^T row-major to the f32 core
-    if (!ws) return MRG_E_WORKSPACE;
-    launch_transpose(a.B, (float*)ws, (int)(K), a.N, (int)b_sk, st);
-    a.B = (const float*)ws;
-    a.ldb = K;
-  } else {
-    a.ldb = (int)b_sn;
-  }
-  return launch_rowgemm<EPI>(a, st);
-}
-
 }  // namespace mrg

@@ -4,12 +4,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "gemm_x3.hpp"
+#include "gemm_x3p.hpp"
 using namespace mrg;
 
 static float frand() { return (float)rand() / RAND_MAX - 0.5f; }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   int64_t rows = argc > 1 ? atoll(argv[1]) : 558771;
   int K1 = argc > 2 ? atoi(argv[2]) : 200, K2 = argc > 3 ? atoi(argv[3]) : 200, N = argc > 4 ? atoi(argv[4]) : 200;
   int K = K1 + K2;
@@ -37,6 +38,10 @@ int main(int argc, char** argv) {
   };
   timeit("x3 (split + gemm)", [&] { launch_bsplit(B, K, 1, N, K, nt, Bp, 0); launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
   timeit("x3 (gemm only)", [&] { launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  if (x3p_eligible(a)) {
+    hipMemset(C, 0, rows * N * 4);
+    timeit("x3 persistent (gemm only)", [&] { launch_rowgemm_x3p<EPI_BIAS_ACT>(a, Bp, 0); });
+  }
   GemmArgs b = a; b.C = C2;
   timeit("f32 mfma", [&] { launch_rowgemm<EPI_BIAS_ACT>(b, 0); });
   // error vs float64 on a sample of rows
