@@ -244,7 +244,7 @@ def test_distmult_score_and_gradients(N, R, T, D):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K1,K2,Nout", [(70000, 200, 200, 200), (70001, 200, 0, 200), (3000, 100, 100, 100), (513, 64, 0, 40),
-                                             (66000, 52, 0, 300), (259, 400, 0, 7), (272115, 200, 0, 200), (300001, 128, 128, 256)])
+                                             (66000, 52, 0, 300), (259, 400, 0, 7), (272115, 200, 0, 200), (300001, 128, 128, 128), (200001, 256, 0, 256)])
 def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     """The split-bf16 matrix core (six bf16 cross terms, f32 accumulate) against the exact-f32 MFMA core, both
     measured against a float64 product: its error may not exceed 1.5x the exact core's (+ 1e-6 of the output
