@@ -65,6 +65,13 @@ def node_ranges(n, parts):
     return lo
 
 
+def node_chunks(n, parts):
+    """Row ranges of EQUAL size ceil(n / parts) (the last ones shorter or empty): what reduce_scatter_tensor /
+    all_gather_into_tensor move without per-rank padding tricks.  Returns (cuts [parts + 1], chunk)."""
+    chunk = (n + parts - 1) // parts if n > 0 else 0
+    return [min(r * chunk, n) for r in range(parts + 1)], chunk
+
+
 class EdgeShard(RelGraph):
     """Rank-local view of a step graph: a relation block of edges + a node range."""
 
@@ -79,7 +86,7 @@ class EdgeShard(RelGraph):
         self.global_edge_ids = torch.from_numpy(mine).to(device)       # caller-order ids of the local rows
         self.E_global = len(src)
         self._b0 = int((etype[mine] < num_rels).sum())
-        lo = node_ranges(n, world)
+        lo, self.node_chunk = node_chunks(n, world)             # equal chunks: one reduce-scatter / all-gather per exchange
         self.node_lo, self.node_hi = lo[rank], lo[rank + 1]
         self.node_cuts = lo
         self.global_in_degree = torch.from_numpy(np.bincount(dst, minlength=n)).to(device)
@@ -96,6 +103,10 @@ class EdgeShard(RelGraph):
 # ---------------------------------------------------------------------------
 # collectives with adjoint backward
 # ---------------------------------------------------------------------------
+def _backend_has_reduce_scatter(group):
+    return dist.get_backend(group) != "gloo"          # gloo (the CPU tests) has no reduce_scatter: all-reduce + slice there
+
+
 class _AllReduceSum(torch.autograd.Function):
     """inplace=True reduces into x itself (a temporary nobody else reads, e.g. a fresh segment-sum partial)."""
 
@@ -115,46 +126,120 @@ class _AllReduceSum(torch.autograd.Function):
         return g, None, None
 
 
-class _AllReduceMax(torch.autograd.Function):
-    """y = elementwise max over ranks; the gradient returns to the ranks that attain it
-    (ties only occur at 0 after ReLU, where the ReLU mask removes the gradient anyway)."""
+class Exchange:
+    """An aggregator exchange in flight: `start` launches the collective on RCCL's own stream (async_op), `finish`
+    makes the current stream wait for it.  Between the two the caller enqueues independent work (the partials of the
+    next MixedOp), which then overlaps the transfer."""
+
+    def __init__(self):
+        self.work = None
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
+class _ReduceScatterRows(torch.autograd.Function):
+    """part [N, C] on every rank (partial over the rank's local edges)  ->  own rows [n_own, C] of the reduction over
+    ranks (sum | max).  With RCCL this is ONE reduce_scatter_tensor over equal node chunks (half the bytes of the
+    round-1 all-reduce + slice); over gloo (CPU tests) all-reduce + slice.  Backward = the adjoint: an all-gather of the
+    owners' gradient rows (max: only the ranks that attain the maximum keep it -- ties only occur at 0 behind a ReLU,
+    where the ReLU mask removes the gradient anyway)."""
 
     @staticmethod
-    def forward(ctx, x, group):
-        ctx.group = group
-        y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.MAX, group=group)
-        ctx.save_for_backward(x, y)
-        return y
+    def forward(ctx, part, shard_info, op, group, ex):
+        cuts, chunk, rank = shard_info
+        world = len(cuts) - 1
+        N, C = part.shape
+        red = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM
+        ctx.info, ctx.op, ctx.group = shard_info, op, group
+        if _backend_has_reduce_scatter(group):
+            if chunk * world != N:                                   # pad to equal chunks (a few rows at most)
+                padded = part.new_zeros(chunk * world, C) if op != "max" else part.new_full((chunk * world, C), float("-inf"))
+                padded[:N] = part
+            else:
+                padded = part
+            out = part.new_empty(chunk, C)
+            work = dist.reduce_scatter_tensor(out, padded, op=red, group=group, async_op=ex is not None)
+            if ex is not None:
+                ex.work = work
+            own = out[: cuts[rank + 1] - cuts[rank]]
+        else:
+            full = part.clone()
+            dist.all_reduce(full, op=red, group=group)
+            own = full[cuts[rank]: cuts[rank + 1]]
+        if op == "max":
+            ctx.save_for_backward(part, own)
+        return own
 
     @staticmethod
     def backward(ctx, g):
-        x, y = ctx.saved_tensors
-        g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g * (x == y), None
+        cuts, chunk, rank = ctx.info
+        world = len(cuts) - 1
+        N = cuts[-1]
+        C = g.shape[1]
+        g = g.contiguous()
+        n_own = cuts[rank + 1] - cuts[rank]
+        if ctx.op == "max":
+            part, own = ctx.saved_tensors
+            payload = torch.cat((g, own), dim=1)                     # the owners' gradient AND maximum travel together
+        else:
+            payload = g
+        W = payload.shape[1]
+        if _backend_has_reduce_scatter(ctx.group):
+            mine = payload if n_own == chunk else torch.cat((payload, payload.new_zeros(chunk - n_own, W)))
+            full = payload.new_empty(chunk * world, W)
+            dist.all_gather_into_tensor(full, mine.contiguous(), group=ctx.group)
+            full = full[:N]
+        else:
+            full = payload.new_zeros(N, W)
+            full[cuts[rank]: cuts[rank + 1]] = payload
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=ctx.group)
+        if ctx.op == "max":
+            return full[:, :C] * (part == full[:, C:]), None, None, None, None
+        return full, None, None, None, None
+
+
+def reduce_scatter_rows(part, shard, op, group, ex=None):
+    return _ReduceScatterRows.apply(part, (shard.node_cuts, shard.node_chunk, shard.rank), op, group, ex)
 
 
 class _AllGatherRows(torch.autograd.Function):
-    """[n_own, D] per rank -> [N, D] everywhere (ranges from node_cuts); backward = the
-    sum over ranks of the gradient rows this rank owns."""
+    """[n_own, D] per rank -> [N, D] everywhere (equal node chunks: one all_gather_into_tensor, no per-rank padding
+    lists, no torch.cat); backward = the sum over ranks of the gradient rows this rank owns (reduce-scatter)."""
 
     @staticmethod
-    def forward(ctx, x, cuts, rank, group):
+    def forward(ctx, x, shard_info, group):
+        cuts, chunk, rank = shard_info
         world = len(cuts) - 1
-        width = max(cuts[r + 1] - cuts[r] for r in range(world))
-        pad = torch.zeros(width, x.shape[1], dtype=x.dtype, device=x.device)
-        pad[: x.shape[0]] = x
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        ctx.cuts, ctx.rank, ctx.group = cuts, rank, group
-        return torch.cat([parts[r][: cuts[r + 1] - cuts[r]] for r in range(world)], dim=0)
+        N, D = cuts[-1], x.shape[1]
+        ctx.info, ctx.group = shard_info, group
+        if dist.get_backend(group) == "gloo":                       # CPU tests: list form
+            pad = torch.zeros(chunk, D, dtype=x.dtype, device=x.device)
+            pad[: x.shape[0]] = x
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad, group=group)
+            return torch.cat(parts, dim=0)[:N]
+        mine = x if x.shape[0] == chunk else torch.cat((x, x.new_zeros(chunk - x.shape[0], D)))
+        full = x.new_empty(chunk * world, D)
+        dist.all_gather_into_tensor(full, mine.contiguous(), group=group)
+        return full[:N]
 
     @staticmethod
     def backward(ctx, g):
+        cuts, chunk, rank = ctx.info
+        world = len(cuts) - 1
+        N, D = cuts[-1], g.shape[1]
+        n_own = cuts[rank + 1] - cuts[rank]
+        if _backend_has_reduce_scatter(ctx.group):
+            padded = g.contiguous() if chunk * world == N else torch.cat((g, g.new_zeros(chunk * world - N, D)))
+            out = g.new_empty(chunk, D)
+            dist.reduce_scatter_tensor(out, padded, op=dist.ReduceOp.SUM, group=ctx.group)
+            return out[:n_own], None, None
         g = g.contiguous().clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g[ctx.cuts[ctx.rank]: ctx.cuts[ctx.rank + 1]], None, None, None
+        return g[cuts[rank]: cuts[rank + 1]], None, None
 
 
 class _SyncBatchNorm(torch.autograd.Function):
@@ -231,32 +316,49 @@ class ShardedSupernet:
             out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
         return out
 
-    def _aggregate(self, op, name, x):
-        """a_max / a_sum / a_mean on a shard: local partial over local edges -> all-reduce ->
-        own node rows (+ residual self rows)  (reference models/operations_lp.py:223-264)."""
+    def _partials(self, mixed_op, take):
+        """The rank-local halves of a middle MixedOp (reference models/operations_lp.py:223-264): per candidate the
+        partial [N, D] over the LOCAL in-edges and the residual self rows; a_sum's and a_mean's partials are summed by
+        the same collective, so they are concatenated to one [N, 2D] tensor."""
         s, E = self.s, self.s.num_edges()
-        hip = x.is_cuda and getattr(self.k, "linear_relu_partial", None) is not None
-        self_rows = None
-        if name == "a_sum":
-            if hip:                                       # one autograd node for the edge part and the residual rows
-                part, self_rows = self.k.sum_partial(x, s)
+        out = {}
+        for name, (op, _, _) in zip(OPS.MIDDLE_OPS, mixed_op._ops):
+            x = take()
+            hip = x.is_cuda and getattr(self.k, "linear_relu_partial", None) is not None
+            if name == "a_sum":
+                part, self_rows = self.k.sum_partial(x, s) if hip else (self.k.seg_reduce("sum", x[:E], None, s), x[E:])
             else:
-                part = self.k.seg_reduce("sum", x[:E], None, s)
-            h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
-            h = op.drop_sum(h)
-        else:
-            kind = "max" if name == "a_max" else "sum"
-            if hip:
-                part, self_rows = self.k.linear_relu_partial(kind, x, op.linear.weight, op.linear.bias, s)
-            else:
-                m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
-                part = self.k.seg_reduce(kind, m, None, s)
-            if name == "a_max":
-                h = _AllReduceMax.apply(part, self.group)[s.node_lo:s.node_hi]
-            else:
-                h = _AllReduceSum.apply(part, self.group, True)[s.node_lo:s.node_hi]
-                h = h * self._inv_degree()
-        return h + (self_rows if self_rows is not None else x[E:])
+                kind = "max" if name == "a_max" else "sum"
+                if hip:
+                    part, self_rows = self.k.linear_relu_partial(kind, x, op.linear.weight, op.linear.bias, s)
+                else:
+                    m = self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu")
+                    part, self_rows = self.k.seg_reduce(kind, m, None, s), x[E:]
+            out[name] = (part, self_rows)
+        return out
+
+    def _exchange_start(self, parts):
+        """Launch the two collectives of one middle MixedOp: reduce-scatter(max) of a_max's partial and ONE
+        reduce-scatter(sum) of [a_sum | a_mean] (batch the aggregators of a MixedOp).  Asynchronous on RCCL's
+        stream when the tensors are on the GPU: the caller goes on with independent work and calls _exchange_finish."""
+        s = self.s
+        async_ok = parts["a_max"][0].is_cuda
+        ex_max, ex_sum = (Exchange(), Exchange()) if async_ok else (None, None)
+        h_max = reduce_scatter_rows(parts["a_max"][0], s, "max", self.group, ex_max)
+        both = torch.cat((parts["a_sum"][0], parts["a_mean"][0]), dim=1)
+        h_both = reduce_scatter_rows(both, s, "sum", self.group, ex_sum)
+        return h_max, h_both, (ex_max, ex_sum)
+
+    def _exchange_finish(self, mixed_op, parts, started):
+        h_max, h_both, exs = started
+        for ex in exs:
+            if ex is not None:
+                ex.wait()                                  # the current stream waits for RCCL's; no host synchronisation
+        D = h_max.shape[1]
+        ys = {"a_max": h_max + parts["a_max"][1],
+              "a_sum": mixed_op._ops[OPS.MIDDLE_OPS.index("a_sum")][0].drop_sum(h_both[:, :D]) + parts["a_sum"][1],
+              "a_mean": h_both[:, D:] * self._inv_degree() + parts["a_mean"][1]}
+        return [ys[name] for name in OPS.MIDDLE_OPS]
 
     def _inv_degree(self):
         """1 / max(in-degree, 1) of the own node rows over the WHOLE graph, [n_own, 1] (computed once)."""
@@ -268,20 +370,28 @@ class ShardedSupernet:
     def _stat_group(self):
         return self.group if self.group is not None else dist.group.WORLD
 
-    def _mixed_middle(self, mixed_op, w, h, total_nodes):
-        if isinstance(h, K.Fan):
-            hs = h
-            h = hs.x
-            take = hs.take
-        else:
-            take = lambda: h
-        if h.is_cuda:
-            ys = [self._aggregate(op, name, take()) for name, (op, _, _) in zip(OPS.MIDDLE_OPS, mixed_op._ops)]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in mixed_op._ops], w, self._stat_group(), total_nodes)
-        out = 0
-        for wk, name, (op, bn, act) in zip(w, OPS.MIDDLE_OPS, mixed_op._ops):
-            out = out + wk * act(sync_batch_norm(self._aggregate(op, name, h), bn, total_nodes, self.group))
-        return out
+    def _middle_stage(self, cell, wm, states, total_nodes):
+        """Cell_Middle over a shard: the partials of every MixedOp are computed first and each exchange is launched as
+        soon as its partials exist, so the collectives of MixedOp i overlap the edge-parallel GEMMs of MixedOp i + 1."""
+        started = []
+        for i in range(cell.n_first):
+            h = states[i]
+            take = h.take if isinstance(h, K.Fan) else (lambda h=h: h)
+            parts = self._partials(cell.cell_middle._ops[i], take)
+            started.append((parts, self._exchange_start(parts)))
+        outs = []
+        for i, (parts, st) in enumerate(started):
+            mixed_op = cell.cell_middle._ops[i]
+            ys = self._exchange_finish(mixed_op, parts, st)
+            bns = [bn for _, bn, _ in mixed_op._ops]
+            if ys[0].is_cuda:
+                outs.append(K.mixed_epilogue(ys, bns, wm[i], self._stat_group(), total_nodes))
+            else:
+                out = 0
+                for wk, y, (_, bn, act) in zip(wm[i], ys, mixed_op._ops):
+                    out = out + wk * act(sync_batch_norm(y, bn, total_nodes, self.group))
+                outs.append(out)
+        return outs
 
     def _cell(self, cell, x, hr, wz, wf, wm, wl):
         M, N = self.rows_total, self.s.number_of_nodes()
@@ -292,7 +402,7 @@ class ShardedSupernet:
             sN = _tsum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
             off += len(states)
             states.append(fan(sN))
-        states = [fan(self._mixed_middle(cell.cell_middle._ops[i], wm[i], states[1 + i], N)) for i in range(cell.n_first)]
+        states = [fan(y) for y in self._middle_stage(cell, wm, states[1:], N)]
         off = 0
         for _ in range(cell.n_last):
             sN = _tsum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
@@ -316,7 +426,7 @@ class ShardedSupernet:
             if l > 0 or m._layers == 1:
                 own = F.relu(own)
             own = F.dropout(own, m._dropout, training=m.training)
-            ent = _AllGatherRows.apply(own, s.node_cuts, s.rank, self.group)
+            ent = _AllGatherRows.apply(own, (s.node_cuts, s.node_chunk, s.rank), self.group)
             rel = torch.matmul(rel, m.w_rel)
         return ent, rel
 

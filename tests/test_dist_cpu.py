@@ -33,6 +33,36 @@ def test_relation_block_cuts_balanced_and_group_aligned():
     assert MD.relation_block_cuts(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 3) == [0, 0, 0, 0]
 
 
+def test_world8_partition_of_the_wn18rr_shape():
+    """BASELINE config 3's skew: 11 relations (22 directed ids), the two largest hold about half of the triples.  An
+    8-way relation-block partition must stay balanced (relations bigger than E / 8 are split by dst range), never cut
+    a (relation, dst) group, keep [in-edges | out-edges] contiguous per shard, and cover every edge exactly once."""
+    from mr_gnas_amd import graph as G, synth
+    n, r, t = synth.SHAPES["wn18rr"]
+    tri = synth.synth_kg(n, r, t, 0)
+    g = G.build_search_graph(n, r, tri)
+    src, dst, _ = g.edges(form="all")
+    et = g.edata["e_type"]
+    hist = np.bincount(et.numpy(), minlength=2 * r)
+    assert hist.max() > g.num_edges() / 8                        # at least one relation alone exceeds a rank's share
+    seen = np.zeros(g.num_edges(), dtype=np.int64)
+    sizes = []
+    for rank in range(8):
+        sh = MD.EdgeShard(n, src, dst, et, g.edata["norm"], r, rank, 8, "cpu")
+        ids = sh.global_edge_ids.numpy()
+        seen[ids] += 1
+        sizes.append(len(ids))
+        e = sh.edata["e_type"].numpy()
+        b0, b1 = sh.bounds()
+        assert (e[:b0] < r).all() and (e[b0:] >= r).all() and b1 == len(ids)     # [original | inverse] halves stay contiguous
+        assert sh.node_hi - sh.node_lo <= sh.node_chunk and sh.node_cuts[-1] == n
+    assert (seen == 1).all()
+    assert max(sizes) <= 1.1 * g.num_edges() / 8, sizes
+    cuts, chunk = MD.node_chunks(n, 8)
+    assert chunk * 8 >= n and cuts[0] == 0 and cuts[-1] == n and all(b - a in (chunk, n - 7 * chunk) for a, b in zip(cuts, cuts[1:]))
+    assert MD.node_chunks(5, 8) == ([0, 1, 2, 3, 4, 5, 5, 5, 5], 1) and MD.node_chunks(0, 3) == ([0, 0, 0, 0], 0)
+
+
 def _worker(rank, world, port, case, out):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_kernels as CK
