@@ -91,7 +91,16 @@ class _Compose(torch.autograd.Function):
 
 
 def compose(kind, s, hr):
-    """s (*|-|+) hr on [rows, D] (reference models/operations_lp.py:71-98)."""
+    """s (*|-|+) hr on [rows, D] (reference models/operations_lp.py:71-98).  When both operands are LazyRows -- rows of the
+    entity / relation tables that nobody has materialised (the gather G feeding the cell's first stage, reference
+    models/model_search_lp.py:135-145) -- gather and compose run as ONE kernel forward and as two balanced segmented sums
+    per operand backward: no [M, D] gather output, no [M, D] operand gradients."""
+    if isinstance(s, LazyRows) and isinstance(hr, LazyRows):
+        return _GatherCompose.apply(COMPOSE[kind], s.table, hr.table, s.gp, hr.gp)
+    if isinstance(s, LazyRows):
+        s = s.materialize()
+    if isinstance(hr, LazyRows):
+        hr = hr.materialize()
     return _Compose.apply(COMPOSE[kind], s, hr)
 
 
@@ -560,6 +569,75 @@ class _Gather(torch.autograd.Function):
 def gather(table, gp):
     """table[gp.idx] with autograd (reference models/model_lp.py:131, models/model_search_lp.py:144-145,153-154)."""
     return _Gather.apply(table, gp)
+
+
+class LazyRows:
+    """``table[gp.idx]`` not yet materialised: what the supernet hands to the cell's first stage, whose three compose
+    candidates then gather on the fly (compose above).  Anything else that needs the rows calls materialize()."""
+
+    def __init__(self, table, gp):
+        self.table, self.gp = table, gp
+        self._rows = None
+
+    is_cuda = property(lambda self: self.table.is_cuda)
+    device = property(lambda self: self.table.device)
+    requires_grad = property(lambda self: self.table.requires_grad)
+    shape = property(lambda self: (int(self.gp.idx32.numel()), int(self.table.shape[1])))
+
+    def materialize(self):
+        if self._rows is None:
+            self._rows = gather(self.table, self.gp)
+        return self._rows
+
+
+def _pair_meta(gp_a, gp_b):
+    """Packed metadata of the MUL backward of a fused gather-compose, segments = gp_a's table rows: element e carries
+    its own index (the upstream gradient row) and gp_b's table row as the second operand.  Cached on gp_a per partner."""
+    cache = gp_a.__dict__.setdefault("_pair", {})
+    m = cache.get(id(gp_b))
+    if m is None:
+        from .graph import settle, span_meta
+        m = cache[id(gp_b)] = (span_meta(gp_a.sp, None, gp_b.idx32), gp_b)      # keeps the partner alive: id() stays unique
+        settle(gp_a.idx.device)
+    return m[0]
+
+
+class _GatherCompose(torch.autograd.Function):
+    """out[i] = ent[ie[i]] (op) rel[ir[i]]  (G + a1: reference models/model_search_lp.py:135-145 + models/operations_lp.py:71-98).
+    Backward: gradients of the TABLES, each a balanced segmented sum over the rows that read a table row
+    (mrg_span_gcs: COPY / NEGS for sub and add, MUL with the other table's row for mult)."""
+
+    @staticmethod
+    def forward(ctx, op, ent, rel, gp_e, gp_r):
+        ent, rel = f32c(ent), f32c(rel)
+        require_hip(ent, rel)
+        rows, D = int(gp_e.idx32.numel()), ent.shape[1]
+        if int(gp_r.idx32.numel()) != rows or rel.shape[1] != D:
+            raise _lib.MrgnasError("gather-compose: the two index lists / tables do not match")
+        out = torch.empty(rows, D, dtype=torch.float32, device=ent.device)
+        call("mrg_gather_compose_fwd", (op, ptr(ent), ptr(rel), ptr(gp_e.idx32), ptr(gp_r.idx32), ptr(out), rows, D, stream_of(ent)),
+             nbytes=rows * (12 * D + 8))
+        ctx.op, ctx.gp = op, (gp_e, gp_r)
+        ctx.save_for_backward(*((ent, rel) if op == 0 else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = f32c(g)
+        gp_e, gp_r = ctx.gp
+        g_ent = g_rel = None
+        if ctx.op == 0:                                     # mult
+            ent, rel = ctx.saved_tensors
+            if ctx.needs_input_grad[1]:
+                g_ent = span_gcs("mul", g, rel, _pair_meta(gp_e, gp_r), gp_e.sp)
+            if ctx.needs_input_grad[2]:
+                g_rel = span_gcs("mul", g, ent, _pair_meta(gp_r, gp_e), gp_r.sp)
+        else:                                               # sub / add
+            if ctx.needs_input_grad[1]:
+                g_ent = span_gcs("copy", g, None, gp_e.meta, gp_e.sp)
+            if ctx.needs_input_grad[2]:
+                g_rel = span_gcs("negs" if ctx.op == 1 else "copy", g, None, gp_r.meta, gp_r.sp)
+        return None, g_ent, g_rel, None, None
 
 
 # ---------------------------------------------------------------------------

@@ -74,10 +74,15 @@ class MixedOp(nn.Module):
         BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
         materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
         if not (h.x if isinstance(h, K.Fan) else h).is_cuda:    # reference formulation (registry of non-HIP test operators)
+            if isinstance(h, K.LazyRows):
+                h, h_in = h.materialize(), h_in.materialize()
             total = 0
             for w, (op, bn, act) in zip(weights, self._ops):
                 total = total + w * act(bn(op(g, h, h_in).float()))
             return total
+        if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
+            ys = [op(g, h, h_in) for op, _, _ in self._ops]
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
         # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
         # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
         n = len(self._ops)
@@ -219,8 +224,9 @@ class SearchNetwork(nn.Module):
         ent = None
         for l, cell in enumerate(self.cells):
             wz, wf, wm, wl = self.layer_weights(l)
-            x = K.gather(ent_all, p_ent) if l == 0 else K.gather(ent, p_in)
-            ent = self.batchnorm_h(cell(g_train, x, K.gather(rel, p_rel), wz, wf, wm, wl))
+            # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
+            x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
+            ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
             if l > 0 or self._layers == 1:
                 ent = F.relu(ent)
             ent = F.dropout(ent, self._dropout, training=self.training)
