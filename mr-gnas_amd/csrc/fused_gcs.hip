@@ -235,15 +235,21 @@ namespace mrg {
 #ifndef MRG_SPAN_UM
 #define MRG_SPAN_UM 4
 #endif
-template <int MODE> struct SPAN_U { static constexpr int value = MODE == MRG_GCS_SUB ? 8 : (MODE == MRG_GCS_MUL ? MRG_SPAN_UM : MRG_SPAN_U1); };
+#ifndef MRG_SPAN_US
+#define MRG_SPAN_US 8
+#endif
+template <int MODE> struct SPAN_U { static constexpr int value = MODE == MRG_GCS_SUB ? MRG_SPAN_US : (MODE == MRG_GCS_MUL ? MRG_SPAN_UM : MRG_SPAN_U1); };
 
-template <int VEC, int LPR, int KMAX, int MODE>
+template <int VEC, int LPR, int KMAX, int MODE, int UOVR = 0>
 __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict__ X, const float* __restrict__ Y,
                                                         const int4* __restrict__ meta, const float* __restrict__ ext_scal,
                                                         int64_t E, int span, const int32_t* __restrict__ span_slot,
                                                         int64_t n_spans, float* __restrict__ out, float* __restrict__ ws_val, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  constexpr int U = SPAN_U<MODE>::value;      // elements whose row gathers are in flight per lane group
+  // elements whose row gathers are in flight per lane group.  UOVR (sub mode on big inputs): 6 instead of 8 -- measured on the
+  // C5 shape (10 M elements, 1 GB table, D = 256) 2.13 ms against 2.42 ms, while the cache-resident FB15k-237 shape prefers 8
+  // (91.7 us against 97.5 us): tools/ns_sweep.py
+  constexpr int U = UOVR > 0 ? UOVR : SPAN_U<MODE>::value;
   constexpr bool NY = NeedsY<MODE>::value;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
@@ -340,7 +346,11 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
   do {                                                                                                                 \
     int grid = grid_for(n_spans, MRG_BLOCK / L);                                                                       \
     if (E > 0 && n_spans > 0) switch (mode) {                                                                          \
-      case MRG_GCS_SUB: LAUNCH(V, L, K, MRG_GCS_SUB); break;                                                           \
+      case MRG_GCS_SUB:                                                                                                \
+        if (E >= ((int64_t)1 << 22))                                                                                   \
+          hipLaunchKernelGGL((span_gcs_k<V, L, K, MRG_GCS_SUB, 6>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, n_spans, out, ws_val, D); \
+        else LAUNCH(V, L, K, MRG_GCS_SUB);                                                                             \
+        break;                                                                                                         \
       case MRG_GCS_MUL: LAUNCH(V, L, K, MRG_GCS_MUL); break;                                                           \
       case MRG_GCS_COPY: LAUNCH(V, L, K, MRG_GCS_COPY); break;                                                         \
       default: LAUNCH(V, L, K, MRG_GCS_NEGS); break;                                                                   \

@@ -37,7 +37,9 @@ def _cnt(plan, name):
     """Launch-side count of a plan: the host-known capacity when the plan has one (HIP-built plans pad with -1 and the
     kernels skip the padding: no device-to-host read), else the exact number."""
     cap = "cap_" + name
-    return plan[cap] if cap in plan else plan["n_" + name]
+    if cap in plan and not (hasattr(plan, "try_resolve") and plan.try_resolve()):
+        return plan[cap]                         # exact sizes still on their way to the host: launch over the padded capacity
+    return plan["n_" + name]
 
 
 def _ws(nbytes, like):

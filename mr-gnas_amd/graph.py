@@ -102,12 +102,31 @@ class _Plan(dict):
     def __init__(self, items, counts, names):
         super().__init__(items)
         self._counts, self._names = counts, names
+        # the counts also travel to pinned host memory right behind the build: once that copy has landed (checked with a
+        # non-blocking event query) launches switch from the padded capacity to the exact sizes without ever waiting
+        self._host = torch.empty(len(names), dtype=torch.int32, pin_memory=True)
+        self._host.copy_(counts, non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream(counts.device))
 
     def _resolve(self):
         if self._counts is not None:
-            for n, v in zip(self._names, self._counts.tolist()):        # the only host synchronisation of a plan build
+            if self._ev.query():
+                vals = self._host.tolist()
+            else:
+                vals = self._counts.tolist()                            # explicit request for exact sizes: the one host wait
+            for n, v in zip(self._names, vals):
                 dict.__setitem__(self, n, int(v))
-            self._counts = None
+            self._counts = self._host = self._ev = None
+
+    def try_resolve(self):
+        """True when the exact sizes are known without waiting (resolving them on the way if their copy has landed)."""
+        if self._counts is None:
+            return True
+        if self._ev.query():
+            self._resolve()
+            return True
+        return False
 
     def __getitem__(self, k):
         if self._counts is not None and k in self._names:
