@@ -213,6 +213,12 @@ def north_star_kernel(g, dim, reps=50, tag="fb15k237"):
     nbytes = st["bytes"] / st["launches"]
     compulsory = E * 16 + 4 * dim * (N + Rp + 2 * N)
     traffic = load_traffic("north_star:" + tag)
+    if tag != "c5_synthetic10m":
+        # calibration point of the PMC traffic passes (tools/traffic_from_pmc.py): one streaming launch of known size,
+        # 12 * D * (E + N) bytes (the step itself no longer launches mrg_compose_fwd since the gather was folded into it)
+        a_ = torch.empty(E + N, dim, device=dev)
+        K.compose("sub", a_, a_.clone())
+        del a_
     del cp, ent, rel
     return {"kernel": "mrg_span_gcs (CompGCN aggregation, compose=sub)", "graph": tag, "bound": "hbm", "edges": E, "segments": 2 * N,
             "dim": dim, "node_table_MB": round(4 * dim * N / 1e6, 1),
