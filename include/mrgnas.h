@@ -100,6 +100,21 @@ int mrg_gather_compose_fwd(int op, const float *ent, const float *rel,
  *   W [D, in_dim] (nn.Linear weight), b [D] or NULL, a [D] (nn.Linear(D,1).weight). */
 int mrg_gate_collapse(const float *W, const float *b, const float *a, float *uvc,
                       int D, int in_dim, void *stream);
+/* Batched forms over the three direction segments (in, out, self) of one operator -- one launch instead of three: *_host are
+ * HOST arrays of 3 device pointers, NULL for an absent segment; uvc / d_uvc are [3][MRG_GATE_LD(D)].
+ * fold != 0 (both operands of the operator are the same rows, reference models/cell_lp.py:95-104: op(g, h_in, h_in)): the
+ * parameters are nn.Linear(2D, D) but the gate is u.s + v.s = (u + v).s -- uvc holds u + v at [0, D) and c at index D
+ * (the layout of a gate without a second operand), and the parameter gradient spreads d(u + v) over both weight halves. */
+int mrg_gate_collapse3(const float *const *W_host, const float *const *b_host, const float *const *a_host, float *uvc,
+                       int D, int in_dim, int fold, void *stream);
+int mrg_gate_param_grad3(const float *const *W_host, const float *const *b_host, const float *const *a_host,
+                         const float *d_uvc, float *const *gW_host, float *const *gb_host, float *const *ga_host,
+                         int D, int in_dim, int fold, void *stream);
+/* The same fold for the dense filters: Wt [3][D][D], Wt_i = W_i[:, :D] + W_i[:, D:] (W_i is [D][2D]); and its adjoint
+ * gW_i = [gWt_i | gWt_i] (gWt_host: 3 device pointers to [D][D]; a NULL source gives a zero gradient). */
+int mrg_fold_halves3(const float *const *W_host, float *Wt, int D, void *stream);
+int mrg_unfold_halves3(const float *const *gWt_host, float *const *gW_host, int D, void *stream);
+
 /* out[i,:] = sigmoid(u_x.s_i + v_x.s_in_i + c_x) * s_i * scale * (i < b1 ? norm[i] : 1)
  *   x = segment of row i (0: i < b0, 1: b0 <= i < b1, 2: i >= b1)
  *   uvc  [3][MRG_GATE_LD(D)]  (u, v, c per segment); s_in NULL => v ignored (f_sparse_last)

@@ -36,6 +36,10 @@ SIGNATURES = {
     "mrg_compose_bwd": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_gather_compose_fwd": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_gate_collapse": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mrg_gate_collapse3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "mrg_gate_param_grad3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mrg_fold_halves3": (_I, [_P, _P, _I, _P]),
+    "mrg_unfold_halves3": (_I, [_P, _P, _I, _P]),
     "mrg_gate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),
     "mrg_gate_bwd_workspace_bytes": (_L, [_L, _I]),
     "mrg_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),

@@ -248,6 +248,91 @@ __global__ void gate_param_grad_k(const float* __restrict__ W, const float* __re
 
 using namespace mrg;
 
+// ---- batched forms: the three direction segments of an operator in ONE launch each, with the "both operands are the same
+// rows" fold built in (fold != 0: the nn.Linear parameters have in_dim = 2D, the gate sees u + v and c at index D) --------
+struct Ptr3 { const float* p[3]; };
+struct MPtr3 { float* p[3]; };
+
+__global__ void gate_collapse3_k(Ptr3 W, Ptr3 b, Ptr3 a, float* __restrict__ uvc, int D, int in_dim, int fold) {
+  __shared__ float part[16][64];
+  const int seg = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + tx;
+  const int width = fold ? D : in_dim;                       // columns of the collapsed vector before the constant
+  float* out = uvc + (int64_t)seg * MRG_GATE_LD(D);
+  const float* Ws = W.p[seg];
+  const float* as = a.p[seg];
+  const float* bs = b.p[seg];
+  float acc = 0.f;
+  if (Ws != nullptr) {
+    if (k < width) {
+      for (int j = ty; j < D; j += 16) {
+        float w = Ws[(int64_t)j * in_dim + k];
+        if (fold) w += Ws[(int64_t)j * in_dim + k + D];
+        acc += w * as[j];
+      }
+    } else if (k == width && bs) {
+      for (int j = ty; j < D; j += 16) acc += as[j] * bs[j];
+    }
+  }
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && k <= width) {
+    float tot = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tot += part[i][tx];
+    out[k] = tot;
+  }
+}
+
+// one block per (output row j of W, segment)
+__global__ void gate_param_grad3_k(Ptr3 W, Ptr3 b, Ptr3 a, const float* __restrict__ d_uvc, MPtr3 gW, MPtr3 gb, MPtr3 ga, int D, int in_dim,
+                                   int fold) {
+  __shared__ float part[MRG_BLOCK / MRG_WAVE];
+  const int seg = blockIdx.y, j = blockIdx.x;
+  const float* Ws = W.p[seg];
+  if (Ws == nullptr) return;
+  const float* d = d_uvc + (int64_t)seg * MRG_GATE_LD(D);
+  const float aj = a.p[seg][j];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < in_dim; k += blockDim.x) {
+    const float dk = d[fold ? (k < D ? k : k - D) : k];
+    gW.p[seg][(int64_t)j * in_dim + k] = aj * dk;
+    acc += Ws[(int64_t)j * in_dim + k] * dk;
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < MRG_BLOCK / MRG_WAVE; ++w) tot += part[w];
+    const float dc = d[fold ? D : in_dim];
+    ga.p[seg][j] = tot + (b.p[seg] ? b.p[seg][j] * dc : 0.f);
+    if (gb.p[seg]) gb.p[seg][j] = aj * dc;
+  }
+}
+
+// Wt_i = W_i[:, :D] + W_i[:, D:]   /   gW_i = [gWt_i | gWt_i]   (dense filters whose two operands are the same rows)
+__global__ void fold_halves3_k(Ptr3 W, float* __restrict__ Wt, int D) {
+  const int seg = blockIdx.y;
+  const float* Ws = W.p[seg];
+  if (Ws == nullptr) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * D; i += gridDim.x * blockDim.x) {
+    const int r = i / D, c = i - r * D;
+    Wt[(int64_t)seg * D * D + i] = Ws[(int64_t)r * 2 * D + c] + Ws[(int64_t)r * 2 * D + D + c];
+  }
+}
+__global__ void unfold_halves3_k(Ptr3 gWt, MPtr3 gW, int D) {
+  const int seg = blockIdx.y;
+  float* g = gW.p[seg];
+  const float* src = gWt.p[seg];
+  if (g == nullptr) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * 2 * D; i += gridDim.x * blockDim.x) {
+    const int r = i / (2 * D), c = i - r * 2 * D;
+    g[i] = src ? src[(int64_t)r * D + (c < D ? c : c - D)] : 0.f;
+  }
+}
+
 extern "C" int mrg_gate_collapse(const float* W, const float* b, const float* a, float* uvc, int D, int in_dim, void* stream) {
   if (!W || !a || !uvc) return MRG_E_NULLPTR;
   if (D <= 0 || in_dim <= 0) return MRG_E_SHAPE;
@@ -261,6 +346,51 @@ extern "C" int mrg_gate_param_grad(const float* W, const float* b, const float* 
   if (!W || !a || !d_uvc || !gW || !ga) return MRG_E_NULLPTR;
   if (D <= 0 || in_dim <= 0) return MRG_E_SHAPE;
   hipLaunchKernelGGL(gate_param_grad_k, dim3(D), dim3(MRG_BLOCK), 0, (hipStream_t)stream, W, b, a, d_uvc, gW, gb, ga, D, in_dim);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+static Ptr3 ptr3(const float* const* h) { Ptr3 p; for (int i = 0; i < 3; ++i) p.p[i] = h ? h[i] : nullptr; return p; }
+static MPtr3 mptr3(float* const* h) { MPtr3 p; for (int i = 0; i < 3; ++i) p.p[i] = h ? h[i] : nullptr; return p; }
+
+extern "C" int mrg_gate_collapse3(const float* const* W_host, const float* const* b_host, const float* const* a_host, float* uvc, int D,
+                                  int in_dim, int fold, void* stream) {
+  if (!W_host || !a_host || !uvc) return MRG_E_NULLPTR;
+  if (D <= 0 || in_dim <= 0 || (fold && in_dim != 2 * D)) return MRG_E_SHAPE;
+  for (int i = 0; i < 3; ++i)
+    if (W_host[i] && !a_host[i]) return MRG_E_NULLPTR;
+  const int width = fold ? D : in_dim;
+  hipLaunchKernelGGL(gate_collapse3_k, dim3((width + 1 + 63) / 64, 3), dim3(1024), 0, (hipStream_t)stream, ptr3(W_host), ptr3(b_host), ptr3(a_host),
+                     uvc, D, in_dim, fold);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_gate_param_grad3(const float* const* W_host, const float* const* b_host, const float* const* a_host, const float* d_uvc,
+                                    float* const* gW_host, float* const* gb_host, float* const* ga_host, int D, int in_dim, int fold, void* stream) {
+  if (!W_host || !a_host || !d_uvc || !gW_host || !ga_host) return MRG_E_NULLPTR;
+  if (D <= 0 || in_dim <= 0 || (fold && in_dim != 2 * D)) return MRG_E_SHAPE;
+  for (int i = 0; i < 3; ++i)
+    if (W_host[i] && (!a_host[i] || !gW_host[i] || !ga_host[i])) return MRG_E_NULLPTR;
+  hipLaunchKernelGGL(gate_param_grad3_k, dim3(D, 3), dim3(MRG_BLOCK), 0, (hipStream_t)stream, ptr3(W_host), ptr3(b_host), ptr3(a_host), d_uvc,
+                     mptr3(gW_host), mptr3(gb_host), mptr3(ga_host), D, in_dim, fold);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_fold_halves3(const float* const* W_host, float* Wt, int D, void* stream) {
+  if (!W_host || !Wt) return MRG_E_NULLPTR;
+  if (D <= 0) return MRG_E_SHAPE;
+  hipLaunchKernelGGL(fold_halves3_k, dim3((D * D + 255) / 256 < 64 ? (D * D + 255) / 256 : 64, 3), dim3(256), 0, (hipStream_t)stream, ptr3(W_host), Wt, D);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_unfold_halves3(const float* const* gWt_host, float* const* gW_host, int D, void* stream) {
+  if (!gWt_host || !gW_host) return MRG_E_NULLPTR;
+  if (D <= 0) return MRG_E_SHAPE;
+  hipLaunchKernelGGL(unfold_halves3_k, dim3((2 * D * D + 255) / 256 < 128 ? (2 * D * D + 255) / 256 : 128, 3), dim3(256), 0, (hipStream_t)stream, ptr3(gWt_host),
+                     mptr3(gW_host), D);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

@@ -125,7 +125,8 @@ def gather_rows(table, idx32, rel_table=None, rel_idx32=None, kind=None):
 # ---------------------------------------------------------------------------
 class _Gate(torch.autograd.Function):
     """Parameters come flat, three per row segment (in, out, self): W, b, a -- None for
-    an absent segment."""
+    an absent segment.  The three segments' parameter collapse / parameter gradient are one launch each
+    (mrg_gate_collapse3 / mrg_gate_param_grad3), with the same-rows fold built in."""
 
     @staticmethod
     def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
@@ -136,16 +137,10 @@ class _Gate(torch.autograd.Function):
         M, D = s.shape
         st = stream_of(s)
         in_dim = 2 * D if (s_in is not None or tied) else D     # inner dimension of the nn.Linear parameters
-        uvc = torch.zeros(3, gate_ld(D), dtype=torch.float32, device=s.device)
-        for seg in range(3):
-            W, b, a = params[3 * seg: 3 * seg + 3]
-            if W is not None:
-                call("mrg_gate_collapse", (ptr(W), ptr(b), ptr(a), ptr(uvc[seg]), D, in_dim, st), nbytes=4 * D * in_dim)
-        if tied:
-            folded = torch.zeros_like(uvc)
-            torch.add(uvc[:, :D], uvc[:, D:2 * D], out=folded[:, :D])
-            folded[:, D] = uvc[:, 2 * D]                         # c sits at index D when there is no second operand
-            uvc = folded
+        Ws, bs, as_ = params[0::3], params[1::3], params[2::3]
+        uvc = torch.empty(3, gate_ld(D), dtype=torch.float32, device=s.device)
+        call("mrg_gate_collapse3", (ptr_array(Ws), ptr_array(bs), ptr_array(as_), ptr(uvc), D, in_dim, int(tied), st),
+             nbytes=4 * D * in_dim * sum(W is not None for W in Ws))
         out = torch.empty_like(s)
         nb = 4 * D * M * (3 if s_in is not None else 2) + (4 * b1 if norm is not None else 0)
         call("mrg_gate_fwd", (ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(out), b0, b1, M, D, scale, st), nbytes=nb)
@@ -167,22 +162,14 @@ class _Gate(torch.autograd.Function):
         nb = 4 * D * M * (5 if s_in is not None else 3) + (4 * b1 if norm is not None else 0)
         call("mrg_gate_bwd", (ptr(g), ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(gs), ptr(gs_in), ptr(d_uvc), ptr(ws),
                               b0, b1, M, D, scale, st), nbytes=nb)
-        if tied:                                                 # d(u + v) goes to both halves; c moves back to index 2D
-            full = torch.empty_like(d_uvc)
-            full[:, :D] = d_uvc[:, :D]
-            full[:, D:2 * D] = d_uvc[:, :D]
-            full[:, 2 * D] = d_uvc[:, D]
-            d_uvc = full
+        Ws, bs, as_ = params[0::3], params[1::3], params[2::3]
+        gWs = [None if W is None else torch.empty_like(W) for W in Ws]
+        gbs = [None if b is None else torch.empty_like(b) for b in bs]
+        gas = [None if a is None else torch.empty_like(a) for a in as_]
+        call("mrg_gate_param_grad3", (ptr_array(Ws), ptr_array(bs), ptr_array(as_), ptr(d_uvc), ptr_array(gWs), ptr_array(gbs), ptr_array(gas),
+                                      D, in_dim, int(tied), st), nbytes=8 * D * in_dim * sum(W is not None for W in Ws))
         gparams = []
-        for seg in range(3):
-            W, b, a = params[3 * seg: 3 * seg + 3]
-            if W is None:
-                gparams += [None, None, None]
-                continue
-            gW, ga = torch.empty_like(W), torch.empty_like(a)
-            gb = torch.empty_like(b) if b is not None else None
-            call("mrg_gate_param_grad", (ptr(W), ptr(b), ptr(a), ptr(d_uvc[seg]), ptr(gW), ptr(gb), ptr(ga), D, in_dim, st),
-                 nbytes=8 * D * in_dim)
+        for gW, gb, ga in zip(gWs, gbs, gas):
             gparams += [gW, gb, ga]
         return (gs, gs_in, None, None, None, None, *gparams)
 
@@ -1010,27 +997,29 @@ class _DenseFilter(torch.autograd.Function):
 
 class _FoldHalves(torch.autograd.Function):
     """Wt_i = W_i[:, :D] + W_i[:, D:] for up to three nn.Linear(2D, D) weights (None passes through): the weight an
-    operator sees when both of its operands are the same rows.  Backward: gW_i = [gWt_i | gWt_i]."""
+    operator sees when both of its operands are the same rows.  Backward: gW_i = [gWt_i | gWt_i].  One launch each way
+    (mrg_fold_halves3 / mrg_unfold_halves3)."""
 
     @staticmethod
     def forward(ctx, *Ws):
-        present = [W is not None for W in Ws]
-        ref = next(W for W in Ws if W is not None)
+        Ws = tuple(f32c(W) for W in Ws)
+        Ws3 = (Ws + (None, None, None))[:3]
+        ref = next(W for W in Ws3 if W is not None)
+        require_hip(*Ws3)
         D = ref.shape[0]
-        buf = torch.empty(sum(present), D, D, dtype=ref.dtype, device=ref.device)
-        outs, j = [], 0
-        for W in Ws:
-            if W is None:
-                outs.append(None)
-                continue
-            torch.add(W[:, :D], W[:, D:], out=buf[j])
-            outs.append(buf[j])
-            j += 1
-        return tuple(outs)
+        buf = torch.empty(3, D, D, dtype=torch.float32, device=ref.device)
+        call("mrg_fold_halves3", (ptr_array(Ws3), ptr(buf), D, stream_of(ref)), nbytes=12 * D * D * sum(W is not None for W in Ws3))
+        ctx.meta = (D, [W is not None for W in Ws3], len(Ws), ref.device)
+        return tuple(buf[i] if Ws3[i] is not None else None for i in range(len(Ws)))
 
     @staticmethod
     def backward(ctx, *gs):
-        return tuple(None if g is None else torch.cat((g, g), dim=1) for g in gs)
+        D, present, n, dev = ctx.meta
+        src = [f32c(gs[i]) if (i < n and present[i] and gs[i] is not None) else None for i in range(3)]
+        gWs = [torch.empty(D, 2 * D, dtype=torch.float32, device=dev) if (i < n and present[i]) else None for i in range(3)]
+        ref = next(t for t in gWs if t is not None)
+        call("mrg_unfold_halves3", (ptr_array(src), ptr_array(gWs), D, stream_of(ref)), nbytes=12 * D * D * sum(present))
+        return tuple(gWs[:n])
 
 
 def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_self, b_self, self_scale):
