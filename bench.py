@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fb15k237_supernet_full",
-                    choices=["fb15k237_supernet_full", "fb15k237_supernet_30k", "fb15k237_supernet_300", "wn18rr_supernet_full"])
+                    choices=["fb15k237_supernet_full", "fb15k237_supernet_30k", "fb15k237_supernet_300", "wn18rr_supernet_full",
+                             "fb15k237_fixed_d64"])
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--negative", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +143,42 @@ class Step:
         self.opt.zero_grad(set_to_none=True)
         for a in self.model.arch_parameters():
             a.grad = None
+        self.last_loss = loss.detach()
+
+
+class FixedStep:
+    """BASELINE config 1 on the GPU: one mini-batch step of the fixed README genotype (reference README.md:26,
+    train/mr_lp_train.py:215-266): full training graph (un-sorted halves), feature_dim = init_fea_dim = 64, num_base_r = 23,
+    batch 256, DistMult [B, N] scorer + BCELoss on label-smoothed dense targets (device LabelIndex), Adam."""
+
+    def __init__(self, args, device):
+        from mr_gnas_amd import graph as G, sampler as SM, supernet as S, synth
+        N, R, T = synth.SHAPES["fb15k237"]
+        tri = synth.synth_kg(N, R, T, args.seed)
+        torch.manual_seed(args.seed)
+        self.g = G.build_train_graph(N, R, tri, device=device)
+        self.E = self.g.num_edges()
+        geno = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2), ('a_max', 5, 3),
+                                       ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)], concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+        self.model = S.FixedNetwork(device, geno, N, R, 64, 64, 23, dropout_cell=0.3, drop_aggr=0.1).to(device)
+        S.xavier_init_(self.model)
+        self.model.train()
+        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3)
+        idx = SM.LabelIndex(tri, R, N, device)
+        rng = np.random.default_rng(args.seed + 3)
+        pick = rng.integers(0, T, 256)
+        self.subj = torch.from_numpy(tri[pick, 0]).to(device)
+        self.rel = torch.from_numpy(tri[pick, 1]).to(device)
+        self.idx, self.samples = idx, self.subj                      # `samples` only reports the batch size in the JSON
+        self.last_loss = None
+
+    def __call__(self):
+        labels = self.idx.labels(self.subj, self.rel, 0.1)             # TrainDataset.__getitem__ on the device (label smoothing 0.1)
+        pred = self.model(self.g, self.subj, self.rel)
+        loss = F.binary_cross_entropy(pred, labels)
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
         self.last_loss = loss.detach()
 
 
@@ -343,6 +380,10 @@ def main():
         from mr_gnas_amd import dist as MD
         step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), rank, world)
         barrier = dist.barrier
+    elif args.workload == "fb15k237_fixed_d64":
+        args.dim = 64
+        step = FixedStep(args, device)
+        barrier = lambda: None
     else:
         step = Step(args, device, build_step_inputs(args.workload, args.negative, args.seed))
         barrier = lambda: None
@@ -440,7 +481,12 @@ def main():
                            "timed_in": "the timed steps" if live else "the instrumented single-stream step before them",
                            "share_of_step": round(d["ms_total"] / (ms_per_step * (args.steps if live else 1)), 4)}
     out["kernels"] = table
-    if world == 1 and not sharded and not args.exact_f32 and not args.no_exact_f32_leg and not args.hip_graph:
+    fixed = args.workload == "fb15k237_fixed_d64"
+    if fixed:
+        out["metric"] = "million edges/sec per fixed-genotype train step (FB15k-237, dim=64, batch 256)"
+        out["config"]["layers"] = 1
+        out["config"]["step"] = "fixed README genotype fwd + DistMult [B,N] + BCE + bwd + Adam"
+    if world == 1 and not sharded and not args.exact_f32 and not args.no_exact_f32_leg and not args.hip_graph and not fixed:
         # the same step with every GEMM on the exact-f32 MFMA pipe (v_mfma_f32_32x32x2_f32), next to the headline number
         lib.mrg_gemm_set_mode(1)
         step()
@@ -461,7 +507,7 @@ def main():
             if free_b > 60 * 2**30:
                 log("... and at the C5 shape (10 M edges, 1 M nodes, D = 256)")
                 out["north_star_kernel_c5"] = north_star_c5(device)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not fixed:
         state = step.model.state_dict()
         log("timing the CPU oracle on the bounded sample")
         out["cpu_baseline"] = cpu_baseline(args, state, step.model.arch_parameters())
