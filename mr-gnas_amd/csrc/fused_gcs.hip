@@ -355,11 +355,7 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
       case MRG_GCS_COPY: LAUNCH(V, L, K, MRG_GCS_COPY); break;                                                         \
       default: LAUNCH(V, L, K, MRG_GCS_NEGS); break;                                                                   \
     }                                                                                                                  \
-    if (n_hubs > 0) {                                                                                                  \
-      int gh = n_hubs < 4096 ? (int)n_hubs : 4096;                                                                     \
-      hipLaunchKernelGGL((seg_hub_k<V, L, K, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, (const float*)nullptr, hub_seg, \
-                         hub_first, hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0); \
-    }                                                                                                                  \
+    if (n_hubs > 0) launch_hub_sum<V, L, K>(hub_wide(nseg, n_spans), hub_seg, hub_first, hub_count, n_hubs, seg_len, out, ws_val, D, st); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL

@@ -71,14 +71,16 @@ __device__ __forceinline__ void finalize_row(Acc<VEC, LPR, KMAX, IS_MAX>& acc, i
 // Combine of the partial results of a split (hub) list: one workgroup per hub.  The RPB lane
 // groups take contiguous ranges of the hub's partial slots (8 loads in flight each) and their
 // sums are combined in range order through LDS -- a fixed association, bitwise reproducible.
-template <int VEC, int LPR, int KMAX, bool IS_MAX>
-__global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__ self_rows, const int32_t* __restrict__ hub_node,
+// THREADS = 1024 (16 lane groups at LPR = 64) is for plans with few, long hubs (segments = relations): the pass is
+// bound by the latency of one workgroup walking its hub's partial rows, so more groups per hub shorten it.
+template <int VEC, int LPR, int KMAX, bool IS_MAX, int THREADS = MRG_BLOCK>
+__global__ __launch_bounds__(THREADS) void seg_hub_k(const float* __restrict__ self_rows, const int32_t* __restrict__ hub_node,
                                                        const int32_t* __restrict__ hub_first, const int32_t* __restrict__ hub_count,
                                                        int64_t n_hubs, const int32_t* __restrict__ in_degree,
                                                        float* __restrict__ out, int32_t* __restrict__ arg,
                                                        const float* __restrict__ ws_val, const int32_t* __restrict__ ws_arg,
                                                        int D, int is_mean) {
-  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int RPB = THREADS / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   constexpr int U = 8;
   __shared__ float sval[RPB * WIDTH];
@@ -147,6 +149,26 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_hub_k(const float* __restrict__
       finalize_row<VEC, LPR, KMAX, IS_MAX>(tot, v, in_degree[v], is_mean != 0, self_rows, out, arg, D, sl);
     }
   }
+}
+
+// few segments, many spans: hubs are few and long -> the wide workgroup.  Decided from the plan's exact sizes (never from
+// hub / slot counts, which may still be capacities when the launch is issued) so that the association is fixed per plan.
+inline bool hub_wide(int64_t nseg, int64_t n_spans) { return nseg <= 2048 && n_spans >= 4 * nseg; }
+
+// the hub pass of a sum plan (span kernels): out rows of split / empty segments
+template <int VEC, int LPR, int KMAX>
+inline void launch_hub_sum(bool wide, const int32_t* hub_seg, const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs,
+                           const int32_t* seg_len, float* out, const float* ws_val, int D, hipStream_t st) {
+  const int gh = n_hubs < 4096 ? (int)n_hubs : 4096;
+  if constexpr (KMAX == 1) {
+    if (wide) {
+      hipLaunchKernelGGL((seg_hub_k<VEC, LPR, KMAX, false, 1024>), dim3(gh), dim3(1024), 0, st, (const float*)nullptr, hub_seg, hub_first,
+                         hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((seg_hub_k<VEC, LPR, KMAX, false>), dim3(gh), dim3(MRG_BLOCK), 0, st, (const float*)nullptr, hub_seg, hub_first,
+                     hub_count, n_hubs, seg_len, out, (int32_t*)nullptr, ws_val, (const int32_t*)nullptr, D, 0);
 }
 
 }  // namespace mrg

@@ -203,6 +203,15 @@ def dst_csr_plan_torch(dst, num_nodes, chunk=CHUNK_EDGES):
 SPAN_ELEMS = int(os.environ.get("MRG_SPAN", "96"))      # sorted elements reduced by one lane group in the span kernels
 
 
+def auto_span(E, nseg):
+    """Span length of a plan: SPAN_ELEMS, longer when the segments are few and very long (DistMult's relation gradient:
+    3 M scored triples over 474 relation rows) so that a hub's partial rows stay in the hundreds, while the plan keeps
+    >= 8192 spans to fill the chip."""
+    if nseg <= 0 or E < 16 * SPAN_ELEMS * nseg:
+        return SPAN_ELEMS
+    return max(SPAN_ELEMS, int(min(E / nseg / 8, E / 8192, 8 * SPAN_ELEMS)) // 32 * 32)
+
+
 def span_plan(seg, nseg, span=None):
     """Plan for mrg_span_gcs (include/mrgnas.h): elements sorted by segment, cut into spans of
     `span` consecutive sorted elements.  Only the first / last run of a span can be a partial
@@ -210,8 +219,9 @@ def span_plan(seg, nseg, span=None):
     segment are consecutive and in list order) that the hub pass adds up.  Device tensors go through the HIP
     builder (mrg_span_plan_build: histogram -> scan -> stable sort -> marking kernels), CPU tensors through the
     tensor formulation span_plan_torch."""
+    span = auto_span(int(seg.numel()), int(nseg)) if span is None else span
     if _hip_ready(seg):
-        return _hip_span_plan(seg, nseg, SPAN_ELEMS if span is None else span)
+        return _hip_span_plan(seg, nseg, span)
     return span_plan_torch(seg, nseg, span)
 
 
@@ -239,8 +249,8 @@ def span_plan_torch(seg, nseg, span=None):
     """The tensor formulation of the span plan (pure torch ops; any device)."""
     dev = seg.device
     seg = seg.long()
-    span = SPAN_ELEMS if span is None else span
     E, nseg = int(seg.numel()), int(nseg)
+    span = auto_span(E, nseg) if span is None else span
     perm = torch.argsort(seg, stable=True)
     seg_s = seg[perm]
     seg_len = torch.bincount(seg, minlength=nseg)

@@ -370,3 +370,22 @@ def test_filters_with_both_operands_the_same_rows(N, T, R, D, order):
             for k, p in op.named_parameters():
                 close(p.grad, Pr[k].grad, f"{name} ({how}) grad {k}", rtol=3e-4, atol=1e-4)
     assert not K.same_rows(x, gM) and not K.same_rows(x[:10], x[1:11])
+
+
+@pytest.mark.parametrize("E,nseg,D", [(400_000, 7, 200), (3_000_000, 474, 32), (60_000, 3, 36)])
+def test_span_sum_with_few_long_segments(E, nseg, D):
+    """Segments that are few and very long (the relation gradient of DistMult: 3 M triples over 474 rows): the plan
+    lengthens its spans (graph.auto_span) and the hub pass runs the wide workgroup; checked against a float64 sum,
+    and bitwise reproducible from one launch to the next."""
+    gen = torch.Generator().manual_seed(E + nseg)
+    seg = torch.randint(0, nseg, (E,), generator=gen)
+    seg[: E // 2] = 1                                                     # one segment holds half of the elements
+    X = torch.randn(5000, D, generator=gen)
+    xi = torch.randint(0, 5000, (E,), generator=gen)
+    plan = G.span_plan(seg.to(DEV), nseg)
+    assert plan["span"] == G.auto_span(E, nseg) and (E < 3_000_000 or plan["span"] > G.SPAN_ELEMS)
+    meta = G.span_meta(plan, xi.to(DEV))
+    out = K.span_gcs("copy", X.to(DEV), None, meta, plan)
+    ref = torch.zeros(nseg, D, dtype=torch.float64).index_add_(0, seg, X.double()[xi])
+    close(out, ref.float(), "span sum, long segments", rtol=2e-6 * (E / nseg) ** 0.5)
+    assert torch.equal(out, K.span_gcs("copy", X.to(DEV), None, meta, plan))
