@@ -356,7 +356,7 @@ def main():
     global _lib
     from mr_gnas_amd import _lib
     lib = _lib.load()
-    MATRIX_CORE["mode"] = 1 if args.exact_f32 else 0
+    MATRIX_CORE["mode"] = 1 if args.exact_f32 else int(os.environ.get("MRG_GEMM_MODE", "0"))    # lab: 3 / 4 = the opt-in split-core kernels
     if lib.mrg_gemm_set_mode(MATRIX_CORE["mode"]) != 0:
         raise SystemExit("mrg_gemm_set_mode failed")
 

@@ -258,7 +258,9 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  * ws: NULL, or mrg_gemm_workspace_bytes(K, Nout) bytes of device memory private to this call. */
 int64_t mrg_gemm_workspace_bytes(int K, int Nout);
 /* 0 (default): split core where possible; 1: exact-f32 core only; 3: split core on the persistent
- * transposed-accumulator kernel (comparison point, measured equal).  Process-wide. */
+ * transposed-accumulator kernel; 4: split core on the two-waves-per-SIMD kernel (64 rows x 4 / 3 column tiles per wave)
+ * for >= 65 536 rows, more than 128 output columns and a plain epilogue.  3 and 4 are tested comparison points: faster
+ * or equal alone, not faster inside the multi-stream step.  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);

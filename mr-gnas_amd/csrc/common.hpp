@@ -111,15 +111,29 @@ inline RowGeom row_geom(int D, bool all_aligned) {
 
 // Deterministic second stage of the two-stage reductions: out[t] = sum_b ws[(b0 + b) * ld + t],
 // b < nb.  A 64 x 16 thread block owns 64 consecutive t; thread row ty sums the partials
-// b = ty, ty + 16, ... (coalesced along t), then the 16 row sums are added in order.
+// b = ty, ty + 16, ... (coalesced along t; four interleaved accumulators), then the 16 row sums are added in order.
+// blockIdx.y selects one of up to four row ranges [bs.x[y], bs.x[y + 1]) of ws, reduced into out + y * out_stride
+struct ReduceRanges { int x[5]; };
 template <typename T>
-__global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, int b0, int nb, int ld, int len) {
+__global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, ReduceRanges bs, int out_stride, int ld, int len) {
   __shared__ T part[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + tx;
+  const int b0 = bs.x[blockIdx.y], nb = bs.x[blockIdx.y + 1] - b0;
+  out += (int64_t)blockIdx.y * out_stride;
   T acc = 0;
-  if (t < len)
-    for (int b = ty; b < nb; b += 16) acc += ws[(int64_t)(b0 + b) * ld + t];
+  if (t < len) {
+    // four loads in flight per thread (the pass is latency-bound: a thread walks up to 64 partial rows); fixed association
+    T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int b = ty;
+    for (; b + 48 < nb; b += 64) {
+      const T v0 = ws[(int64_t)(b0 + b) * ld + t], v1 = ws[(int64_t)(b0 + b + 16) * ld + t];
+      const T v2 = ws[(int64_t)(b0 + b + 32) * ld + t], v3 = ws[(int64_t)(b0 + b + 48) * ld + t];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; b < nb; b += 16) a0 += ws[(int64_t)(b0 + b) * ld + t];
+    acc = (a0 + a1) + (a2 + a3);
+  }
   part[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && t < len) {
@@ -132,7 +146,15 @@ __global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, 
 
 template <typename T>
 inline void launch_ordered_reduce(const T* ws, T* out, int b0, int nb, int ld, int len, hipStream_t st) {
-  hipLaunchKernelGGL((ordered_reduce_k<T>), dim3((len + 63) / 64), dim3(1024), 0, st, ws, out, b0, nb, ld, len);
+  ReduceRanges bs{{b0, b0 + nb, 0, 0, 0}};
+  hipLaunchKernelGGL((ordered_reduce_k<T>), dim3((len + 63) / 64, 1), dim3(1024), 0, st, ws, out, bs, 0, ld, len);
+}
+// n_ranges (<= 4) consecutive row ranges bounds[0..n_ranges] in one launch: out + r * out_stride receives range r
+template <typename T>
+inline void launch_ordered_reduce_ranges(const T* ws, T* out, const int* bounds, int n_ranges, int out_stride, int ld, int len, hipStream_t st) {
+  ReduceRanges bs{};
+  for (int i = 0; i <= n_ranges; ++i) bs.x[i] = bounds[i];
+  hipLaunchKernelGGL((ordered_reduce_k<T>), dim3((len + 63) / 64, n_ranges), dim3(1024), 0, st, ws, out, bs, out_stride, ld, len);
 }
 
 inline int grid_for(int64_t work_items, int items_per_block) {

@@ -449,8 +449,7 @@ extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();
-  for (int seg = 0; seg < 3; ++seg)
-    launch_ordered_reduce<float>((const float*)ws, d_uvc + seg * ld, p.blk[seg], p.blk[seg + 1] - p.blk[seg], ld, ld, st);
+  launch_ordered_reduce_ranges<float>((const float*)ws, d_uvc, p.blk, 3, ld, ld, ld, st);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

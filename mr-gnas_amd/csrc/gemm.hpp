@@ -124,6 +124,9 @@ __device__ __forceinline__ float4 gemm_mask_a(float4 v, const GemmArgs& a, int64
 // Every load (bias, row scale, gate multiplicand, accumulate input) is issued unconditionally from a
 // clamped address BEFORE the stores, and a full tile stores without per-element branches: a store inside
 // a data-dependent branch makes hipcc wait vmcnt(0) per store, which serialises the 16*NT stores of a lane.
+#ifndef MRG_C_NT
+#define MRG_C_NT 0
+#endif
 template <int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh,
                                               bool full) {
@@ -179,7 +182,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     if (full) {
       if (cok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) crow[r][n * 32] = v[r];
+        for (int r = 0; r < 16; ++r) {
+#if MRG_C_NT
+          __builtin_nontemporal_store(v[r], crow[r] + n * 32);           // lab: C is written once and re-read by a later kernel
+#else
+          crow[r][n * 32] = v[r];
+#endif
+        }
         if (EPI == EPI_GATE && a.aux) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) xrow[r][n * 32] = g[r];

@@ -24,7 +24,8 @@
 #include <type_traits>
 #include "gemm.hpp"
 
-// lab switches (tools/gemm_x3_lab.hip): 1 no epilogue stores, 2 no A split, 4 no DMA after the first slab, 8 no barrier
+// lab switches (tools/gemm_x3_lab.hip): 1 no epilogue stores, 2 no A split, 4 no DMA after the first slab, 8 no barrier,
+// 32 no B loads after the first slab, 64 no split at all, 128 no fragment reads, 256 staggered start (desynchronised rounds)
 #ifndef MRG_X3_DBG
 #define MRG_X3_DBG 0
 #endif
@@ -33,11 +34,23 @@
 #define MRG_A_CPOL 0
 #endif
 // VALU instructions the scheduler may place after each MFMA of a tile (lab sweep: 2 / 3 / 4 / 6)
+// lab switch 256: s_sleep(127) repetitions (64 * 127 cycles each) the odd workgroups of the first round wait
+#ifndef MRG_X3_STAGGER
+#define MRG_X3_STAGGER 6
+#endif
 #ifndef MRG_X3_VPM
 #define MRG_X3_VPM 3
 #endif
 
 namespace mrg {
+
+// lab switch 512: per-wave phase timestamps (100 MHz wall clock) -> mrg_x3_trace[wave slot * 4 + {start, loop, epilogue, end}]
+#if MRG_X3_DBG & 512
+__device__ unsigned long long* mrg_x3_trace;
+#define MRG_X3_STAMP(slot, i) do { if (lane == 0) mrg_x3_trace[(int64_t)(slot) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define MRG_X3_STAMP(slot, i) do { } while (0)
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -145,6 +158,11 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   const int K = a.K1 + a.K2;
   const int nslab = (K + 15) >> 4;
 
+  if ((MRG_X3_DBG & 256) && blockIdx.x < 256 && (blockIdx.x & 1)) {     // lab: first-round workgroups of every other CU start late
+    for (int i = 0; i < MRG_X3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+  MRG_X3_STAMP(trace_slot, 0);
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   read_a(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  MRG_X3_STAMP(trace_slot, 1);
 #pragma unroll
   for (int j = 0; j < NPAIR; ++j) split_one(j, ch, cm, cl);
 
@@ -302,10 +321,12 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   slab(std::integral_constant<int, 1>{}, nslab - 3);
   slab(std::integral_constant<int, 2>{}, nslab - 2);
   slab(std::integral_constant<int, 3>{}, nslab - 1);
+  MRG_X3_STAMP(trace_slot, 2);
   if ((MRG_X3_DBG & 1) && acc[0][0][0] != 123.456f) return;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
     gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, (int64_t)blockIdx.x * GBM + GBM <= a.rows);
+  if (MRG_X3_DBG & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MRG_X3_STAMP(trace_slot, 3); }
 }
 
 inline bool x3_eligible(const GemmArgs& a) {

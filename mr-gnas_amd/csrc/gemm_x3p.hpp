@@ -25,6 +25,7 @@
 //     copies the not-yet-arrived register).
 #pragma once
 #include "gemm_x3.hpp"
+#include "gemm_x3w.hpp"
 
 namespace mrg {
 
@@ -330,6 +331,7 @@ inline int launch_rowgemm_x3p(GemmArgs a, const void* Bp, hipStream_t st) {
 // ---- dispatch between the two cores ---------------------------------------------------------------
 // mode 0 (default): split-bf16 core whenever the operands qualify and a workspace was given;
 // mode 3: the same arithmetic on the persistent kernel of this file (comparison point);
+// mode 4: the same arithmetic on the two-waves-per-SIMD kernel of gemm_x3w.hpp where it applies (comparison point);
 // mode 1: exact-f32 core only (v_mfma_f32_32x32x2_f32) -- the comparison point of the tests and of bench.py.
 inline int& gemm_mode() { static int m = 0; return m; }
 
@@ -353,6 +355,15 @@ inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStre
     // shares: that loop runs at ~60 % of the MFMA micro-benchmark's rate whatever is removed from it, so hiding the
     // prologue / epilogue latencies does not pay.  Kept opt-in (tested) as the comparison point; the default stays round 1's.
     if (gemm_mode() == 3 && x3p_eligible(a)) return launch_rowgemm_x3p<EPI>(a, ws, st);
+    // mode 4: the two-waves-per-SIMD kernel (gemm_x3w.hpp) for plain epilogues.  Alone it is 12-23 % faster than the one-wave
+    // kernel (lab: 0.195 / 0.172 ms with non-temporal stores vs 0.223 ms at rows 272 115, K = N = 200) and 13 % faster inside a
+    // single-stream step (253 vs 290 us), but the step that runs its MixedOp candidates on four streams already fills the
+    // one-wave kernel's idle phases with the other candidates' kernels: 70.0-70.6 ms/step (one-wave, 4 streams) vs 70.5-71.4
+    // (two-wave, 4 streams) vs 71.1-71.5 (two-wave, 1 stream) on the same box.  The gate epilogue (three pointers per
+    // accumulator row) does not fit its 256 registers (331 vs 295 us) and dual-source K = 2D products gain nothing.
+    if constexpr (EPI != EPI_GATE) {
+      if (gemm_mode() == 4 && a.K2 == 0 && x3w_eligible(a)) return launch_rowgemm_x3w<EPI>(a, ws, st);
+    }
     return launch_rowgemm_x3<EPI>(a, ws, st);
   }
   if (b_sk != 1) {                                   // present B^T row-major to the f32 core

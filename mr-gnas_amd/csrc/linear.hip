@@ -565,7 +565,7 @@ static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const flo
   a.rows = rows; a.rows_per_block = p.rows_per_block; a.TM = p.TM; a.TN = p.TN; a.TNB = p.TNB;
   if (!X2 || K2 == 0) { a.X2 = X1; a.K2 = 0; }
   const bool vec = vec0;
-  if (vec && gemm_mode() == 0 && p.TM <= 7) {        // split-bf16 core
+  if (vec && gemm_mode() != 1 && p.TM <= 7) {        // split-bf16 core
     const int ng = p.TM <= 4 ? 1 : 2, kt = 16 / ng;
     dim3 gridx(p.G, (p.TN + kt - 1) / kt);
     const size_t ldsx = (size_t)(ng == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
@@ -623,7 +623,7 @@ extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
 }
 
 extern "C" int mrg_gemm_set_mode(int mode) {
-  if (mode != 0 && mode != 1 && mode != 3) return MRG_E_ENUM;
+  if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return MRG_E_ENUM;
   gemm_mode() = mode;
   return MRG_OK;
 }

@@ -244,7 +244,7 @@ def test_distmult_score_and_gradients(N, R, T, D):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K1,K2,Nout", [(70000, 200, 200, 200), (70001, 200, 0, 200), (3000, 100, 100, 100), (513, 64, 0, 40),
-                                             (66000, 52, 0, 300), (259, 400, 0, 7), (272115, 200, 0, 200), (300001, 128, 128, 128), (200001, 256, 0, 256)])
+                                             (66000, 52, 0, 300), (259, 400, 0, 7), (272115, 200, 0, 200), (65537, 128, 0, 450), (300001, 128, 128, 128), (200001, 256, 0, 256)])
 def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     """The split-bf16 matrix core (six bf16 cross terms, f32 accumulate) against the exact-f32 MFMA core, both
     measured against a float64 product: its error may not exceed 1.5x the exact core's (+ 1e-6 of the output
@@ -261,7 +261,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     ref_gx = gy.double() @ W.double()
     errs = {}
     try:
-        for mode in (0, 1, 3):                      # 3: the persistent transposed-accumulator variant of the split core (opt-in)
+        for mode in (0, 1, 3, 4):                   # 3: persistent variant, 4: two waves / SIMD where eligible (both opt-in)
             assert lib.mrg_gemm_set_mode(mode) == 0
             if K2 == 0:
                 out = K.linear(x, W, b, None)
@@ -278,7 +278,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     finally:
         lib.mrg_gemm_set_mode(0)
     for i, scale in ((0, float(ref.abs().max())), (1, float(ref_gx.abs().max()))):
-        for mode in (0, 3):
+        for mode in (0, 3, 4):
             assert errs[mode][i] <= 1.5 * errs[1][i] + 1e-6 * scale, (mode, errs, scale)
             assert errs[mode][i] <= 2e-5 * scale
 

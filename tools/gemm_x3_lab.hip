@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "gemm_x3p.hpp"
 using namespace mrg;
 
@@ -14,6 +15,7 @@ int main(int argc, char** argv) {
   int64_t rows = argc > 1 ? atoll(argv[1]) : 558771;
   int K1 = argc > 2 ? atoi(argv[2]) : 200, K2 = argc > 3 ? atoi(argv[3]) : 200, N = argc > 4 ? atoi(argv[4]) : 200;
   int K = K1 + K2;
+  const int reps = argc > 5 ? atoi(argv[5]) : 10;            // long runs for tools/clock_probe.sh
   float *A1, *A2, *B, *C, *C2; void* Bp;
   hipMalloc(&A1, rows * K1 * 4); hipMalloc(&A2, rows * (K2 ? K2 : 4) * 4); hipMalloc(&B, (size_t)N * K * 4);
   hipMalloc(&C, rows * N * 4); hipMalloc(&C2, rows * N * 4);
@@ -27,13 +29,21 @@ int main(int argc, char** argv) {
   hipMalloc(&Bp, x3_bsplit_bytes(N, K, nt));
   GemmArgs a{}; a.A1 = A1; a.A2 = K2 ? A2 : nullptr; a.K1 = K1; a.K2 = K2; a.B = B; a.ldb = K; a.C = C; a.ldc = N; a.N = N; a.rows = rows;
   a.bias = dbias; a.act = 0;
+#if MRG_X3_DBG & 512
+  // every launch of this build stamps: the buffer must exist before the first one (slots: 4 waves x workgroups of either kernel)
+  const int64_t slots = 4 * (2 * ((rows + 255) / 256 + 8)) * 4;
+  unsigned long long* tr = nullptr;
+  if (hipMalloc(&tr, slots * 4 * 8) != hipSuccess || !tr) { printf("trace buffer allocation failed\n"); return 1; }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mrg_x3_trace), &tr, sizeof(tr)) != hipSuccess) { printf("trace symbol not set\n"); return 1; }
+  hipDeviceSynchronize();
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char* name, auto fn) {
     fn(); hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) fn();
+    for (int i = 0; i < reps; ++i) fn();
     hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     printf("%-28s %8.3f ms  %7.1f TF/s (f32-equivalent)  err=%s\n", name, ms, 2.0 * rows * K * N / ms * 1e-9, hipGetErrorString(hipGetLastError()));
   };
   timeit("x3 (split + gemm)", [&] { launch_bsplit(B, K, 1, N, K, nt, Bp, 0); launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
@@ -42,6 +52,35 @@ int main(int argc, char** argv) {
     hipMemset(C, 0, rows * N * 4);
     timeit("x3 persistent (gemm only)", [&] { launch_rowgemm_x3p<EPI_BIAS_ACT>(a, Bp, 0); });
   }
+  if (x3w_eligible(a)) {
+    hipMemset(C, 0, rows * N * 4);
+    timeit("x3 two waves/SIMD (gemm only)", [&] { launch_rowgemm_x3w<EPI_BIAS_ACT>(a, Bp, 0); });
+  }
+#if MRG_X3_DBG & 512
+  {  // per-wave phase timestamps of ONE launch of each kernel (100 MHz clock: 10 ns units)
+    std::vector<unsigned long long> h(slots * 4);
+    auto report = [&](const char* name) {
+      hipDeviceSynchronize();
+      hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull, t3 = 0; int64_t n = 0;
+      for (int64_t i = 0; i < slots; ++i) if (h[4 * i] && h[4 * i + 3]) { t0 = std::min(t0, h[4 * i]); t3 = std::max(t3, h[4 * i + 3]); ++n; }
+      double sp = 0, sl = 0, se = 0; std::vector<double> starts;
+      for (int64_t i = 0; i < slots; ++i) if (h[4 * i] && h[4 * i + 3]) {
+        sp += (h[4 * i + 1] - h[4 * i]) * 0.01; sl += (h[4 * i + 2] - h[4 * i + 1]) * 0.01; se += (h[4 * i + 3] - h[4 * i + 2]) * 0.01;
+        starts.push_back((h[4 * i] - t0) * 0.01);
+      }
+      std::sort(starts.begin(), starts.end());
+      printf("%s: %lld waves, span %.1f us; mean per wave: prologue %.2f us, k-loop %.2f us, epilogue+drain %.2f us\n", name, (long long)n,
+             (t3 - t0) * 0.01, sp / n, sl / n, se / n);
+      printf("   wave start times (us) at deciles:");
+      for (int d = 0; d <= 10; ++d) printf(" %.1f", starts[std::min<size_t>(starts.size() - 1, starts.size() * d / 10)]);
+      printf("\n");
+    };
+    hipMemset(tr, 0, slots * 4 * 8);
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); report("one wave/SIMD");
+    if (x3w_eligible(a)) { hipMemset(tr, 0, slots * 4 * 8); launch_rowgemm_x3w<EPI_BIAS_ACT>(a, Bp, 0); report("two waves/SIMD"); }
+  }
+#endif
   GemmArgs b = a; b.C = C2;
   timeit("f32 mfma", [&] { launch_rowgemm<EPI_BIAS_ACT>(b, 0); });
   // error vs float64 on a sample of rows
