@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 3   /* 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 4   /* 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -264,6 +264,19 @@ int64_t mrg_gemm_workspace_bytes(int K, int Nout);
 int mrg_gemm_set_mode(int mode);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);
+/* a_max_op.forward as ONE GEMM (reference models/operations_lp.py:230-235; SURVEY section 2b K_lin_relu_segmax):
+ *   out[v] = max over in-edges e of v of ReLU(X[e] W^T + bias)  + self_rows[v]        (0 + self row without in-edge)
+ * The split-core GEMM walks the edge rows in destination order (eid = the by-destination edge list of the chunk plan,
+ * dst[e] = destination of edge e) and its epilogue reduces ReLU(acc + bias) over the runs of equal destination in
+ * registers, publishing 64-bit atomic maxima of (value bits, 0xFFFFFFFF - list position): exact, order-independent,
+ * lowest edge id among equal values (DGL's argmax).  The [E, Nout] message tensor is never written.
+ * arg [N, Nout] int32 (winning edge id, -1 without in-edge) and mx [N, Nout] (the maximum itself: the backward's ReLU
+ * mask is mx > 0) are optional.  ws: mrg_linear_relu_segmax_workspace_bytes(N, K, Nout) bytes; that function returns 0
+ * when the split core cannot take the shape (K <= 48 or K % 4 != 0): use mrg_linear_fwd + mrg_seg_reduce_fwd then. */
+int64_t mrg_linear_relu_segmax_workspace_bytes(int64_t N, int K, int Nout);
+int mrg_linear_relu_segmax_fwd(const float *X, const float *W, const float *bias, const int32_t *eid, const int32_t *dst,
+                               const float *self_rows, float *out, int32_t *arg, float *mx, void *ws,
+                               int64_t E, int64_t N, int K, int Nout, void *stream);
 /* gX[rows, K] (+)= gY[rows, Nout] W[:, 0:K]   (gY already masked by the activation).  W is
  * [Nout][ldw] row-major, ldw >= K (a column block of a wider weight, e.g. one half of an
  * nn.Linear(2D, D)); accumulate != 0 adds into gX.  ws (mandatory) holds the split / transposed block. */

@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM_MAX = 256;      // rows per workgroup = 128 * MT (MT row tiles of 32 per wave)
 
-enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3 };
+enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3, EPI_SEGMAX = 4 };
 
 struct GemmArgs {
   const float* A1; const float* A2;   // [rows][K1], [rows][K2] row-major; A2 may be NULL (K2 = 0)
@@ -42,7 +42,57 @@ struct GemmArgs {
   const float* rowscale; float scale; // c_row = scale * (rowscale ? rowscale[row] : 1)     (EPI_GATE, EPI_SCALE)
   float* aux;                         // EPI_GATE: optional store of sigmoid(acc + bias), [rows][N]
   const float* Cin; int ld_cin;       // EPI_ACCUM: C = acc + Cin
+  // split core only (gemm_x3.hpp): output row r reads A row row_index[r] (NULL: r itself)
+  const int32_t* row_index;
+  // EPI_SEGMAX (no C): seg_out[row_seg[row_index[r]] * N + col] = max over rows r of pack(ReLU(acc + bias), r), see gemm_epilogue_segmax
+  const int32_t* row_seg;
+  unsigned long long* seg_out;
 };
+
+// ---- a_max: ReLU + destination-segmented max as the GEMM's epilogue (reference models/operations_lp.py:230-234) ----------
+// The GEMM walks the edges in destination order (row_index = the by-destination edge list), so the 32 rows of an accumulator
+// strip are a few runs of equal destination.  A lane reduces its 16 rows run by run in registers and publishes one
+// 64-bit atomic max per (run, column): key = float bits of the ReLU output (>= +0, so unsigned order = float order) in the
+// high word, 0xFFFFFFFF - sorted row position in the low word.  max() is exact, so the result does not depend on the
+// order of the atomics; among equal values the smallest position (= lowest edge id: the list of a destination is in edge
+// order) wins, like DGL's first-index argmax; key 0 = "no in-edge".  The [E, D] ReLU output is never written.
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue_segmax(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh) {
+  if (rowbase >= a.rows) return;
+  int seg[16];
+  unsigned low[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const bool ok = row < a.rows;
+    const int64_t rc = ok ? row : a.rows - 1;
+    const int e = a.row_index ? a.row_index[rc] : (int)rc;
+    const int d = a.row_seg[e];
+    seg[r] = ok ? d : -1;
+    low[r] = 0xFFFFFFFFu - (unsigned)rc;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 32 + li;
+    const bool cok = col < a.N;
+    const float bv = (a.bias && cok) ? a.bias[col] : 0.f;
+    int cur = -1;
+    unsigned long long best = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (seg[r] != cur) {                                   // uniform over the 32 lanes of a half wave
+        if (cur >= 0 && cok) atomicMax(a.seg_out + (int64_t)cur * a.N + col, best);
+        cur = seg[r];
+        best = 0;
+      }
+      const float x = acc[n][r] + bv;
+      const float y = x > 0.f ? x : 0.f;                     // ReLU; NaN -> 0 like the unfused epilogue
+      const unsigned long long key = ((unsigned long long)__float_as_uint(y) << 32) | low[r];
+      best = key > best ? key : best;
+    }
+    if (cur >= 0 && cok) atomicMax(a.seg_out + (int64_t)cur * a.N + col, best);
+  }
+}
 
 // Branch-free guarded loads, split in two halves so the data is not needed until the tile is
 // written to LDS (after the MFMAs of the previous tile):

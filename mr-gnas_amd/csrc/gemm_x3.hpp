@@ -177,7 +177,8 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   for (int i = 0; i < NA; ++i) {
     const int f = lane + 64 * i;
     const int64_t row = roww + (f >> 2);
-    const int64_t rc = row < a.rows ? row : a.rows - 1;
+    int64_t rc = row < a.rows ? row : a.rows - 1;
+    if (a.row_index) rc = a.row_index[rc];                 // gathered rows (EPI_SEGMAX: edges in destination order)
     arow1[i] = a.A1 + rc * a.K1;
     arow2[i] = a.A2 + rc * a.K2;
     acol[i] = 4 * ((f & 3) ^ ((f >> 4) & 3));
@@ -324,8 +325,10 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   MRG_X3_STAMP(trace_slot, 2);
   if ((MRG_X3_DBG & 1) && acc[0][0][0] != 123.456f) return;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-    gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, (int64_t)blockIdx.x * GBM + GBM <= a.rows);
+  for (int m = 0; m < MT; ++m) {
+    if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc[m], roww + m * 32, col0, li, lh);
+    else gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, (int64_t)blockIdx.x * GBM + GBM <= a.rows);
+  }
   if (MRG_X3_DBG & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MRG_X3_STAMP(trace_slot, 3); }
 }
 

@@ -613,9 +613,62 @@ static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const flo
   return MRG_OK;
 }
 
+// a_max, second half: unpack the 64-bit keys of gemm_epilogue_segmax.  out = max (0 without in-edge) + self row;
+// arg = the winning edge id (-1 without in-edge); mx = the max itself (the backward's ReLU mask: mx > 0).
+__global__ void segmax_finalize_k(const unsigned long long* __restrict__ keys, const float* __restrict__ self_rows,
+                                  const int32_t* __restrict__ eid, float* __restrict__ out, int32_t* __restrict__ arg,
+                                  float* __restrict__ mx, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[i];
+    const unsigned lo = (unsigned)k;
+    const float v = __uint_as_float((unsigned)(k >> 32));
+    out[i] = self_rows ? v + self_rows[i] : v;
+    if (arg) arg[i] = lo == 0u ? -1 : eid[0xFFFFFFFFu - lo];
+    if (mx) mx[i] = v;
+  }
+}
+
 }  // namespace mrg
 
 using namespace mrg;
+
+// ---- a_max as two launches: split-core GEMM with the ReLU + segmented-max epilogue, then the unpack pass ---------------
+static bool segmax_shape_ok(int K, int Nout) { return K > 48 && K % 4 == 0 && Nout > 0; }
+
+extern "C" int64_t mrg_linear_relu_segmax_workspace_bytes(int64_t N, int K, int Nout) {
+  if (N < 0 || !segmax_shape_ok(K, Nout)) return 0;                    // 0: the split core cannot take the shape (use the unfused entry points)
+  return ((N * (int64_t)Nout * 8 + 255) / 256) * 256 + (int64_t)x3_bsplit_bytes(Nout, K, gemm_pick_nt(Nout)) + 256;
+}
+
+extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const float* bias, const int32_t* eid, const int32_t* dst,
+                                          const float* self_rows, float* out, int32_t* arg, float* mx, void* ws, int64_t E, int64_t N,
+                                          int K, int Nout, void* stream) {
+  if (E < 0 || N < 0 || K <= 0 || Nout <= 0 || E >= ((int64_t)1 << 32) - 1) return MRG_E_SHAPE;
+  if (!segmax_shape_ok(K, Nout)) return MRG_E_SHAPE;
+  if (N == 0) return MRG_OK;
+  if (!out || !W) return MRG_E_NULLPTR;
+  if (E > 0 && (!X || !eid || !dst)) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  if (!aligned16(X) || !aligned16(ws)) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)ws;
+  const size_t key_bytes = (size_t)((N * (int64_t)Nout * 8 + 255) / 256) * 256;
+  void* bsplit = (char*)ws + key_bytes;
+  if (hipMemsetAsync(keys, 0, (size_t)N * Nout * 8, st) != hipSuccess) return MRG_E_WORKSPACE;
+  if (E > 0) {
+    GemmArgs a{};
+    a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
+    a.row_index = eid; a.row_seg = dst; a.seg_out = keys;
+    if (!x3_eligible(a)) return MRG_E_SHAPE;
+    launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), bsplit, st);
+    const int rc = launch_rowgemm_x3<EPI_SEGMAX>(a, bsplit, st);
+    if (rc != MRG_OK) return rc;
+  }
+  const int64_t total = N * (int64_t)Nout;
+  hipLaunchKernelGGL(segmax_finalize_k, dim3(grid_for(total, 256 * 4)), dim3(256), 0, st, keys, self_rows, eid, out, arg, mx, total);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
 
 extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
   if (K <= 0 || Nout <= 0) return 0;

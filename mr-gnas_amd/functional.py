@@ -295,6 +295,9 @@ def aggregate_rows(kind, x, graph, add_self=True, keep=None):
     return _AggRows.apply(REDUCE[kind], x, graph, add_self, keep)
 
 
+FUSED_AMAX = os.environ.get("MRG_FUSED_AMAX", "1") == "1"      # lab switch: 0 = linear + segmented max as separate launches
+
+
 class _LinReluAgg(torch.autograd.Function):
     """a_max / a_mean as ONE autograd node on the reference's [M, D] layout
     (reference models/operations_lp.py:230-235, 245-250):
@@ -311,6 +314,20 @@ class _LinReluAgg(torch.autograd.Function):
         if x.shape[0] != E + N:
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
         st = stream_of(x)
+        fused_ws = _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) if (mode == 2 and FUSED_AMAX) else 0
+        if fused_ws > 0:
+            # a_max as ONE GEMM whose epilogue is ReLU + segmented max (the [E, D] messages are never written; the
+            # backward's ReLU mask is "the maximum is positive")
+            p = graph.plan()
+            out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            arg = torch.empty(N, D, dtype=torch.int32, device=x.device)
+            mx = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            call("mrg_linear_relu_segmax_fwd", (ptr(x), ptr(W), ptr(b), ptr(p["eid"]), ptr(graph.i32("dst")), ptr(x[E:]), ptr(out), ptr(arg),
+                                                ptr(mx), ptr(_ws(fused_ws, x)), E, N, D, D, st),
+                 nbytes=4 * E * D + 8 * E + 4 * D * D + 4 * N * D * 4, flops=2 * E * D * D)
+            ctx.mode, ctx.graph, ctx.fused = mode, graph, True
+            ctx.save_for_backward(x, W, arg, mx)
+            return out
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
         gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
         call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
@@ -321,21 +338,28 @@ class _LinReluAgg(torch.autograd.Function):
             sp, meta = graph.agg_plan("mean" if mode == 1 else "sum")
             out, arg = span_gcs("copy", y, None, meta, sp), None
             out += x[E:]
-        ctx.mode, ctx.graph = mode, graph
+        ctx.mode, ctx.graph, ctx.fused = mode, graph, False
         ctx.save_for_backward(x, W, y, *((arg,) if arg is not None else ()))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, W, y, *rest = ctx.saved_tensors
-        arg = rest[0] if rest else None
         graph, mode = ctx.graph, ctx.mode
         g = f32c(g)
+        if ctx.fused:
+            x, W, arg, mx = ctx.saved_tensors
+        else:
+            x, W, y, *rest = ctx.saved_tensors
+            arg = rest[0] if rest else None
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         st = stream_of(x)
         gx = torch.empty_like(x)
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
-        _seg_bwd(mode, g, graph, arg, gy, gx[E:], relu_src=y)          # gy masked by ReLU; gx[E:] = g
+        if ctx.fused:
+            _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)             # the winning message is ReLU-dead iff the maximum is 0
+            gx[E:] = g
+        else:
+            _seg_bwd(mode, g, graph, arg, gy, gx[E:], relu_src=y)          # gy masked by ReLU; gx[E:] = g
         work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
         wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
         call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)

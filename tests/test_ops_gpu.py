@@ -389,3 +389,36 @@ def test_span_sum_with_few_long_segments(E, nseg, D):
     ref = torch.zeros(nseg, D, dtype=torch.float64).index_add_(0, seg, X.double()[xi])
     close(out, ref.float(), "span sum, long segments", rtol=2e-6 * (E / nseg) ** 0.5)
     assert torch.equal(out, K.span_gcs("copy", X.to(DEV), None, meta, plan))
+
+
+@pytest.mark.parametrize("N,E,R,D,hub", [(3000, 70000, 11, 200, False), (500, 90000, 7, 64, True), (4000, 20000, 5, 128, False), (64, 300, 3, 52, True)])
+def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
+    """a_max as one GEMM with the ReLU + segmented-max epilogue (mrg_linear_relu_segmax_fwd) against linear -> ReLU ->
+    segmented max as separate launches: outputs, argmax routing (ties included: half of the ReLU outputs are exact zeros) and
+    every gradient must be bit-identical; nodes without in-edges, a hub that spans many row tiles."""
+    gen = torch.Generator().manual_seed(N + E)
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N - 10, (E,), generator=gen)              # the last 10 nodes have no in-edge
+    if hub:
+        dst[: E // 2] = 3
+    et = torch.randint(0, R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32), device=DEV)
+    x0 = torch.randn(E + N, D, generator=gen)
+    W0 = torch.randn(D, D, generator=gen) / D ** 0.5
+    b0 = torch.randn(D, generator=gen) * 0.1
+    gout = torch.randn(N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for fused in (True, False):
+            K.FUSED_AMAX = fused
+            x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
+            out = K.linear_relu_aggregate("max", x, W, b, g)
+            out.backward(gout)
+            res[fused] = (out.detach(), x.grad, W.grad, b.grad)
+    finally:
+        K.FUSED_AMAX = True
+    assert int(mr_gnas_amd._lib.load().mrg_linear_relu_segmax_workspace_bytes(N, D, D)) > 0
+    for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
+        assert torch.equal(a, b_), what
+    ref = OO.a_max(OGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32)), {"linear.weight": W0, "linear.bias": b0}, x0, None)
+    close(res[True][0], ref, "fused a_max vs oracle")
