@@ -338,6 +338,40 @@ def test_c5_segmented_max_and_gather_bit_exact(c5):
     free()
 
 
+def test_c5_fused_amax(c5):
+    """a_max as one GEMM with the segmented-max epilogue at C5 (10 M gathered rows of 1 KiB, 2.56e8 64-bit keys): bit-exact
+    with the two-launch form (outputs and the [M, 256] input gradient), and against ReLU(linear) -> scatter amax on a column block."""
+    D = 256
+    g, N, E, gen = c5["g"], c5["N"], c5["E"], c5["gen"]
+    _, dst, _ = g.edges(form="all")
+    x0 = torch.randn(E + N, D, device=DEV, generator=gen)
+    W0 = torch.randn(D, D, device=DEV, generator=gen) / 16
+    b0 = torch.randn(D, device=DEV, generator=gen) * 0.1
+    gout = torch.randn(N, D, device=DEV, generator=gen)
+    keep = {}
+    try:
+        for fused in (True, False):
+            K.FUSED_AMAX = fused
+            x = x0.clone().requires_grad_(True)
+            out = K.linear_relu_aggregate("max", x, W0, b0, g)
+            out.backward(gout)
+            if fused:
+                keep = dict(out=out.detach(), gx=x.grad)
+            else:
+                assert torch.equal(keep["out"], out.detach()) and torch.equal(keep["gx"], x.grad)
+            del x, out
+            free()
+    finally:
+        K.FUSED_AMAX = True
+    cols = slice(64, 128)
+    y = torch.relu(x0[:E].double() @ W0[cols].double().t() + b0[cols].double()).float()
+    ref = torch.zeros(N, 64, device=DEV).scatter_reduce(0, dst.view(-1, 1).expand(E, 64), y, "amax", include_self=False) + x0[E:, cols]
+    err = float((keep["out"][:, cols] - ref).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"C5 fused a_max: {err:.3e}"
+    del keep, y, ref, x0
+    free()
+
+
 def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
     """The MixedOp epilogue, the K-way gradient sum and a dense filter at M = 11 M rows, D = 256 against float64 on
     a row sample (first / last rows and random ones)."""
