@@ -105,7 +105,8 @@ class Step:
         self.model = S.SearchNetwork(device, N, R, 2, 1, 2, 2, args.dim, 100, 2 * R + 1, 40.0, 0.3, 0.1).to(device)
         S.xavier_init_(self.model)
         self.model.train()
-        self.opt = torch.optim.SGD(self.model.parameters(), 1e-3, momentum=0.9, weight_decay=0.0)
+        self.params, self.arch = list(self.model.parameters()), list(self.model.arch_parameters())
+        self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         self.clip = 5.0
         self.last_loss = None
         self._args = args
@@ -138,10 +139,10 @@ class Step:
         ent, rel = self.model(self.g, self.node_id, self.src_in, self.edge_type)
         loss = self.model.get_loss(self.g, ent, rel, self.samples, self.labels)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        torch.nn.utils.clip_grad_norm_(self.params, self.clip)          # the list is built once: walking the module tree costs ~1 ms per step
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        for a in self.model.arch_parameters():
+        for a in self.arch:
             a.grad = None
         self.last_loss = loss.detach()
 

@@ -476,7 +476,8 @@ class ShardedStep:
         self.samples = torch.from_numpy(samples[lo[rank]:lo[rank + 1]]).to(device)
         self.labels = torch.from_numpy(labels[lo[rank]:lo[rank + 1]]).to(device)
         self.total_samples = len(samples)
-        self.opt = torch.optim.SGD(self.model.parameters(), 1e-3, momentum=0.9, weight_decay=0.0)
+        self.params, self.arch = list(self.model.parameters()), list(self.model.arch_parameters())
+        self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         self.clip, self.group, self.last_loss = 5.0, group, None
         torch.manual_seed(args.seed + 1000 + rank)         # dropout masks differ per rank (disjoint rows)
 
@@ -484,12 +485,11 @@ class ShardedStep:
         ent, rel = self.net.forward()
         loss = self.net.loss(ent, rel, self.samples, self.labels, self.total_samples)
         loss.backward()
-        params = list(self.model.parameters())
-        all_reduce_gradients(params + self.model.arch_parameters()[:4], self.group)
-        torch.nn.utils.clip_grad_norm_(params, self.clip)
+        all_reduce_gradients(self.params + self.arch[:4], self.group)
+        torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        for a in self.model.arch_parameters():
+        for a in self.arch:
             a.grad = None
         total = loss.detach().clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)

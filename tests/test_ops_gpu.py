@@ -408,7 +408,9 @@ def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
     b0 = torch.randn(D, generator=gen) * 0.1
     gout = torch.randn(N, D, generator=gen).to(DEV)
     res = {}
+    min_rows = K.FUSED_AMAX_MIN_ROWS
     try:
+        K.FUSED_AMAX_MIN_ROWS = 0
         for fused in (True, False):
             K.FUSED_AMAX = fused
             x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
@@ -416,7 +418,7 @@ def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
             out.backward(gout)
             res[fused] = (out.detach(), x.grad, W.grad, b.grad)
     finally:
-        K.FUSED_AMAX = True
+        K.FUSED_AMAX, K.FUSED_AMAX_MIN_ROWS = True, min_rows
     assert int(mr_gnas_amd._lib.load().mrg_linear_relu_segmax_workspace_bytes(N, D, D)) > 0
     for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
         assert torch.equal(a, b_), what
