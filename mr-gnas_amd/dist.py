@@ -421,8 +421,12 @@ class ShardedSupernet:
         ent = None
         for l, cell in enumerate(m.cells):
             wz, wf, wm, wl = m.layer_weights(l)
-            x = self.k.gather(ent_all, self.p_ent0) if l == 0 else self.k.gather(ent, self.p_ent)
-            own = sync_batch_norm(self._cell(cell, x, self.k.gather(rel, self.p_rel), wz, wf, wm, wl), m.batchnorm_h, N, self.group)
+            table, plan = (ent_all, self.p_ent0) if l == 0 else (ent, self.p_ent)
+            if table.is_cuda and self.k is K:              # cell zero's compose candidates gather on the fly (supernet.SearchNetwork.forward)
+                x, hr = K.LazyRows(table, plan), K.LazyRows(rel, self.p_rel)
+            else:
+                x, hr = self.k.gather(table, plan), self.k.gather(rel, self.p_rel)
+            own = sync_batch_norm(self._cell(cell, x, hr, wz, wf, wm, wl), m.batchnorm_h, N, self.group)
             if l > 0 or m._layers == 1:
                 own = F.relu(own)
             own = F.dropout(own, m._dropout, training=m.training)

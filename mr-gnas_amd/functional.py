@@ -391,6 +391,17 @@ class _LinReluPartial(torch.autograd.Function):
         require_hip(x, W, b)
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         st = stream_of(x)
+        fused_ws = _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) if (mode == 2 and FUSED_AMAX and E >= FUSED_AMAX_MIN_ROWS) else 0
+        if fused_ws > 0:                                # one GEMM with the ReLU + segmented-max epilogue, as in _LinReluAgg
+            out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            arg = torch.empty(N, D, dtype=torch.int32, device=x.device)
+            mx = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            call("mrg_linear_relu_segmax_fwd", (ptr(x), ptr(W), ptr(b), ptr(graph.plan()["eid"]), ptr(graph.i32("dst")), None, ptr(out), ptr(arg),
+                                                ptr(mx), ptr(_ws(fused_ws, x)), E, N, D, D, st),
+                 nbytes=4 * E * D + 8 * E + 4 * D * D + 4 * N * D * 3, flops=2 * E * D * D)
+            ctx.mode, ctx.graph, ctx.fused = mode, graph, True
+            ctx.save_for_backward(x, W, arg, mx)
+            return out, x[E:].clone()
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
         gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
         call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
@@ -400,14 +411,17 @@ class _LinReluPartial(torch.autograd.Function):
         else:
             sp, meta = graph.agg_plan("sum")
             out, arg = span_gcs("copy", y, None, meta, sp), None
-        ctx.mode, ctx.graph = mode, graph
+        ctx.mode, ctx.graph, ctx.fused = mode, graph, False
         ctx.save_for_backward(x, W, y, *((arg,) if arg is not None else ()))
         return out, x[E:].clone()                       # the residual self rows leave through the same node
 
     @staticmethod
     def backward(ctx, g, gself):
-        x, W, y, *rest = ctx.saved_tensors
-        arg = rest[0] if rest else None
+        if ctx.fused:
+            x, W, arg, mx = ctx.saved_tensors
+        else:
+            x, W, y, *rest = ctx.saved_tensors
+            arg = rest[0] if rest else None
         graph, mode = ctx.graph, ctx.mode
         E, D = graph.num_edges(), x.shape[1]
         g = f32c(g) if g is not None else torch.zeros(graph.number_of_nodes(), D, dtype=torch.float32, device=x.device)
@@ -418,7 +432,10 @@ class _LinReluPartial(torch.autograd.Function):
         else:
             gx[E:].zero_()
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
-        _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)            # gy masked by ReLU
+        if ctx.fused:
+            _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)          # the winning message is ReLU-dead iff the maximum is 0
+        else:
+            _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)        # gy masked by ReLU
         work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
         wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
         call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
