@@ -362,6 +362,11 @@ def main():
         raise SystemExit("mrg_gemm_set_mode failed")
 
     sharded = world > 1 or os.environ.get("MRG_FORCE_SHARDED") == "1"     # the env switch rehearses the N>1 code on one GPU
+    if args.hip_graph:
+        # a captured step runs on ONE stream: capturing the candidate / segment side streams of the full-size step
+        # segfaults inside the HIP runtime (with and without RCCL in the capture)
+        os.environ["MRG_MIXED_STREAMS"] = "1"
+        os.environ["MRG_SEGMENT_STREAMS"] = "1"
     if sharded:
         if args.hip_graph:
             # Capturing a step that contains RCCL collectives works (measured with an RCCL group of one rank: 300-edge graph
