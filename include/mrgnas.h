@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 4   /* 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 5   /* 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -301,6 +301,28 @@ int mrg_linear_bwd_weight(const float *gY, const float *X1, const float *X2, flo
 int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const float *W, const float *bias,
                          const float *rowscale, float scale, float *out, float *gate, void *ws,
                          int64_t rows, int D, void *stream);
+/* The three direction segments of one dense filter in ONE launch each (weight split + grouped row GEMM) instead of three:
+ * rows [0, b0) use W[0] / bias[0], [b0, b1) W[1] / bias[1] (edge rows: c = scale_edge * norm[row]), [b1, M) W[2] / bias[2]
+ * (self rows: c = scale_self).  W / bias: HOST arrays of three device pointers (bias entries may be NULL).  Split core
+ * only: mrg_dense_filter3_workspace_bytes(D, K) returns 0 when the shape does not qualify (then use the per-segment
+ * entry point).  Same arithmetic per row as mrg_dense_filter_fwd: results are bit-identical. */
+int64_t mrg_dense_filter3_workspace_bytes(int D, int K);
+int mrg_dense_filter_fwd3(int kind, const float *s, const float *s_in, const float *const *W, const float *const *bias,
+                          const float *norm, float scale_edge, float scale_self, float *out, float *gate, void *ws,
+                          int64_t b0, int64_t b1, int64_t M, int D, void *stream);
+/* dz (and the direct term of gs) for all M rows of the three segments in one launch: rows [0, b1) c = scale_edge * norm[row],
+ * rows [b1, M) c = scale_self (see mrg_dense_filter_dz). */
+int mrg_dense_filter_dz3(int kind, const float *g, const float *s, const float *gate, const float *norm, float scale_edge,
+                         float scale_self, float *dz, float *gs, int64_t b1, int64_t M, int D, void *stream);
+/* mrg_linear_bwd_input / mrg_linear_bwd_weight for the three row ranges [0, b0) [b0, b1) [b1, M) with their own weights
+ * W[0..2] (HOST array of device pointers, each [Nout][ldw]) in one launch each.  The *_workspace_bytes queries return 0
+ * when the split core cannot take the shape or mrg_gemm_set_mode(1) is active: use the per-range entry points then. */
+int64_t mrg_linear_bwd_input3_workspace_bytes(int K, int Nout);
+int mrg_linear_bwd_input3(const float *gY, const float *const *W, float *gX, void *ws, int64_t b0, int64_t b1, int64_t M,
+                          int K, int Nout, int ldw, int accumulate, void *stream);
+int64_t mrg_linear_bwd_weight3_workspace_bytes(int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout);
+int mrg_linear_bwd_weight3(const float *gY, const float *X1, const float *X2, float *const *gW, float *const *gbias, void *ws,
+                           int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout, void *stream);
 /* backward, step 1:  kind 0: dz = g*s*c*gate*(1-gate), gs = g*c*gate (direct term);  kind 1: dz = g*c.
  * Steps 2-3 are mrg_linear_bwd_input (gs += dz W[:, :D]; gs_in = dz W[:, D:]) and
  * mrg_linear_bwd_weight (gW = dz^T [s | s_in], gbias = column sums of dz). */

@@ -30,6 +30,19 @@ constexpr int GBM_MAX = 256;      // rows per workgroup = 128 * MT (MT row tiles
 
 enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3, EPI_SEGMAX = 4 };
 
+// Up to three row ranges of ONE launch of the split-core row GEMM that share every tensor but differ in the weight matrix
+// (the in / out / self direction segments of a dense filter: one launch instead of three).  Workgroup blocks
+// [tile0[s], tile0[s+1]) own range s = rows [lo[s], hi[s]) (absolute row numbers of the shared tensors).
+struct GemmGroups {
+  int n;                              // 0: plain GEMM over rows [0, rows)
+  int tile0[4];
+  int64_t lo[3], hi[3];
+  int64_t bp_stride;                  // range s reads the pre-split weight at Bp + s * bp_stride (launch_bsplit3)
+  const float* bias[3];
+  float scale[3];
+  int use_rowscale[3];
+};
+
 struct GemmArgs {
   const float* A1; const float* A2;   // [rows][K1], [rows][K2] row-major; A2 may be NULL (K2 = 0)
   int K1, K2;
@@ -47,6 +60,7 @@ struct GemmArgs {
   // EPI_SEGMAX (no C): seg_out[row_seg[row_index[r]] * N + col] = max over rows r of pack(ReLU(acc + bias), r), see gemm_epilogue_segmax
   const int32_t* row_seg;
   unsigned long long* seg_out;
+  GemmGroups grp;                     // split core, one-wave kernel only
 };
 
 // ---- a_max: ReLU + destination-segmented max as the GEMM's epilogue (reference models/operations_lp.py:230-234) ----------

@@ -108,6 +108,38 @@ inline void launch_bsplit(const float* B, int64_t sn, int64_t sk, int N, int K, 
   hipLaunchKernelGGL(bsplit_k, dim3((total + 255) / 256), dim3(256), 0, st, B, sn, sk, N, K, ntile, nslab, (u32x4*)Bp);
 }
 
+// up to three weights of the same shape in one launch (blockIdx.y): the direction segments of a dense filter
+struct BSplit3 { const float* B[3]; u32x4* out[3]; };
+static __global__ void bsplit3_k(BSplit3 p, int64_t sn, int64_t sk, int N, int K, int ntile, int nslab) {
+  const float* __restrict__ B = p.B[blockIdx.y];
+  u32x4* __restrict__ Bp = p.out[blockIdx.y];
+  if (!B) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nslab * ntile * 64) return;
+  const int lane = idx & 63, tile = (idx >> 6) % ntile, slab = (idx >> 6) / ntile;
+  const int n = tile * 32 + (lane & 31), k0 = slab * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? B[n * sn + (k0 + j) * sk] : 0.f;
+  u32x4 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a, b, c;
+    split_pair(v[2 * j], v[2 * j + 1], a, b, c);
+    h[j] = a; m[j] = b; l[j] = c;
+  }
+  u32x4* o = Bp + ((int64_t)(slab * ntile + tile) * 3) * 64 + lane;
+  o[0] = h; o[64] = m; o[128] = l;
+}
+
+inline void launch_bsplit3(const float* const* B, int64_t sn, int64_t sk, int N, int K, int nt, void* const* out, hipStream_t st) {
+  const int ntile = x3_tiles(N, nt), nslab = x3_slabs(K);
+  const int total = nslab * ntile * 64;
+  BSplit3 p{};
+  for (int i = 0; i < 3; ++i) { p.B[i] = B[i]; p.out[i] = (u32x4*)out[i]; }
+  hipLaunchKernelGGL(bsplit3_k, dim3((total + 255) / 256, 3), dim3(256), 0, st, p, sn, sk, N, K, ntile, nslab);
+}
+
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n <= 63
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #define MRG_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -141,7 +173,7 @@ constexpr int X3_SLOTS = 4;         // per-wave LDS ring of A slabs
 // inside the wave's own instruction stream: the in-order vmcnt counter is waited on with the exact number
 // of younger operations (3 per column tile, 2*MT per A slab), never drained.
 template <int NT, int MT, int EPI, bool DUAL>
-__global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
+__global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {   // a and Bp are re-pointed by a grouped launch
   constexpr int WROWS = 32 * MT, GBM = WROWS * (X3_THREADS / 64);
   constexpr int SLOT_CH = WROWS * 4;          // 16-byte chunks per ring slot
   constexpr int NA = SLOT_CH / 64;            // DMA instructions per slab
@@ -153,7 +185,23 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int64_t roww = (int64_t)blockIdx.x * GBM + wave * WROWS;
+  int64_t row0 = (int64_t)blockIdx.x * GBM;
+  // grouped launch: this workgroup's row range and its weight.  The range index and the weight pointer are formed by
+  // unconditional scalar arithmetic (bp_stride = 0 in a plain launch): the B loads address through an SGPR pair.
+  int sg = 0;
+  if (a.grp.n > 0) sg = ((int)blockIdx.x >= a.grp.tile0[1] ? 1 : 0) + ((int)blockIdx.x >= a.grp.tile0[2] ? 1 : 0);
+  sg = __builtin_amdgcn_readfirstlane(sg);
+  const char* __restrict__ Bq = Bp + (int64_t)sg * a.grp.bp_stride;
+  if (a.grp.n > 0) {                                     // constant indices only: a dynamic one would move the argument block to scratch
+#define MRG_PICK(F) (sg == 0 ? a.grp.F[0] : (sg == 1 ? a.grp.F[1] : a.grp.F[2]))
+    row0 = MRG_PICK(lo) + (int64_t)((int)blockIdx.x - MRG_PICK(tile0)) * GBM;
+    a.rows = MRG_PICK(hi);
+    a.bias = MRG_PICK(bias);
+    a.scale = MRG_PICK(scale);
+    if (!MRG_PICK(use_rowscale)) a.rowscale = nullptr;
+#undef MRG_PICK
+  }
+  const int64_t roww = row0 + wave * WROWS;
   const int col0 = blockIdx.y * (NT * 32);
   const int K = a.K1 + a.K2;
   const int nslab = (K + 15) >> 4;
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   // the wait would read stale registers -- the float64 comparisons of tests/test_ops_gpu.py would catch that.
   u32x4 bq[NT][3];
   const unsigned voff = (unsigned)lane * 16u;
-  const char* bcol = Bp + (int64_t)blockIdx.y * NT * 3072;
+  const char* bcol = Bq + (int64_t)blockIdx.y * NT * 3072;
   auto load_b = [&](int n, int slab) {
     const char* sb = bcol + ((int64_t)slab * ntile + n) * 3072;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[n][0]) : "v"(voff), "s"(sb));
@@ -327,7 +375,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc[m], roww + m * 32, col0, li, lh);
-    else gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, (int64_t)blockIdx.x * GBM + GBM <= a.rows);
+    else gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, row0 + GBM <= a.rows);
   }
   if (MRG_X3_DBG & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MRG_X3_STAMP(trace_slot, 3); }
 }
@@ -345,7 +393,15 @@ inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st) {
   const int ntile = x3_tiles(a.N, nt);
   const int mt = a.rows > 128 * 512 ? 2 : 1;            // short operands: more, smaller workgroups
   const int gbm = 32 * mt * (X3_THREADS / 64);
-  dim3 grid((unsigned)((a.rows + gbm - 1) / gbm), (unsigned)(ntile / nt));
+  if (a.grp.n > 0) {                                    // grouped: blocks of range s follow those of range s - 1
+    a.grp.tile0[0] = 0;
+    for (int i = 0; i < 3; ++i) {
+      const int64_t r = i < a.grp.n && a.grp.hi[i] > a.grp.lo[i] ? a.grp.hi[i] - a.grp.lo[i] : 0;
+      a.grp.tile0[i + 1] = a.grp.tile0[i] + (int)((r + gbm - 1) / gbm);
+    }
+    if (a.grp.tile0[3] == 0) return MRG_OK;
+  }
+  dim3 grid((unsigned)(a.grp.n > 0 ? a.grp.tile0[3] : (a.rows + gbm - 1) / gbm), (unsigned)(ntile / nt));
   const size_t lds = (size_t)(X3_THREADS / 64) * X3_SLOTS * 32 * mt * 64;
 #define MRG_GOX2(NTV, MTV, DV)                                                                                        \
   do {                                                                                                                \

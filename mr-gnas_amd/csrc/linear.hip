@@ -18,6 +18,10 @@ struct WgradArgs {
   float* ws;
   int64_t rows, rows_per_block;
   int TM, TN, TNB;
+  // grouped launch (wgrad_x3_k / wgrad_reduce_k, gridDim.z = 3): row range, plan and partial-tile workspace of range z
+  int ngrp;
+  int64_t g_lo[3], g_hi[3], g_rpb[3], g_ws_off[3];      // g_ws_off in floats
+  int g_G[3];
 };
 
 // X' = [X1 | X2 | 1 | 0...]: which tensor / local column a global column c maps to
@@ -317,9 +321,20 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
   int64_t r_end = r_begin + a.rows_per_block;
   if (r_end > a.rows) r_end = a.rows;
+  int64_t ws_off = 0;
+  if (a.ngrp > 0) {                                       // one row range per blockIdx.z (constant indices: no scratch copy of the arguments)
+    const int z = blockIdx.z;
+#define MRG_PICKZ(F) (z == 0 ? a.F[0] : (z == 1 ? a.F[1] : a.F[2]))
+    if ((int)blockIdx.x >= MRG_PICKZ(g_G)) return;          // workgroup-uniform, before any barrier
+    const int64_t rpb = MRG_PICKZ(g_rpb), hi = MRG_PICKZ(g_hi);
+    r_begin = MRG_PICKZ(g_lo) + (int64_t)blockIdx.x * rpb;
+    r_end = r_begin + rpb < hi ? r_begin + rpb : hi;
+    ws_off = MRG_PICKZ(g_ws_off);
+#undef MRG_PICKZ
+  }
 
   // loop-invariant DMA metadata of this thread's chunks
   const float* src[NPF]; int64_t stride[NPF]; int rr[NPF]; int kind[NPF];     // kind: 0 data, 1 ones, 2 zeros
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
     cur = cur == SLOTS - 1 ? 0 : cur + 1;
   }
   const int ldw = a.TN * 32;
-  float* out = a.ws + (int64_t)blockIdx.x * (a.TM * 32) * ldw;
+  float* out = a.ws + ws_off + (int64_t)blockIdx.x * (a.TM * 32) * ldw;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -458,6 +473,33 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
 __global__ void wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
                                int G, int K, int Nout, int ldg, int ldx) {
   __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  if (c <= K)
+    for (int g = ty; g < G; g += 16) acc += ws[((int64_t)g * ldg + n) * ldx + c];
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c <= K) {
+    float tot = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tot += part[i][tx];
+    if (c < K) gW[(int64_t)n * K + c] = tot;
+    else if (gbias) gbias[n] = tot;
+  }
+}
+
+// the same for up to three row ranges in one launch (blockIdx.z)
+struct WgradReduce3 { const float* ws[3]; float* gW[3]; float* gbias[3]; int G[3]; };
+__global__ void wgrad_reduce3_k(WgradReduce3 p, int K, int Nout, int ldg, int ldx) {
+  __shared__ float part[16][64];
+  const int z = blockIdx.z;
+  const float* __restrict__ ws = z == 0 ? p.ws[0] : (z == 1 ? p.ws[1] : p.ws[2]);
+  float* __restrict__ gW = z == 0 ? p.gW[0] : (z == 1 ? p.gW[1] : p.gW[2]);
+  float* __restrict__ gbias = z == 0 ? p.gbias[0] : (z == 1 ? p.gbias[1] : p.gbias[2]);
+  const int G = z == 0 ? p.G[0] : (z == 1 ? p.G[1] : p.G[2]);
+  if (!gW) return;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   const int n = blockIdx.y;
@@ -714,6 +756,105 @@ extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, 
     return launch_gemm<EPI_ACCUM>(a, 1, ldw, ws, st);
   }
   return launch_gemm<EPI_BIAS_ACT>(a, 1, ldw, ws, st);
+}
+
+// ---- the three direction segments of a dense filter in one launch each (split core only) -----------------------------------
+// gX rows [0, b0) (+)= gY W[0][:, 0:K], rows [b0, b1) with W[1], rows [b1, M) with W[2]; W: HOST array of three device
+// pointers to [Nout][ldw] weights (a column block when offset by the caller).
+static size_t bwd_input3_each(int K, int Nout) { return (size_t)(((int64_t)x3_bsplit_bytes(K, Nout, gemm_pick_nt(K)) + 255) / 256 * 256); }
+
+extern "C" int64_t mrg_linear_bwd_input3_workspace_bytes(int K, int Nout) {
+  if (K <= 0 || Nout <= 48 || Nout % 4 != 0 || gemm_mode() == 1) return 0;      // 0: the split core cannot take the shape / is switched off
+  return 3 * (int64_t)bwd_input3_each(K, Nout);
+}
+
+extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host, float* gX, void* ws, int64_t b0, int64_t b1, int64_t M,
+                                     int K, int Nout, int ldw, int accumulate, void* stream) {
+  if (K <= 0 || Nout <= 0 || ldw < K || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (K <= 0 || Nout <= 48 || Nout % 4 != 0) return MRG_E_SHAPE;
+  if (M == 0) return MRG_OK;
+  if (!gY || !W_host || !gX) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.A1 = gY; a.K1 = Nout; a.C = gX; a.ldc = K; a.N = K; a.rows = M; a.act = MRG_ACT_NONE;
+  if (accumulate) { a.Cin = gX; a.ld_cin = K; }
+  if (!x3_eligible(a)) return MRG_E_SHAPE;
+  const int64_t lo[3] = {0, b0, b1}, hi[3] = {b0, b1, M};
+  const size_t each = bwd_input3_each(K, Nout);
+  const float* Bs[3]; void* outs[3];
+  a.grp.n = 3;
+  a.grp.bp_stride = (int64_t)each;
+  for (int i = 0; i < 3; ++i) {
+    const bool live = hi[i] > lo[i];
+    if (live && !W_host[i]) return MRG_E_NULLPTR;
+    Bs[i] = live ? W_host[i] : nullptr;
+    outs[i] = (char*)ws + i * each;
+    a.grp.lo[i] = lo[i]; a.grp.hi[i] = live ? hi[i] : lo[i];
+    a.grp.scale[i] = 1.0f;
+  }
+  launch_bsplit3(Bs, 1, ldw, K, Nout, gemm_pick_nt(K), outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
+  MRG_LAUNCH_CHECK();
+  if (accumulate) return launch_rowgemm_x3<EPI_ACCUM>(a, outs[0], st);
+  return launch_rowgemm_x3<EPI_BIAS_ACT>(a, outs[0], st);
+}
+
+// gW[s][Nout][K1+K2] = gY[lo_s:hi_s]^T [X1 | X2][lo_s:hi_s], gbias[s] = column sums, for the three row ranges in one launch
+static bool wgrad3_ok(int K1, int K2, int Nout) {
+  return Nout >= 4 && Nout <= 224 && Nout % 4 == 0 && K1 >= 4 && K1 % 4 == 0 && K2 >= 0 && K2 % 4 == 0;
+}
+
+extern "C" int64_t mrg_linear_bwd_weight3_workspace_bytes(int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout) {
+  if (M < 0 || b0 < 0 || b1 < b0 || M < b1 || !wgrad3_ok(K1, K2, Nout) || gemm_mode() == 1) return 0;
+  const int64_t rows[3] = {b0, b1 - b0, M - b1};
+  int64_t total = 0;
+  for (int i = 0; i < 3; ++i) total += (wgrad_workspace_bytes(rows[i], K1 + K2, Nout) + 255) / 256 * 256;
+  return total;
+}
+
+extern "C" int mrg_linear_bwd_weight3(const float* gY, const float* X1, const float* X2, float* const* gW_host, float* const* gb_host, void* ws,
+                                      int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout, void* stream) {
+  if (M < 0 || b0 < 0 || b1 < b0 || M < b1 || !wgrad3_ok(K1, K2, Nout)) return MRG_E_SHAPE;
+  if (!gW_host) return MRG_E_NULLPTR;
+  if (M > 0 && (!gY || !X1 || (K2 > 0 && !X2))) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  if (!aligned16(gY) || !aligned16(X1) || (K2 > 0 && !aligned16(X2))) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int K = K1 + K2;
+  const int64_t lo[3] = {0, b0, b1}, hi[3] = {b0, b1, M};
+  WgradArgs a{};
+  a.gY = gY; a.Nout = Nout; a.ldg = Nout; a.X1 = X1; a.X2 = K2 > 0 ? X2 : X1; a.K1 = K1; a.K2 = K2; a.ws = (float*)ws; a.rows = M;
+  a.ngrp = 3;
+  WgradReduce3 red{};
+  int maxG = 0;
+  int64_t off = 0;
+  WgradPlan p0 = wgrad_plan(1, K, Nout, true);
+  if (!p0.ok || p0.TM > 7) return MRG_E_SHAPE;
+  a.TM = p0.TM; a.TN = p0.TN; a.TNB = p0.TNB;
+  for (int i = 0; i < 3; ++i) {
+    const int64_t rows = hi[i] - lo[i];
+    WgradPlan p = wgrad_plan(rows, K, Nout, true);
+    const bool live = gW_host[i] != nullptr;
+    a.g_lo[i] = lo[i]; a.g_hi[i] = hi[i]; a.g_rpb[i] = p.rows_per_block; a.g_G[i] = live ? p.G : 0; a.g_ws_off[i] = off / (int64_t)sizeof(float);
+    red.ws[i] = (const float*)((const char*)ws + off); red.gW[i] = gW_host[i]; red.gbias[i] = gb_host ? gb_host[i] : nullptr; red.G[i] = p.G;
+    off += (wgrad_workspace_bytes(rows, K, Nout) + 255) / 256 * 256;
+    if (live && p.G > maxG) maxG = p.G;
+  }
+  if (maxG == 0) return MRG_OK;
+  const int ng = a.TM <= 4 ? 1 : 2, kt = 16 / ng;
+  dim3 gridx(maxG, (a.TN + kt - 1) / kt, 3);
+  const size_t ldsx = (size_t)(ng == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
+  if (ng == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+    hipLaunchKernelGGL((wgrad_x3_k<1>), gridx, dim3(WX_THREADS), ldsx, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+    hipLaunchKernelGGL((wgrad_x3_k<2>), gridx, dim3(WX_THREADS), ldsx, st, a);
+  }
+  MRG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_reduce3_k, dim3((K + 1 + 63) / 64, Nout, 3), dim3(1024), 0, st, red, K, Nout, a.TM * 32, a.TN * 32);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
 }
 
 extern "C" int64_t mrg_linear_bwd_weight_workspace_bytes(int64_t rows, int K, int Nout) {

@@ -959,6 +959,9 @@ class Fork:
             self.main.wait_stream(st)
 
 
+GROUPED_SEGMENTS = os.environ.get("MRG_GROUPED_SEGMENTS", "1") == "1"    # lab switch: 0 = one launch per direction segment
+
+
 class _DenseFilter(torch.autograd.Function):
     """Three direction segments [0,b0) [b0,b1) [b1,M), each with its own nn.Linear (W, b);
     params flat: W_in, b_in, W_out, b_out, W_self, b_self (None for an absent segment / bias).
@@ -974,6 +977,15 @@ class _DenseFilter(torch.autograd.Function):
         out = torch.empty_like(s)
         gate = torch.empty_like(s) if kind == 0 else None
         K_ = 2 * D if s_in is not None else D
+        ws3 = int(_lib.load().mrg_dense_filter3_workspace_bytes(D, K_)) if (GROUPED_SEGMENTS and all(params[2 * i] is not None for i in range(3))) else 0
+        if ws3 > 0:                                     # the three direction segments in one weight-split + one grouped GEMM launch
+            call("mrg_dense_filter_fwd3", (kind, ptr(s), ptr(s_in), ptr_array([params[0], params[2], params[4]]),
+                                           ptr_array([params[1], params[3], params[5]]), ptr(norm), scale_edge, scale_self, ptr(out), ptr(gate),
+                                           ptr(_ws(ws3, s)), b0, b1, M, D, st),
+                 nbytes=4 * M * (K_ + D * (2 if kind == 0 else 1)), flops=2 * M * K_ * D)
+            ctx.cfg = (kind, b0, b1, scale_edge, scale_self)
+            ctx.save_for_backward(s, s_in, norm, gate, *params)
+            return out
         segs = [(i, lo, hi, scale, edge) for i, (lo, hi, scale, edge) in
                 enumerate(((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))) if hi > lo]
         gws = [_ws(_ws_bytes("mrg_gemm_workspace_bytes", K_, D), s) for _ in segs]
@@ -1001,6 +1013,25 @@ class _DenseFilter(torch.autograd.Function):
         gs = torch.empty_like(s)
         gs_in = torch.empty_like(s) if s_in is not None else None
         K_ = 2 * D if s_in is not None else D
+        lib = _lib.load()
+        if GROUPED_SEGMENTS and all(params[2 * i] is not None for i in range(3)):
+            wsi, wsw = int(lib.mrg_linear_bwd_input3_workspace_bytes(D, D)), int(lib.mrg_linear_bwd_weight3_workspace_bytes(b0, b1, M, D, K_ - D, D))
+            if wsi > 0 and wsw > 0:                     # the three direction segments in one launch per stage: 7 - 9 launches instead of 21 - 27
+                Ws = [params[0], params[2], params[4]]
+                gWs = [torch.empty_like(W) for W in Ws]
+                gbs = [torch.empty_like(params[2 * i + 1]) if params[2 * i + 1] is not None else None for i in range(3)]
+                dz = torch.empty(M, D, dtype=torch.float32, device=s.device)
+                call("mrg_dense_filter_dz3", (kind, ptr(g), ptr(s), ptr(gate), ptr(norm), scale_edge, scale_self, ptr(dz), ptr(gs), b1, M, D, st),
+                     nbytes=4 * M * D * (5 if kind == 0 else 2))
+                gwork = dict(nbytes=4 * M * 2 * D + 12 * D * D, flops=2 * M * D * D)
+                call("mrg_linear_bwd_input3", (ptr(dz), ptr_array(Ws), ptr(gs), ptr(_ws(wsi, s)), b0, b1, M, D, D, K_, int(kind == 0), st), **gwork)
+                if s_in is not None:
+                    call("mrg_linear_bwd_input3", (ptr(dz), ptr_array([W[:, D:] for W in Ws]), ptr(gs_in), ptr(_ws(wsi, s)), b0, b1, M, D, D, K_, 0, st),
+                         **gwork)
+                call("mrg_linear_bwd_weight3", (ptr(dz), ptr(s), ptr(s_in), ptr_array(gWs), ptr_array(gbs), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st),
+                     nbytes=4 * M * (D + K_), flops=2 * M * K_ * D)
+                grads = [t for pair in zip(gWs, gbs) for t in pair]
+                return (None, gs, gs_in, None, None, None, None, None, *grads)
         grads = []
         segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
         work = []

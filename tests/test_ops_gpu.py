@@ -424,3 +424,34 @@ def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
         assert torch.equal(a, b_), what
     ref = OO.a_max(OGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32)), {"linear.weight": W0, "linear.bias": b0}, x0, None)
     close(res[True][0], ref, "fused a_max vs oracle")
+
+
+@pytest.mark.parametrize("kind,tied", [("f_dense_comp", False), ("f_comp", False), ("f_dense_comp", True), ("f_comp", True)])
+@pytest.mark.parametrize("N,E,R,D", [(2000, 90000, 9, 200), (300, 5000, 4, 64), (50, 0, 2, 64)])
+def test_grouped_direction_segments_are_bit_exact(kind, tied, N, E, R, D):
+    """The dense filters with their three direction segments in one launch each (mrg_dense_filter_fwd3 / ..._bwd3 entry
+    points) against one launch per segment: outputs and every gradient bit-identical (same per-row arithmetic); ragged
+    segment boundaries, an empty graph (self rows only)."""
+    gen = torch.Generator().manual_seed(N + E + D)
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    et = torch.randint(0, 2 * R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    op = O.MIXED_OPS[kind]({"feature_dim": D}).to(DEV)
+    a0 = torch.randn(E + N, D, generator=gen)
+    b0 = a0 if tied else torch.randn(E + N, D, generator=gen)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for grouped in (True, False):
+            K.GROUPED_SEGMENTS = grouped
+            a = a0.clone().to(DEV).requires_grad_(True)
+            b = a if tied else b0.clone().to(DEV).requires_grad_(True)
+            op.zero_grad()
+            out = op(g, a, b)
+            out.backward(gout)
+            res[grouped] = [out.detach(), a.grad] + ([] if tied else [b.grad]) + [p.grad.clone() for p in op.parameters()]
+    finally:
+        K.GROUPED_SEGMENTS = True
+    for x, y in zip(res[True], res[False]):
+        assert torch.equal(x, y)
