@@ -419,8 +419,9 @@ class ShardedSupernet:
         rel = torch.mm(m.rel_wt, m.embedding_e.weight)
         N = s.number_of_nodes()
         ent = None
+        weights = m.row_weights()
         for l, cell in enumerate(m.cells):
-            wz, wf, wm, wl = m.layer_weights(l)
+            wz, wf, wm, wl = weights[l]
             table, plan = (ent_all, self.p_ent0) if l == 0 else (ent, self.p_ent)
             if table.is_cuda and self.k is K:              # cell zero's compose candidates gather on the fly (supernet.SearchNetwork.forward)
                 x, hr = K.LazyRows(table, plan), K.LazyRows(rel, self.p_rel)

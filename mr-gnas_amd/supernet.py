@@ -201,6 +201,14 @@ class SearchNetwork(nn.Module):
         sl = lambda t, n: F.softmax(t[l * n:(l + 1) * n], dim=1)
         return sl(a[0], self.nz), sl(a[1], self.n_first_edges), sl(a[2], self.nf), sl(a[3], self.n_last_edges)
 
+    def row_weights(self):
+        """layer_weights for every layer, each matrix as a tuple of its [K] rows: ONE softmax and ONE unbind per architecture
+        parameter and step.  (Slicing a layer and indexing a row per MixedOp costs a select, a zero-filled gradient, a copy and
+        an accumulate each: ~65 tiny launches per step, which a 30 000-edge step notices.)"""
+        ns = (self.nz, self.n_first_edges, self.nf, self.n_last_edges)
+        rows = [F.softmax(t, dim=1).unbind(0) for t in self._arch_parameters[:4]]
+        return [tuple(r[l * n:(l + 1) * n] for r, n in zip(rows, ns)) for l in range(self._layers)]
+
     def prepare(self, g, node_id, src_in, edge_type):
         """Gather indices of a step graph: (ent plan, rel plan, layer>=2 plan).  Cached on the graph object
         for as long as the SAME index tensors are passed unmodified (identity + in-place version); anything
@@ -222,8 +230,9 @@ class SearchNetwork(nn.Module):
         rel = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel, p_in = self._plans(g_train, node_id, src_in, edge_type)
         ent = None
+        weights = self.row_weights()
         for l, cell in enumerate(self.cells):
-            wz, wf, wm, wl = self.layer_weights(l)
+            wz, wf, wm, wl = weights[l]
             # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
             x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
             ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
