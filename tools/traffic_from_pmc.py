@@ -21,7 +21,6 @@ import sys
 ENTRY_KERNELS = {
     "mrg_linear_bwd_weight": ["wgrad_x3_k", "wgrad_reduce_k"],
     "mrg_linear_bwd_input": ["rowgemm_x3_k<7, 2, 0"],
-    "mrg_linear_bwd_input2": ["rowgemm_x3_k<7, 2, 4"],
     "mrg_dense_filter_fwd": ["rowgemm_x3_k<7, 2, 1"],
     "mrg_sum_buffers": ["sum_k"],
     "mrg_distmult_score": ["distmult_k"],
@@ -35,6 +34,12 @@ ENTRY_KERNELS = {
     "mrg_compose_bwd": ["compose_bwd_k"],
     "mrg_seg_reduce_bwd": ["seg_bwd_k"],
     "mrg_dense_filter_dz": ["dense_dz_k"],
+    # the three-segment entry points run the same kernels over all M rows: their dispatches are the ones with the largest grid
+    "mrg_dense_filter_fwd3": ["rowgemm_x3_k<7, 2, 1@max|rowgemm_x3_k<7, 2, 2@max"],      # a|b: one or the other per call
+    "mrg_linear_bwd_input3": ["rowgemm_x3_k<7, 2, 0@max|rowgemm_x3_k<7, 2, 3@max"],
+    "mrg_linear_bwd_weight3": ["wgrad_x3_k@max", "wgrad_reduce3_k"],
+    "mrg_dense_filter_dz3": ["dense_dz_k@max"],
+    "mrg_linear_relu_segmax_fwd": ["rowgemm_x3_k<7, 2, 4", "segmax_finalize_k"],
 }
 NORTH_STAR = "span_gcs_k<4, 64, 1, 0,"            # MODE = SUB only runs in bench.py's north-star passes (last parameter: prefetch-depth override)
 
@@ -84,8 +89,15 @@ def main():
             res["device_kernels"][f"{name} [grid {grid}]"] = v
     for entry, subs in ENTRY_KERNELS.items():
         total, found = 0.0, False
-        for sub in subs:
-            keys = [k for k in kern if sub in k[0]]
+        for alts in subs:
+            keys = []
+            for sub in alts.split("|"):
+                sub, _, pick = sub.partition("@")
+                ks = [k for k in kern if sub in k[0]]
+                if ks and pick == "max":
+                    top = max(k[1] for k in ks)
+                    ks = [k for k in ks if k[1] == top]
+                keys += ks
             if not keys:
                 continue
             found = True
