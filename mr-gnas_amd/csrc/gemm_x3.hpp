@@ -11,7 +11,7 @@
 // retires 64 flop/cycle/SIMD (157 TF/s chip peak), v_mfma_f32_32x32x16_bf16 1024; six bf16 MFMAs replace
 // eight f32 MFMAs per 16 k-columns at 1/16 of the cycles each: 2.7x less matrix-pipe time for the same
 // answer.  The price is VALU work for the splits, which is why
-//   * B (a weight matrix, a few hundred KB) is split ONCE per call by bsplit_k into fragment order
+//   * B (a weight matrix, a few hundred KB) is split ONCE per call by bsplit3_k into fragment order
 //     ([k-slab][column tile][plane][lane][8 bf16], one ds_read_b128 per fragment, conflict free), and
 //   * A (activations, read once from HBM as f32 by LDS-DMA) is split in registers right after its
 //     fragment read: 44 VALU instructions per 16 k-columns per wave against 6*NT MFMAs.
@@ -82,33 +82,7 @@ inline size_t x3_bsplit_bytes(int N, int K, int nt) { return (size_t)x3_slabs(K)
 // B(n, k) = B[n * sn + k * sk]  ->  Bp[slab][tile][plane][lane] (16 B = 8 bf16: n = tile*32 + lane%32,
 // k = slab*16 + (lane/32)*8 + j).  Rows >= N and columns >= K are zero, which is also what makes the
 // clamped out-of-range A chunks harmless.  sk != 1 presents W^T without a transpose pass.
-static __global__ void bsplit_k(const float* __restrict__ B, int64_t sn, int64_t sk, int N, int K, int ntile, int nslab,
-                                u32x4* __restrict__ Bp) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nslab * ntile * 64) return;
-  const int lane = idx & 63, tile = (idx >> 6) % ntile, slab = (idx >> 6) / ntile;
-  const int n = tile * 32 + (lane & 31), k0 = slab * 16 + (lane >> 5) * 8;
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? B[n * sn + (k0 + j) * sk] : 0.f;
-  u32x4 h, m, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned a, b, c;
-    split_pair(v[2 * j], v[2 * j + 1], a, b, c);
-    h[j] = a; m[j] = b; l[j] = c;
-  }
-  u32x4* o = Bp + ((int64_t)(slab * ntile + tile) * 3) * 64 + lane;
-  o[0] = h; o[64] = m; o[128] = l;
-}
-
-inline void launch_bsplit(const float* B, int64_t sn, int64_t sk, int N, int K, int nt, void* Bp, hipStream_t st) {
-  const int ntile = x3_tiles(N, nt), nslab = x3_slabs(K);
-  const int total = nslab * ntile * 64;
-  hipLaunchKernelGGL(bsplit_k, dim3((total + 255) / 256), dim3(256), 0, st, B, sn, sk, N, K, ntile, nslab, (u32x4*)Bp);
-}
-
-// up to three weights of the same shape in one launch (blockIdx.y): the direction segments of a dense filter
+// Up to three weights of the same shape in one launch (blockIdx.y): the direction segments of a dense filter.
 struct BSplit3 { const float* B[3]; u32x4* out[3]; };
 static __global__ void bsplit3_k(BSplit3 p, int64_t sn, int64_t sk, int N, int K, int ntile, int nslab) {
   const float* __restrict__ B = p.B[blockIdx.y];
@@ -138,6 +112,14 @@ inline void launch_bsplit3(const float* const* B, int64_t sn, int64_t sk, int N,
   BSplit3 p{};
   for (int i = 0; i < 3; ++i) { p.B[i] = B[i]; p.out[i] = (u32x4*)out[i]; }
   hipLaunchKernelGGL(bsplit3_k, dim3((total + 255) / 256, 3), dim3(256), 0, st, p, sn, sk, N, K, ntile, nslab);
+}
+
+inline void launch_bsplit(const float* B, int64_t sn, int64_t sk, int N, int K, int nt, void* Bp, hipStream_t st) {
+  const int ntile = x3_tiles(N, nt), nslab = x3_slabs(K);
+  const int total = nslab * ntile * 64;
+  BSplit3 p{};
+  p.B[0] = B; p.out[0] = (u32x4*)Bp;
+  hipLaunchKernelGGL(bsplit3_k, dim3((total + 255) / 256, 1), dim3(256), 0, st, p, sn, sk, N, K, ntile, nslab);
 }
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n <= 63
@@ -209,7 +191,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   if ((MRG_X3_DBG & 256) && blockIdx.x < 256 && (blockIdx.x & 1)) {     // lab: first-round workgroups of every other CU start late
     for (int i = 0; i < MRG_X3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+  [[maybe_unused]] const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
   MRG_X3_STAMP(trace_slot, 0);
   f32x16 acc[MT][NT];
 #pragma unroll

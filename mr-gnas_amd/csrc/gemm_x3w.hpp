@@ -203,7 +203,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void rowgemm_x3w_k(GemmArgs a, const
   }
   float* ring = smem + wave * (X3_SLOTS * 64 * 4 * 4);
   const bool full = row0 + 256 <= a.rows;
-  const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+  [[maybe_unused]] const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
   if (half == 0) x3w_wave_tile<4, EPI, DUAL>(a, Bp, ntile, roww, tile0, ring, lane, full, trace_slot);
   else x3w_wave_tile<3, EPI, DUAL>(a, Bp, ntile, roww, tile0, ring, lane, full, trace_slot);
 }

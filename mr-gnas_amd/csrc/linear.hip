@@ -18,7 +18,7 @@ struct WgradArgs {
   float* ws;
   int64_t rows, rows_per_block;
   int TM, TN, TNB;
-  // grouped launch (wgrad_x3_k / wgrad_reduce_k, gridDim.z = 3): row range, plan and partial-tile workspace of range z
+  // grouped launch (wgrad_x3_k / wgrad_reduce3_k, gridDim.z = 3): row range, plan and partial-tile workspace of range z
   int ngrp;
   int64_t g_lo[3], g_hi[3], g_rpb[3], g_ws_off[3];      // g_ws_off in floats
   int g_G[3];
@@ -470,27 +470,7 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
 
 // gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
 // thread row ty sums the partial tiles g = ty, ty+16, ..., the 16 row sums are added in order.
-__global__ void wgrad_reduce_k(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gbias,
-                               int G, int K, int Nout, int ldg, int ldx) {
-  __shared__ float part[16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
-  const int n = blockIdx.y;
-  float acc = 0.f;
-  if (c <= K)
-    for (int g = ty; g < G; g += 16) acc += ws[((int64_t)g * ldg + n) * ldx + c];
-  part[ty][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && c <= K) {
-    float tot = part[0][tx];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) tot += part[i][tx];
-    if (c < K) gW[(int64_t)n * K + c] = tot;
-    else if (gbias) gbias[n] = tot;
-  }
-}
-
-// the same for up to three row ranges in one launch (blockIdx.z)
+// Up to three row ranges in one launch (blockIdx.z).
 struct WgradReduce3 { const float* ws[3]; float* gW[3]; float* gbias[3]; int G[3]; };
 __global__ void wgrad_reduce3_k(WgradReduce3 p, int K, int Nout, int ldg, int ldx) {
   __shared__ float part[16][64];
@@ -619,8 +599,9 @@ static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const flo
       hipLaunchKernelGGL((wgrad_x3_k<2>), gridx, dim3(WX_THREADS), ldsx, st, a);
     }
     MRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias, p.G, K, Nout,
-                       p.TM * 32, p.TN * 32);
+    WgradReduce3 red{};
+    red.ws[0] = (const float*)ws; red.gW[0] = gW; red.gbias[0] = gbias; red.G[0] = p.G;
+    hipLaunchKernelGGL(wgrad_reduce3_k, dim3((K + 1 + 63) / 64, Nout, 1), dim3(1024), 0, st, red, K, Nout, p.TM * 32, p.TN * 32);
     MRG_LAUNCH_CHECK();
     return MRG_OK;
   }
@@ -649,8 +630,9 @@ static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const flo
 #undef GOF
 #undef GO
   MRG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((K + 1 + 63) / 64, Nout), dim3(1024), 0, st, (const float*)ws, gW, gbias, p.G, K, Nout,
-                     p.TM * 32, p.TN * 32);
+  WgradReduce3 red1{};
+  red1.ws[0] = (const float*)ws; red1.gW[0] = gW; red1.gbias[0] = gbias; red1.G[0] = p.G;
+  hipLaunchKernelGGL(wgrad_reduce3_k, dim3((K + 1 + 63) / 64, Nout, 1), dim3(1024), 0, st, red1, K, Nout, p.TM * 32, p.TN * 32);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

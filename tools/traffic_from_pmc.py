@@ -19,7 +19,7 @@ import sys
 
 # C-ABI entry point -> substrings of the device kernels ONE call launches (each once); missing kernels are skipped
 ENTRY_KERNELS = {
-    "mrg_linear_bwd_weight": ["wgrad_x3_k", "wgrad_reduce_k"],
+    "mrg_linear_bwd_weight": ["wgrad_x3_k", "wgrad_reduce3_k"],
     "mrg_linear_bwd_input": ["rowgemm_x3_k<7, 2, 0"],
     "mrg_dense_filter_fwd": ["rowgemm_x3_k<7, 2, 1"],
     "mrg_sum_buffers": ["sum_k"],
