@@ -255,11 +255,24 @@ def north_star_kernel(g, dim, reps=50, tag="fb15k237"):
     if tag != "c5_synthetic10m":
         # calibration point of the PMC traffic passes (tools/traffic_from_pmc.py): one streaming launch of known size,
         # 12 * D * (E + N) bytes (the step itself no longer launches mrg_compose_fwd since the gather was folded into it)
+        # It doubles as the box's ACHIEVABLE streaming rate (quote it next to the 8 TB/s peak): two reads + one write.
         a_ = torch.empty(E + N, dim, device=dev)
-        K.compose("sub", a_, a_.clone())
-        del a_
+        b_ = a_.clone()
+        K.compose("sub", a_, b_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            K.compose("sub", a_, b_)
+        e1.record()
+        torch.cuda.synchronize()
+        stream_gbs = 5 * 12.0 * dim * (E + N) / (e0.elapsed_time(e1) / 1e3) / 1e9
+        del a_, b_
+    else:
+        stream_gbs = None
     del cp, ent, rel
     return {"kernel": "mrg_span_gcs (CompGCN aggregation, compose=sub)", "graph": tag, "bound": "hbm", "edges": E, "segments": 2 * N,
+            "streaming_kernel_GBs": None if stream_gbs is None else round(stream_gbs, 1),
             "dim": dim, "node_table_MB": round(4 * dim * N / 1e6, 1),
             "bytes_alg": int(nbytes), "bytes_compulsory": int(compulsory), "traffic": traffic,
             "us_per_launch": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1),
