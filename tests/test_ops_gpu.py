@@ -234,7 +234,7 @@ def test_distmult_score_and_gradients(N, R, T, D):
     got = K.distmult_score(ed, rd, sp)
     (got * w.cuda()).sum().backward()
     assert got.shape == (T,)
-    scale = max(1.0, float(ref.abs().max()) if T else 1.0)
+    scale = max(1.0, float(ref.detach().abs().max()) if T else 1.0)
     np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().float().numpy(), atol=1e-4 * scale, rtol=1e-4)
     for a, b in ((ed.grad, e64.grad), (rd.grad, r64.grad)):
         s = max(1.0, float(b.abs().max()))
