@@ -232,6 +232,12 @@ int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, dou
 int mrg_mix_finalize_fwd(const double *sums, const float *const *gamma_host, const float *const *beta_host,
                          float *const *rmean_host, float *const *rvar_host, int K, double total_rows, int D,
                          float eps, float momentum, float *coef, void *stream);
+/* mrg_mix_colstats + mrg_mix_finalize_fwd in two launches instead of three (the ordered reduction of the per-block
+ * statistics and the finalize step are one kernel): for callers without a collective between the two -- the single-GPU
+ * step.  Bit-identical coefficients and running statistics.  ws: mrg_mix_workspace_bytes(K, D). */
+int mrg_mix_stats_coef(const float *const *y, const float *const *gamma, const float *const *beta,
+                       float *const *running_mean, float *const *running_var, int K, int64_t rows, double total_rows,
+                       int D, float eps, float momentum, float *coef, void *ws, void *stream);
 int mrg_mix_fwd(const float *const *y_host, int K, const float *coef, const float *w, float *out,
                 int64_t rows, int D, void *stream);
 int mrg_mix_bwd_reduce(const float *g, const float *const *y_host, int K, const float *coef, const float *w,

@@ -112,6 +112,21 @@ inline RowGeom row_geom(int D, bool all_aligned) {
 // Deterministic second stage of the two-stage reductions: out[t] = sum_b ws[(b0 + b) * ld + t],
 // b < nb.  A 64 x 16 thread block owns 64 consecutive t; thread row ty sums the partials
 // b = ty, ty + 16, ... (coalesced along t; four interleaved accumulators), then the 16 row sums are added in order.
+// thread row ty's share of column t: partial rows b = ty, ty + 16, ... of ws[(b0 + b) * ld + t], four loads in flight
+// (the pass is latency-bound: a thread walks up to 64 partial rows); fixed association
+template <typename T>
+__device__ __forceinline__ T ordered_partial(const T* __restrict__ ws, int b0, int nb, int ld, int t, int ty) {
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int b = ty;
+  for (; b + 48 < nb; b += 64) {
+    const T v0 = ws[(int64_t)(b0 + b) * ld + t], v1 = ws[(int64_t)(b0 + b + 16) * ld + t];
+    const T v2 = ws[(int64_t)(b0 + b + 32) * ld + t], v3 = ws[(int64_t)(b0 + b + 48) * ld + t];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; b < nb; b += 16) a0 += ws[(int64_t)(b0 + b) * ld + t];
+  return (a0 + a1) + (a2 + a3);
+}
+
 // blockIdx.y selects one of up to four row ranges [bs.x[y], bs.x[y + 1]) of ws, reduced into out + y * out_stride
 struct ReduceRanges { int x[5]; };
 template <typename T>
@@ -121,19 +136,7 @@ __global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, 
   const int t = blockIdx.x * 64 + tx;
   const int b0 = bs.x[blockIdx.y], nb = bs.x[blockIdx.y + 1] - b0;
   out += (int64_t)blockIdx.y * out_stride;
-  T acc = 0;
-  if (t < len) {
-    // four loads in flight per thread (the pass is latency-bound: a thread walks up to 64 partial rows); fixed association
-    T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int b = ty;
-    for (; b + 48 < nb; b += 64) {
-      const T v0 = ws[(int64_t)(b0 + b) * ld + t], v1 = ws[(int64_t)(b0 + b + 16) * ld + t];
-      const T v2 = ws[(int64_t)(b0 + b + 32) * ld + t], v3 = ws[(int64_t)(b0 + b + 48) * ld + t];
-      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-    }
-    for (; b < nb; b += 16) a0 += ws[(int64_t)(b0 + b) * ld + t];
-    acc = (a0 + a1) + (a2 + a3);
-  }
+  const T acc = t < len ? ordered_partial<T>(ws, b0, nb, ld, t, ty) : T(0);
   part[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && t < len) {

@@ -118,6 +118,44 @@ __global__ void mix_finalize_fwd_k(const double* __restrict__ sums, PtrPack gamm
   }
 }
 
+// The ordered reduction of the per-block statistics and the finalize step in ONE launch (single-GPU path: no all-reduce sits
+// between them): a 64 x 16 block owns 64 columns of one candidate, reduces their sum and sum of squares over the nb partial
+// rows exactly like ordered_reduce_k and turns them into the coefficients.  Bit-identical to the two-launch form.
+__global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb, PtrPack gamma, PtrPack beta, MutPack rmean, MutPack rvar,
+                                          int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef) {
+  __shared__ double part[2][16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx, k = blockIdx.y;
+  const int ld = K * 2 * D;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) part[j][ty][tx] = c < D ? ordered_partial<double>(ws, 0, nb, ld, (k * 2 + j) * D + c, ty) : 0.0;
+  __syncthreads();
+  if (ty != 0 || c >= D) return;
+  double tot[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    double t = part[j][0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t += part[j][i][tx];
+    tot[j] = t;
+  }
+  double mean = tot[0] / total_rows;
+  double var = tot[1] / total_rows - mean * mean;
+  if (var < 0) var = 0;
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  float g = gamma.p[k] ? gamma.p[k][c] : 1.f, b = beta.p[k] ? beta.p[k][c] : 0.f;
+  float* o = coef + (int64_t)k * 4 * D;
+  o[c] = (float)(g * invstd);
+  o[D + c] = (float)(b - mean * g * invstd);
+  o[2 * D + c] = (float)invstd;
+  o[3 * D + c] = (float)(mean * invstd);
+  if (rmean.p[k]) {
+    double unbiased = total_rows > 1 ? var * (total_rows / (total_rows - 1.0)) : var;
+    rmean.p[k][c] = (1.f - momentum) * rmean.p[k][c] + momentum * (float)mean;
+    rvar.p[k][c] = (1.f - momentum) * rvar.p[k][c] + momentum * (float)unbiased;
+  }
+}
+
 // ---- forward combine
 template <int VEC, int LPR, int KMAX>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
@@ -341,12 +379,50 @@ extern "C" int64_t mrg_mix_workspace_bytes(int K, int D) {
 }
 
 // sums [K][2][D] float64
+static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out);
+
+// mrg_mix_colstats + mrg_mix_finalize_fwd in two launches instead of three (statistics kernel, then reduction and finalize fused):
+// for callers without a collective between the two (the single-GPU step).  Same results bit for bit.
+extern "C" int mrg_mix_stats_coef(const float* const* y_host, const float* const* gamma_host, const float* const* beta_host,
+                                  float* const* rmean_host, float* const* rvar_host, int K, int64_t rows, double total_rows, int D, float eps,
+                                  float momentum, float* coef, void* ws, void* stream) {
+  if (K < 1 || K > MRG_MIX_MAXK || D <= 0 || total_rows < 0) return MRG_E_SHAPE;
+  if (!coef || !gamma_host || !beta_host) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 1;
+  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid);
+  if (rc != MRG_OK) return rc;
+  PtrPack ga{}, be{};
+  MutPack rm{}, rv{};
+  for (int k = 0; k < K; ++k) {
+    ga.p[k] = gamma_host[k]; be.p[k] = beta_host[k];
+    rm.p[k] = rmean_host ? rmean_host[k] : nullptr;
+    rv.p[k] = rvar_host ? rvar_host[k] : nullptr;
+    if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
+  }
+  hipLaunchKernelGGL(mix_reduce_finalize_fwd_k, dim3((D + 63) / 64, K), dim3(1024), 0, st, (const double*)ws, grid, ga, be, rm, rv, K,
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
 extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows, int D, double* sums, void* ws, void* stream) {
+  if (!sums) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 1;
+  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid);
+  if (rc != MRG_OK) return rc;
+  int len = K * 2 * D;
+  launch_ordered_reduce<double>((const double*)ws, sums, 0, grid, len, len, st);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// the statistics kernel: per-block partial sums [grid][K][2][D] in ws
+static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out) {
   if (!pack_ok((const void* const*)y_host, K)) return MRG_E_SHAPE;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
-  if (!sums) return MRG_E_NULLPTR;
   if (!ws) return MRG_E_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   PtrPack ys{};
   bool al = true;
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
@@ -361,9 +437,7 @@ extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows,
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();
-  int len = K * 2 * D;
-  launch_ordered_reduce<double>((const double*)ws, sums, 0, grid, len, len, st);
-  MRG_LAUNCH_CHECK();
+  *grid_out = grid;
   return MRG_OK;
 }
 

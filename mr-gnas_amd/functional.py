@@ -845,16 +845,19 @@ class _MixedEpilogue(torch.autograd.Function):
         training = bn0.training or not bn0.track_running_stats
         if training:
             ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), ref)
-            sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
-            call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), st), nbytes=4 * D * rows * nz)
-            if cfg.group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=cfg.group)
             track = bn0.track_running_stats
             rm = ptr_array([b.running_mean if track else None for b in cfg.bns])
             rv = ptr_array([b.running_var if track else None for b in cfg.bns])
             mom = bn0.momentum if bn0.momentum is not None else 0.1
-            call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
+            if cfg.group is None:                          # no collective between statistics and coefficients: two launches, not three
+                call("mrg_mix_stats_coef", (ypa, ptr_array(gam), ptr_array(bet), rm, rv, K_, rows, total, D, bn0.eps, mom, ptr(coef), ptr(ws), st),
+                     nbytes=4 * D * rows * nz)
+            else:
+                import torch.distributed as dist
+                sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
+                call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), st), nbytes=4 * D * rows * nz)
+                dist.all_reduce(sums, group=cfg.group)
+                call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:                                      # one multi-tensor launch instead of one per BatchNorm
                 torch._foreach_add_([b.num_batches_tracked for b in cfg.bns], 1)
         else:   # eval: fixed statistics

@@ -455,3 +455,33 @@ def test_grouped_direction_segments_are_bit_exact(kind, tied, N, E, R, D):
         K.GROUPED_SEGMENTS = True
     for x, y in zip(res[True], res[False]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("rows,D,K_", [(70001, 200, 4), (513, 64, 3), (5, 36, 2)])
+def test_fused_statistics_to_coefficients_is_bit_exact(rows, D, K_):
+    """mrg_mix_stats_coef (statistics kernel, then reduction + finalize in one launch) against mrg_mix_colstats +
+    mrg_mix_finalize_fwd: coefficients and running statistics bit-identical."""
+    from mr_gnas_amd._lib import call, ptr, ptr_array, stream_of
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + D)
+    ys = [torch.randn(rows, D, generator=gen).to(DEV) * (k + 1) for k in range(K_)]
+    ys[1] = None                                                      # an all-zero branch (f_zero)
+    gam = [torch.rand(D, generator=gen).to(DEV) for _ in range(K_)]
+    bet = [torch.randn(D, generator=gen).to(DEV) for _ in range(K_)]
+    out = {}
+    for fused in (True, False):
+        rm = [torch.zeros(D, device=DEV) for _ in range(K_)]
+        rv = [torch.ones(D, device=DEV) for _ in range(K_)]
+        coef = torch.full((K_, 4, D), 7.0, device=DEV)
+        ws = torch.empty(int(lib.mrg_mix_workspace_bytes(K_, D)), dtype=torch.uint8, device=DEV)
+        st = stream_of(coef)
+        if fused:
+            call("mrg_mix_stats_coef", (ptr_array(ys), ptr_array(gam), ptr_array(bet), ptr_array(rm), ptr_array(rv), K_, rows, float(rows), D, 1e-5, 0.1,
+                                        ptr(coef), ptr(ws), st))
+        else:
+            sums = torch.empty(K_, 2, D, dtype=torch.float64, device=DEV)
+            call("mrg_mix_colstats", (ptr_array(ys), K_, rows, D, ptr(sums), ptr(ws), st))
+            call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), ptr_array(rm), ptr_array(rv), K_, float(rows), D, 1e-5, 0.1, ptr(coef), st))
+        out[fused] = [coef] + rm + rv
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)

@@ -27,6 +27,7 @@ ENTRY_KERNELS = {
     "mrg_mix_bwd_apply": ["mix_bwd_apply_k"],
     "mrg_mix_fwd": ["mix_fwd_k"],
     "mrg_mix_colstats": ["mix_colstats_k"],
+    "mrg_mix_stats_coef": ["mix_colstats_k", "mix_reduce_finalize_fwd_k"],
     "mrg_mix_bwd_reduce": ["mix_bwd_reduce_k"],
     "mrg_gate_fwd": ["gate_fwd_k"],
     "mrg_gate_bwd": ["gate_bwd_k"],
