@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 5   /* 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 6   /* 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -283,6 +283,25 @@ int64_t mrg_linear_relu_segmax_workspace_bytes(int64_t N, int K, int Nout);
 int mrg_linear_relu_segmax_fwd(const float *X, const float *W, const float *bias, const int32_t *eid, const int32_t *dst,
                                const float *self_rows, float *out, int32_t *arg, float *mx, void *ws,
                                int64_t E, int64_t N, int K, int Nout, void *stream);
+/* a_mean_op.forward (reference models/operations_lp.py:245-250; SURVEY section 2b K_lin_relu_segmean) without the [E, Nout]
+ * message tensor, in two launches:
+ *   1. mrg_linear_relu_segsum_fwd: the split-core GEMM over the edges in destination order; its epilogue adds
+ *      ReLU(X[e] W^T + bias) over the runs of equal destination inside each lane's 16 rows of a 32-row strip (a fixed
+ *      order) and stores a run's sum at the position of its first row: part [E, Nout], only those "head" rows are written.
+ *      relu_bits [E, ceil(Nout / 32)] keeps y > 0 per element of ORIGINAL edge row e (bit = column % 32) for the backward.
+ *   2. mrg_seg_reduce_heads_fwd: out[v] = (sum of v's head rows, ascending) / max(deg, 1) + self_rows[v] (MRG_REDUCE_MEAN;
+ *      MRG_REDUCE_SUM without the division) over the chunk plan; rowptr [N + 1] = list starts.  Which rows are heads
+ *      follows from the list positions alone.  Deterministic: no float atomics.
+ * Backward of the reducer with the bit mask: mrg_seg_reduce_bwd_bits.  Shapes as mrg_linear_relu_segmax_fwd. */
+int mrg_linear_relu_segsum_fwd(const float *X, const float *W, const float *bias, const int32_t *eid, const int32_t *dst,
+                               float *part, unsigned *relu_bits, void *ws, int64_t E, int K, int Nout, void *stream);
+int mrg_seg_reduce_heads_fwd(int mode, const float *part, const float *self_rows, const int32_t *rowptr,
+                             const int32_t *chunk_node, const int32_t *chunk_start, const int32_t *chunk_end,
+                             const int32_t *chunk_slot, int64_t n_chunks, const int32_t *hub_node, const int32_t *hub_first,
+                             const int32_t *hub_count, int64_t n_hubs, int64_t n_slots, const int32_t *in_degree, float *out,
+                             void *ws, int64_t N, int D, void *stream);
+int mrg_seg_reduce_bwd_bits(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree, float *gmsg, float *gself,
+                            const unsigned *relu_bits, int64_t E, int64_t N, int D, void *stream);
 /* gX[rows, K] (+)= gY[rows, Nout] W[:, 0:K]   (gY already masked by the activation).  W is
  * [Nout][ldw] row-major, ldw >= K (a column block of a wider weight, e.g. one half of an
  * nn.Linear(2D, D)); accumulate != 0 adds into gX.  ws (mandatory) holds the split / transposed block. */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -71,6 +71,9 @@ SIGNATURES = {
     "mrg_linear_bwd_input3": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P]),
     "mrg_linear_bwd_weight3_workspace_bytes": (_L, [_L, _L, _L, _I, _I, _I]),
     "mrg_linear_bwd_weight3": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _P]),
+    "mrg_linear_relu_segsum_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "mrg_seg_reduce_heads_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_seg_reduce_bwd_bits": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_linear_relu_segmax_workspace_bytes": (_L, [_L, _I, _I]),
     "mrg_linear_relu_segmax_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
     "mrg_linear_bwd_input_workspace_bytes": (_L, [_I, _I]),

@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM_MAX = 256;      // rows per workgroup = 128 * MT (MT row tiles of 32 per wave)
 
-enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3, EPI_SEGMAX = 4 };
+enum { EPI_BIAS_ACT = 0, EPI_GATE = 1, EPI_SCALE = 2, EPI_ACCUM = 3, EPI_SEGMAX = 4, EPI_SEGSUM = 5 };
 
 // Up to three row ranges of ONE launch of the split-core row GEMM that share every tensor but differ in the weight matrix
 // (the in / out / self direction segments of a dense filter: one launch instead of three).  Workgroup blocks
@@ -60,6 +60,9 @@ struct GemmArgs {
   // EPI_SEGMAX (no C): seg_out[row_seg[row_index[r]] * N + col] = max over rows r of pack(ReLU(acc + bias), r), see gemm_epilogue_segmax
   const int32_t* row_seg;
   unsigned long long* seg_out;
+  // EPI_SEGSUM (no C): run sums of ReLU(acc + bias) at seg_part[head position * N + col], ReLU bit mask at relu_bits, see gemm_epilogue_segsum
+  float* seg_part;
+  unsigned* relu_bits; int bits_ld;
   GemmGroups grp;                     // split core, one-wave kernel only
 };
 
@@ -70,6 +73,53 @@ struct GemmArgs {
 // high word, 0xFFFFFFFF - sorted row position in the low word.  max() is exact, so the result does not depend on the
 // order of the atomics; among equal values the smallest position (= lowest edge id: the list of a destination is in edge
 // order) wins, like DGL's first-index argmax; key 0 = "no in-edge".  The [E, D] ReLU output is never written.
+// ---- a_mean / a_sum over ReLU(Linear): the ordered first level of a destination-segmented SUM as the GEMM's epilogue ---------
+// Same walk as gemm_epilogue_segmax (edges in destination order).  A lane adds the ReLU outputs of each run of equal
+// destination among ITS 16 rows of a strip (ascending rows: a fixed order) and stores the run's sum at the position of the
+// run's first row ("head"): seg_part[head * N + col].  Only head rows are ever written or read; which rows are heads follows
+// from the destination list alone (mrg_seg_reduce_heads_fwd re-derives it), so the second level adds a destination's run
+// sums in ascending head order -- deterministic, no float atomics.  relu_bits[e * bits_ld + tile] keeps y > 0 per column
+// (bit = column within the tile) of ORIGINAL edge row e for the backward: the [E, D] message tensor is never written.
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue_segsum(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh) {
+  if (rowbase >= a.rows) return;
+  int seg[16], eidv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const bool ok = row < a.rows;
+    const int64_t rc = ok ? row : a.rows - 1;
+    const int e = a.row_index ? a.row_index[rc] : (int)rc;
+    eidv[r] = ok ? e : -1;
+    seg[r] = ok ? a.row_seg[e] : -1;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 32 + li;
+    const bool cok = col < a.N;
+    const float bv = (a.bias && cok) ? a.bias[col] : 0.f;
+    int cur = -1;
+    int64_t head = 0;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = acc[n][r] + bv;
+      const bool pos = x > 0.f;
+      const unsigned long long ball = __ballot(pos);          // lanes 0-31: this register's row of half 0, lanes 32-63: of half 1
+      if (li == 0 && eidv[r] >= 0 && a.relu_bits)
+        a.relu_bits[(int64_t)eidv[r] * a.bits_ld + (col0 >> 5) + n] = lh ? (unsigned)(ball >> 32) : (unsigned)ball;
+      if (seg[r] != cur) {                                   // uniform over the 32 lanes of a half wave
+        if (cur >= 0 && cok) a.seg_part[head * a.N + col] = sum;
+        cur = seg[r];
+        head = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sum = 0.f;
+      }
+      sum += pos ? x : 0.f;
+    }
+    if (cur >= 0 && cok) a.seg_part[head * a.N + col] = sum;
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void gemm_epilogue_segmax(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh) {
   if (rowbase >= a.rows) return;

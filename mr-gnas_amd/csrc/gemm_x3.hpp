@@ -357,6 +357,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc[m], roww + m * 32, col0, li, lh);
+    else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc[m], roww + m * 32, col0, li, lh);
     else gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, row0 + GBM <= a.rows);
   }
   if (MRG_X3_DBG & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MRG_X3_STAMP(trace_slot, 3); }

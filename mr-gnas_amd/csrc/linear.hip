@@ -694,6 +694,26 @@ extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const 
   return MRG_OK;
 }
 
+// ---- a_mean (a_sum over ReLU(Linear)) first level: the split-core GEMM over the edges in destination order with the
+// run-sum epilogue (gemm_epilogue_segsum); second level: mrg_seg_reduce_heads_fwd.  part: [E, Nout] floats (only head rows
+// are written), relu_bits: [E, ceil(Nout / 32)] words.  ws: mrg_gemm_workspace_bytes(K, Nout).
+extern "C" int mrg_linear_relu_segsum_fwd(const float* X, const float* W, const float* bias, const int32_t* eid, const int32_t* dst,
+                                          float* part, unsigned* relu_bits, void* ws, int64_t E, int K, int Nout, void* stream) {
+  if (E < 0 || K <= 0 || Nout <= 0 || E >= ((int64_t)1 << 31)) return MRG_E_SHAPE;
+  if (!segmax_shape_ok(K, Nout)) return MRG_E_SHAPE;
+  if (E == 0) return MRG_OK;
+  if (!X || !W || !eid || !dst || !part) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  if (!aligned16(X) || !aligned16(ws)) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
+  a.row_index = eid; a.row_seg = dst; a.seg_part = part; a.relu_bits = relu_bits; a.bits_ld = (Nout + 31) / 32;
+  if (!x3_eligible(a)) return MRG_E_SHAPE;
+  launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), ws, st);
+  return launch_rowgemm_x3<EPI_SEGSUM>(a, ws, st);
+}
+
 extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
   if (K <= 0 || Nout <= 0) return 0;
   return (int64_t)gemm_workspace_bytes(K, Nout);

@@ -10,14 +10,25 @@
 
 namespace mrg {
 
-template <int VEC, int LPR, int KMAX, bool IS_MAX>
+// HEADS (sum / mean only): msg is indexed by LIST POSITION and only the "head" rows hold data -- the run sums that the
+// GEMM epilogue gemm_epilogue_segsum left at the first row of every run of one destination inside one half (rows 4h..4h+3
+// of every group of 8) of a 32-row strip.  Position j of node v's list is a head iff the previous row of its half of the
+// strip lies outside the strip or before the list (head_rowptr[v]): re-derived here, nothing is stored for it.
+__device__ __forceinline__ bool seg_is_head(int j, int list_start) {
+  const int q = j & 31;
+  const int prev = (q & 3) ? j - 1 : (q >= 8 ? j - 5 : -1);
+  return prev < list_start;                                // also true for prev == -1 (first group of the half in its strip)
+}
+
+template <int VEC, int LPR, int KMAX, bool IS_MAX, bool HEADS = false>
 __global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict__ msg, const float* __restrict__ self_rows,
                                                          const int32_t* __restrict__ eid, const int32_t* __restrict__ chunk_node,
                                                          const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ chunk_end,
                                                          const int32_t* __restrict__ chunk_slot, int64_t n_chunks,
                                                          const int32_t* __restrict__ in_degree, float* __restrict__ out,
                                                          int32_t* __restrict__ arg, float* __restrict__ ws_val,
-                                                         int32_t* __restrict__ ws_arg, int D, int is_mean) {
+                                                         int32_t* __restrict__ ws_arg, int D, int is_mean,
+                                                         const int32_t* __restrict__ head_rowptr = nullptr) {
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int U = 4;                                      // rows in flight per lane group
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
@@ -29,11 +40,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict
     const int slot = chunk_slot[ch];
     Acc<VEC, LPR, KMAX, IS_MAX> acc;
     acc.init();
+    const int list_start = HEADS ? head_rowptr[v] : 0;
     for (int j = j0; j < j1; j += U) {
       int e[U];
       Vec<VEC> x[U][KMAX];
 #pragma unroll
-      for (int q = 0; q < U; ++q) e[q] = (j + q < j1) ? eid[j + q] : -1;
+      for (int q = 0; q < U; ++q) {
+        if (HEADS) e[q] = (j + q < j1 && seg_is_head(j + q, list_start)) ? j + q : -1;
+        else e[q] = (j + q < j1) ? eid[j + q] : -1;
+      }
 #pragma unroll
       for (int q = 0; q < U; ++q) {
 #pragma unroll
@@ -72,7 +87,8 @@ template <int VEC, int LPR, int KMAX, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__ gout, const int32_t* __restrict__ dst,
                                                        const int32_t* __restrict__ in_degree, const int32_t* __restrict__ arg,
                                                        float* __restrict__ gmsg, float* __restrict__ gself,
-                                                       const float* __restrict__ relu_src, int64_t E, int64_t rows, int D) {
+                                                       const float* __restrict__ relu_src, int64_t E, int64_t rows, int D,
+                                                       const unsigned* __restrict__ relu_bits = nullptr) {
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
@@ -100,6 +116,13 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__
             Vec<VEC> y = Vec<VEC>::load(relu_src + r * D + c * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) g[j] = y[j] > 0.f ? g[j] : 0.f;
+          } else if (relu_bits) {    // ... kept as one bit per element by the fused forward (word = 32 columns of row r)
+            const int bld = (D + 31) >> 5;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              const int col = c * VEC + j;
+              g[j] = ((relu_bits[r * bld + (col >> 5)] >> (col & 31)) & 1u) ? g[j] : 0.f;
+            }
           }
         }
         g.store(o + c * VEC);
@@ -117,12 +140,43 @@ extern "C" int64_t mrg_seg_reduce_workspace_bytes(int64_t n_slots, int D) {
   return (n_slots + 1) * (int64_t)D * 8 + 64;   // float values + int32 arg per partial slot
 }
 
+static int seg_reduce_fwd_impl(int mode, const float* msg, const float* self_rows, const int32_t* eid,
+                               const int32_t* chunk_node, const int32_t* chunk_start, const int32_t* chunk_end,
+                               const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
+                               const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
+                               const int32_t* in_degree, float* out, int32_t* arg, void* ws, int64_t N, int D,
+                               void* stream, const int32_t* head_rowptr);
+
 extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_rows, const int32_t* eid,
                                   const int32_t* chunk_node, const int32_t* chunk_start, const int32_t* chunk_end,
                                   const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
                                   const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
                                   const int32_t* in_degree, float* out, int32_t* arg, void* ws, int64_t N, int D,
                                   void* stream) {
+  return seg_reduce_fwd_impl(mode, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, hub_node, hub_first,
+                             hub_count, n_hubs, n_slots, in_degree, out, arg, ws, N, D, stream, nullptr);
+}
+
+// Second level of the fused a_mean / a_sum (first level: mrg_linear_relu_segsum_fwd): part is indexed by list position
+// (row j of the by-destination edge list) and holds run sums at the head rows only; rowptr [N + 1] is the list start of
+// every node.  mode: MRG_REDUCE_SUM or MRG_REDUCE_MEAN.
+extern "C" int mrg_seg_reduce_heads_fwd(int mode, const float* part, const float* self_rows, const int32_t* rowptr,
+                                        const int32_t* chunk_node, const int32_t* chunk_start, const int32_t* chunk_end,
+                                        const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
+                                        const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
+                                        const int32_t* in_degree, float* out, void* ws, int64_t N, int D, void* stream) {
+  if (mode != MRG_REDUCE_SUM && mode != MRG_REDUCE_MEAN) return MRG_E_ENUM;
+  if (!rowptr) return MRG_E_NULLPTR;
+  return seg_reduce_fwd_impl(mode, part, self_rows, nullptr, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, hub_node, hub_first,
+                             hub_count, n_hubs, n_slots, in_degree, out, nullptr, ws, N, D, stream, rowptr);
+}
+
+static int seg_reduce_fwd_impl(int mode, const float* msg, const float* self_rows, const int32_t* eid,
+                               const int32_t* chunk_node, const int32_t* chunk_start, const int32_t* chunk_end,
+                               const int32_t* chunk_slot, int64_t n_chunks, const int32_t* hub_node,
+                               const int32_t* hub_first, const int32_t* hub_count, int64_t n_hubs, int64_t n_slots,
+                               const int32_t* in_degree, float* out, int32_t* arg, void* ws, int64_t N, int D,
+                               void* stream, const int32_t* head_rowptr) {
   if (mode < 0 || mode > 2) return MRG_E_ENUM;
   if (N < 0 || D <= 0 || n_chunks < N || n_hubs < 0 || n_slots < 0) return MRG_E_SHAPE;
   if (N == 0) return MRG_OK;
@@ -142,6 +196,8 @@ extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_
     int grid = grid_for(n_chunks, MRG_BLOCK / L);                                                                      \
     if (mode == MRG_REDUCE_MAX)                                                                                        \
       hipLaunchKernelGGL((seg_chunk_k<V, L, K, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
+    else if (head_rowptr)                                                                                              \
+      hipLaunchKernelGGL((seg_chunk_k<V, L, K, false, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean, head_rowptr); \
     else                                                                                                               \
       hipLaunchKernelGGL((seg_chunk_k<V, L, K, false>), dim3(grid), dim3(MRG_BLOCK), 0, st, msg, self_rows, eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, in_degree, out, arg, ws_val, ws_arg, D, is_mean); \
     if (n_hubs > 0) {                                                                                                  \
@@ -158,9 +214,25 @@ extern "C" int mrg_seg_reduce_fwd(int mode, const float* msg, const float* self_
   return MRG_OK;
 }
 
+static int seg_reduce_bwd_impl(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree, const int32_t* arg, float* gmsg,
+                               float* gself, const float* relu_src, const unsigned* relu_bits, int64_t E, int64_t N, int D, void* stream);
+
 extern "C" int mrg_seg_reduce_bwd(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree,
                                   const int32_t* arg, float* gmsg, float* gself, const float* relu_src, int64_t E, int64_t N,
                                   int D, void* stream) {
+  return seg_reduce_bwd_impl(mode, gout, dst, in_degree, arg, gmsg, gself, relu_src, nullptr, E, N, D, stream);
+}
+
+// the same with the ReLU mask as bits (relu_bits [E, ceil(D / 32)], written by mrg_linear_relu_segsum_fwd)
+extern "C" int mrg_seg_reduce_bwd_bits(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree, float* gmsg, float* gself,
+                                       const unsigned* relu_bits, int64_t E, int64_t N, int D, void* stream) {
+  if (mode != MRG_REDUCE_SUM && mode != MRG_REDUCE_MEAN) return MRG_E_ENUM;
+  if (E > 0 && !relu_bits) return MRG_E_NULLPTR;
+  return seg_reduce_bwd_impl(mode, gout, dst, in_degree, nullptr, gmsg, gself, nullptr, relu_bits, E, N, D, stream);
+}
+
+static int seg_reduce_bwd_impl(int mode, const float* gout, const int32_t* dst, const int32_t* in_degree, const int32_t* arg, float* gmsg,
+                               float* gself, const float* relu_src, const unsigned* relu_bits, int64_t E, int64_t N, int D, void* stream) {
   if (mode < 0 || mode > 2) return MRG_E_ENUM;
   if (E < 0 || N < 0 || D <= 0) return MRG_E_SHAPE;
   if (!gout || (E > 0 && (!dst || !gmsg))) return MRG_E_NULLPTR;
@@ -174,9 +246,9 @@ extern "C" int mrg_seg_reduce_bwd(int mode, const float* gout, const int32_t* ds
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
     int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                    \
-    if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
-    else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
-    else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D); \
+    if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
+    else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
+    else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL

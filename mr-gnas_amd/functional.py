@@ -299,6 +299,7 @@ FUSED_AMAX = os.environ.get("MRG_FUSED_AMAX", "1") == "1"      # lab switch: 0 =
 # below this many edges the step is launch-bound and the fused form's extra launches (key memset, unpack pass, mask product)
 # cost more than the [E, D] round trip they save: 30 000-edge sampled step 18.4 vs 17.7 ms
 FUSED_AMAX_MIN_ROWS = int(os.environ.get("MRG_FUSED_AMAX_MIN_ROWS", "100000"))
+FUSED_AMEAN = os.environ.get("MRG_FUSED_AMEAN", "1") == "1"    # lab switch: 0 = linear, then the span reducer over the [E, D] messages
 
 
 class _LinReluAgg(torch.autograd.Function):
@@ -332,6 +333,26 @@ class _LinReluAgg(torch.autograd.Function):
             ctx.mode, ctx.graph, ctx.fused = mode, graph, True
             ctx.save_for_backward(x, W, arg, mx)
             return out
+        if (mode == 1 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and hasattr(graph, "plan")
+                and _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) > 0):
+            # a_mean without the [E, D] messages: the GEMM's epilogue leaves ordered run sums at the head rows of `part` and one
+            # ReLU bit per element; the chunk reducer adds a node's head rows
+            p = graph.plan()
+            part = torch.empty(E, D, dtype=torch.float32, device=x.device)          # only the head rows are written / read
+            bits = torch.empty(E, (D + 31) // 32, dtype=torch.int32, device=x.device)
+            gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
+            call("mrg_linear_relu_segsum_fwd", (ptr(x), ptr(W), ptr(b), ptr(p["eid"]), ptr(graph.i32("dst")), ptr(part), ptr(bits), ptr(gws),
+                                                E, D, D, st), nbytes=4 * E * D + 8 * E + 4 * D * D, flops=2 * E * D * D)
+            out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            n_chunks, n_hubs, n_slots = _cnt(p, "chunks"), _cnt(p, "hubs"), _cnt(p, "slots")
+            ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), x) if n_slots > 0 else None
+            call("mrg_seg_reduce_heads_fwd", (1, ptr(part), ptr(x[E:]), ptr(p["rowptr"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
+                                              ptr(p["chunk_end"]), ptr(p["chunk_slot"]), n_chunks, ptr(p["hub_node"]), ptr(p["hub_first"]),
+                                              ptr(p["hub_count"]), n_hubs, n_slots, ptr(p["in_degree"]), ptr(out), ptr(ws), N, D, st),
+                 nbytes=8 * N * D + 4 * E)
+            ctx.mode, ctx.graph, ctx.fused = mode, graph, "mean"
+            ctx.save_for_backward(x, W, bits)
+            return out
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
         gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
         call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
@@ -350,7 +371,9 @@ class _LinReluAgg(torch.autograd.Function):
     def backward(ctx, g):
         graph, mode = ctx.graph, ctx.mode
         g = f32c(g)
-        if ctx.fused:
+        if ctx.fused == "mean":
+            x, W, bits = ctx.saved_tensors
+        elif ctx.fused:
             x, W, arg, mx = ctx.saved_tensors
         else:
             x, W, y, *rest = ctx.saved_tensors
@@ -359,7 +382,10 @@ class _LinReluAgg(torch.autograd.Function):
         st = stream_of(x)
         gx = torch.empty_like(x)
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
-        if ctx.fused:
+        if ctx.fused == "mean":
+            call("mrg_seg_reduce_bwd_bits", (1, ptr(g), ptr(graph.i32("dst")), ptr(graph.plan()["in_degree"]), ptr(gy), ptr(gx[E:]), ptr(bits),
+                                             E, N, D, st), nbytes=4 * D * E + 4 * E + 8 * D * N)
+        elif ctx.fused:
             _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)             # the winning message is ReLU-dead iff the maximum is 0
             gx[E:] = g
         else:

@@ -372,6 +372,43 @@ def test_c5_fused_amax(c5):
     free()
 
 
+def test_c5_fused_amean(c5):
+    """a_mean without the [E, 256] messages at C5 (10 M gathered rows; run sums at the head rows of a 10 GB buffer of which
+    ~0.5 GB is touched; 80 MB of ReLU bits): against ReLU(linear) -> scatter mean in float64 on a column block, and the input
+    gradient of a row sample against the two-launch form."""
+    D = 256
+    g, N, E, gen = c5["g"], c5["N"], c5["E"], c5["gen"]
+    _, dst, _ = g.edges(form="all")
+    x0 = torch.randn(E + N, D, device=DEV, generator=gen)
+    W0 = torch.randn(D, D, device=DEV, generator=gen) / 16
+    b0 = torch.randn(D, device=DEV, generator=gen) * 0.1
+    gout = torch.randn(N, D, device=DEV, generator=gen)
+    rows = torch.randint(0, E, (4096,), device=DEV, generator=gen)
+    keep = {}
+    try:
+        for fused in (True, False):
+            K.FUSED_AMEAN = fused
+            x = x0.clone().requires_grad_(True)
+            out = K.linear_relu_aggregate("mean", x, W0, b0, g)
+            out.backward(gout)
+            keep[fused] = (out.detach()[:, 64:128].clone(), x.grad[rows].clone(), x.grad[E:E + 4096].clone())
+            del x, out
+            free()
+    finally:
+        K.FUSED_AMEAN = True
+    for a, b, what in zip(keep[True], keep[False], ("out", "gx sample", "gx self rows")):
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * max(1.0, float(b.abs().max())), f"C5 fused a_mean {what}: {err:.3e}"
+    cols = slice(64, 128)
+    y = torch.relu(x0[:E].double() @ W0[cols].double().t() + b0[cols].double())
+    ref = torch.zeros(N, 64, dtype=torch.float64, device=DEV).scatter_reduce(0, dst.view(-1, 1).expand(E, 64), y, "mean", include_self=False)
+    ref = ref + x0[E:, cols].double()
+    err = float((keep[True][0].double() - ref).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), f"C5 fused a_mean vs float64: {err:.3e}"
+    del keep, y, ref, x0
+    free()
+
+
 def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
     """The MixedOp epilogue, the K-way gradient sum and a dense filter at M = 11 M rows, D = 256 against float64 on
     a row sample (first / last rows and random ones)."""

@@ -485,3 +485,45 @@ def test_fused_statistics_to_coefficients_is_bit_exact(rows, D, K_):
         out[fused] = [coef] + rm + rv
     for a, b in zip(out[True], out[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,E,R,D,hub", [(3000, 70000, 11, 200, False), (500, 90000, 7, 64, True), (4000, 20000, 5, 128, False), (64, 300, 3, 52, True),
+                                         (40, 33, 2, 100, False)])
+def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
+    """a_mean as GEMM with the run-sum epilogue + heads reducer + bit-mask backward (no [E, D] messages) against linear ->
+    ReLU -> span reducer: outputs and gradients within float summation-order tolerance (the association differs), the ReLU
+    bit mask exact (checked through the input gradient of rows whose message is dead), bitwise reproducible; a hub that spans
+    many strips, nodes without in-edges, a list shorter than a strip half."""
+    gen = torch.Generator().manual_seed(N + E + 1)
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N - 10, (E,), generator=gen)
+    if hub:
+        dst[: E // 2] = 3
+    et = torch.randint(0, R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32), device=DEV)
+    x0 = torch.randn(E + N, D, generator=gen)
+    W0 = torch.randn(D, D, generator=gen) / D ** 0.5
+    b0 = torch.randn(D, generator=gen) * 0.1
+    gout = torch.randn(N, D, generator=gen).to(DEV)
+    res = {}
+    min_rows = K.FUSED_AMAX_MIN_ROWS
+    try:
+        K.FUSED_AMAX_MIN_ROWS = 0
+        for fused in (True, True, False):
+            K.FUSED_AMEAN = fused
+            x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
+            out = K.linear_relu_aggregate("mean", x, W, b, g)
+            out.backward(gout)
+            cur = (out.detach(), x.grad, W.grad, b.grad)
+            if fused and True in res:
+                assert all(torch.equal(p, q) for p, q in zip(cur, res[True])), "fused a_mean is not reproducible"
+            res[fused] = cur
+    finally:
+        K.FUSED_AMEAN, K.FUSED_AMAX_MIN_ROWS = True, min_rows
+    for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
+        close(a, b_.cpu(), "fused a_mean " + what, rtol=2e-5, atol=1e-6)
+    # exact mask: rows whose message is dead in every column get a zero input gradient in both forms, and vice versa
+    dead_f, dead_u = (res[True][1][:E] == 0), (res[False][1][:E] == 0)
+    assert torch.equal(dead_f.all(1), dead_u.all(1))
+    ref = OO.a_mean(OGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32)), {"linear.weight": W0, "linear.bias": b0}, x0, None)
+    close(res[True][0], ref, "fused a_mean vs oracle")
