@@ -308,8 +308,9 @@ class _LinReluAgg(torch.autograd.Function):
         m = ReLU(Linear(x[:E]));  h = reduce_{e -> v} m[e];  out = h + x[E:]
     The backward writes the gradient of x once (rows [0,E) from the input-gradient GEMM, rows [E,M) a copy of
     the incoming gradient) instead of two zero-padded slice gradients that autograd would add, and the ReLU
-    mask is applied inside the reducer's backward kernel.  a_max runs as ONE GEMM whose epilogue is the ReLU and the
-    segmented max (mrg_linear_relu_segmax_fwd) whenever the split matrix core takes the shape: m is never written."""
+    mask is applied inside the reducer's backward kernel.  Whenever the split matrix core takes the shape, a_max runs as ONE
+    GEMM whose epilogue is the ReLU and the segmented max (mrg_linear_relu_segmax_fwd) and a_mean as a GEMM whose epilogue
+    leaves ordered run sums for the heads reducer (mrg_linear_relu_segsum_fwd): m is never written."""
 
     @staticmethod
     def forward(ctx, mode, x, W, b, graph):

@@ -41,6 +41,7 @@ ENTRY_KERNELS = {
     "mrg_linear_bwd_weight3": ["wgrad_x3_k@max", "wgrad_reduce3_k"],
     "mrg_dense_filter_dz3": ["dense_dz_k@max"],
     "mrg_linear_relu_segmax_fwd": ["rowgemm_x3_k<7, 2, 4", "segmax_finalize_k"],
+    "mrg_linear_relu_segsum_fwd": ["rowgemm_x3_k<7, 2, 5"],
 }
 NORTH_STAR = "span_gcs_k<4, 64, 1, 0,"            # MODE = SUB only runs in bench.py's north-star passes (last parameter: prefetch-depth override)
 
