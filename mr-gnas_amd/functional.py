@@ -429,6 +429,24 @@ class _LinReluPartial(torch.autograd.Function):
             ctx.mode, ctx.graph, ctx.fused = mode, graph, True
             ctx.save_for_backward(x, W, arg, mx)
             return out, x[E:].clone()
+        if (mode != 2 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) > 0):
+            # the partial SUM of ReLU(linear) without the [E, D] messages (see _LinReluAgg): run sums in the GEMM epilogue + heads reducer
+            p = graph.plan()
+            part = torch.empty(E, D, dtype=torch.float32, device=x.device)
+            bits = torch.empty(E, (D + 31) // 32, dtype=torch.int32, device=x.device)
+            gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
+            call("mrg_linear_relu_segsum_fwd", (ptr(x), ptr(W), ptr(b), ptr(p["eid"]), ptr(graph.i32("dst")), ptr(part), ptr(bits), ptr(gws),
+                                                E, D, D, st), nbytes=4 * E * D + 8 * E + 4 * D * D, flops=2 * E * D * D)
+            out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+            n_chunks, n_hubs, n_slots = _cnt(p, "chunks"), _cnt(p, "hubs"), _cnt(p, "slots")
+            ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), x) if n_slots > 0 else None
+            call("mrg_seg_reduce_heads_fwd", (0, ptr(part), None, ptr(p["rowptr"]), ptr(p["chunk_node"]), ptr(p["chunk_start"]),
+                                              ptr(p["chunk_end"]), ptr(p["chunk_slot"]), n_chunks, ptr(p["hub_node"]), ptr(p["hub_first"]),
+                                              ptr(p["hub_count"]), n_hubs, n_slots, ptr(p["in_degree"]), ptr(out), ptr(ws), N, D, st),
+                 nbytes=8 * N * D + 4 * E)
+            ctx.mode, ctx.graph, ctx.fused = mode, graph, "sum"
+            ctx.save_for_backward(x, W, bits)
+            return out, x[E:].clone()
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
         gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
         call("mrg_linear_fwd", (ptr(x), ptr(W), ptr(b), ptr(y), ptr(gws), E, D, D, 1, st),
@@ -444,7 +462,9 @@ class _LinReluPartial(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, gself):
-        if ctx.fused:
+        if ctx.fused == "sum":
+            x, W, bits = ctx.saved_tensors
+        elif ctx.fused:
             x, W, arg, mx = ctx.saved_tensors
         else:
             x, W, y, *rest = ctx.saved_tensors
@@ -459,7 +479,10 @@ class _LinReluPartial(torch.autograd.Function):
         else:
             gx[E:].zero_()
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
-        if ctx.fused:
+        if ctx.fused == "sum":
+            call("mrg_seg_reduce_bwd_bits", (0, ptr(g), ptr(graph.i32("dst")), ptr(graph.plan()["in_degree"]), ptr(gy), None, ptr(bits),
+                                             E, graph.number_of_nodes(), D, st), nbytes=4 * D * E + 4 * E + 4 * D * graph.number_of_nodes())
+        elif ctx.fused:
             _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)          # the winning message is ReLU-dead iff the maximum is 0
         else:
             _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)        # gy masked by ReLU
