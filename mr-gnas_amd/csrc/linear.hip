@@ -660,7 +660,7 @@ using namespace mrg;
 static bool segmax_shape_ok(int K, int Nout) { return K > 48 && K % 4 == 0 && Nout > 0; }
 
 extern "C" int64_t mrg_linear_relu_segmax_workspace_bytes(int64_t N, int K, int Nout) {
-  if (N < 0 || !segmax_shape_ok(K, Nout)) return 0;                    // 0: the split core cannot take the shape (use the unfused entry points)
+  if (N < 0 || !segmax_shape_ok(K, Nout) || gemm_mode() == 1) return 0;   // 0: the split core cannot take the shape or is switched off (use the unfused entry points)
   return ((N * (int64_t)Nout * 8 + 255) / 256) * 256 + (int64_t)x3_bsplit_bytes(Nout, K, gemm_pick_nt(Nout)) + 256;
 }
 

@@ -302,6 +302,12 @@ FUSED_AMAX_MIN_ROWS = int(os.environ.get("MRG_FUSED_AMAX_MIN_ROWS", "100000"))
 FUSED_AMEAN = os.environ.get("MRG_FUSED_AMEAN", "1") == "1"    # lab switch: 0 = linear, then the span reducer over the [E, D] messages
 
 
+def _fused_agg_ws(N, D):
+    """Workspace of the fused a_max (0: not available).  Asked every time: it also answers 0 while mrg_gemm_set_mode(1) keeps
+    every GEMM on the exact-f32 core (the fused epilogues exist on the split core only)."""
+    return int(_lib.load().mrg_linear_relu_segmax_workspace_bytes(N, D, D))
+
+
 class _LinReluAgg(torch.autograd.Function):
     """a_max / a_mean as ONE autograd node on the reference's [M, D] layout
     (reference models/operations_lp.py:230-235, 245-250):
@@ -320,7 +326,7 @@ class _LinReluAgg(torch.autograd.Function):
         if x.shape[0] != E + N:
             raise _lib.MrgnasError(f"expected {E + N} rows (E + N), got {x.shape[0]}")
         st = stream_of(x)
-        fused_ws = _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) if (mode == 2 and FUSED_AMAX and E >= FUSED_AMAX_MIN_ROWS) else 0
+        fused_ws = _fused_agg_ws(N, D) if (mode == 2 and FUSED_AMAX and E >= FUSED_AMAX_MIN_ROWS) else 0
         if fused_ws > 0:
             # a_max as ONE GEMM whose epilogue is ReLU + segmented max (the [E, D] messages are never written; the
             # backward's ReLU mask is "the maximum is positive")
@@ -335,7 +341,7 @@ class _LinReluAgg(torch.autograd.Function):
             ctx.save_for_backward(x, W, arg, mx)
             return out
         if (mode == 1 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and hasattr(graph, "plan")
-                and _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) > 0):
+                and _fused_agg_ws(N, D) > 0):
             # a_mean without the [E, D] messages: the GEMM's epilogue leaves ordered run sums at the head rows of `part` and one
             # ReLU bit per element; the chunk reducer adds a node's head rows
             p = graph.plan()
@@ -418,7 +424,7 @@ class _LinReluPartial(torch.autograd.Function):
         require_hip(x, W, b)
         E, N, D = graph.num_edges(), graph.number_of_nodes(), x.shape[1]
         st = stream_of(x)
-        fused_ws = _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) if (mode == 2 and FUSED_AMAX and E >= FUSED_AMAX_MIN_ROWS) else 0
+        fused_ws = _fused_agg_ws(N, D) if (mode == 2 and FUSED_AMAX and E >= FUSED_AMAX_MIN_ROWS) else 0
         if fused_ws > 0:                                # one GEMM with the ReLU + segmented-max epilogue, as in _LinReluAgg
             out = torch.empty(N, D, dtype=torch.float32, device=x.device)
             arg = torch.empty(N, D, dtype=torch.int32, device=x.device)
@@ -429,7 +435,7 @@ class _LinReluPartial(torch.autograd.Function):
             ctx.mode, ctx.graph, ctx.fused = mode, graph, True
             ctx.save_for_backward(x, W, arg, mx)
             return out, x[E:].clone()
-        if (mode != 2 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and _ws_bytes("mrg_linear_relu_segmax_workspace_bytes", N, D, D) > 0):
+        if (mode != 2 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and _fused_agg_ws(N, D) > 0):
             # the partial SUM of ReLU(linear) without the [E, D] messages (see _LinReluAgg): run sums in the GEMM epilogue + heads reducer
             p = graph.plan()
             part = torch.empty(E, D, dtype=torch.float32, device=x.device)
