@@ -238,7 +238,10 @@ int mrg_mix_finalize_fwd(const double *sums, const float *const *gamma_host, con
 int mrg_mix_stats_coef(const float *const *y, const float *const *gamma, const float *const *beta,
                        float *const *running_mean, float *const *running_var, int K, int64_t rows, double total_rows,
                        int D, float eps, float momentum, float *coef, void *ws, void *stream);
-int mrg_mix_fwd(const float *const *y_host, int K, const float *coef, const float *w, float *out,
+/* out = (addend ? addend : 0) + sum_k w[k] ReLU(y_k scale_k + shift_k).  addend (may be NULL, may NOT alias out): the output
+ * of the MixedOp this one is summed with -- a state fed by several MixedOps (reference models/cell_lp.py:104-113) is
+ * accumulated here instead of by separate full-size add kernels. */
+int mrg_mix_fwd(const float *const *y_host, int K, const float *coef, const float *w, const float *addend, float *out,
                 int64_t rows, int D, void *stream);
 int mrg_mix_bwd_reduce(const float *g, const float *const *y_host, int K, const float *coef, const float *w,
                        float *red, void *ws, int64_t rows, int D, void *stream);

@@ -55,7 +55,7 @@ SIGNATURES = {
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
     "mrg_mix_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
-    "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_finalize_bwd": (_I, [_P, _I, ctypes.c_double, _I, _P, _P, _P, _P, _P]),
     "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),

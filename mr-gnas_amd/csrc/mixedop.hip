@@ -159,7 +159,8 @@ __global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb,
 // ---- forward combine
 template <int VEC, int LPR, int KMAX>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
-                                                       float* __restrict__ out, int64_t rows, int D) {
+                                                       float* __restrict__ out, int64_t rows, int D,
+                                                       const float* __restrict__ addend) {
   extern __shared__ float lds[];                 // [K][2][D] scale, shift
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
       if (c < dv) {
-        Vec<VEC> acc = Vec<VEC>::fill(0.f);
+        // `addend`: the output of the MixedOp this one is summed with (reference models/cell_lp.py:104-113: sum of the
+        // MixedOps feeding a state) -- added here instead of by a separate full-size kernel
+        Vec<VEC> acc = addend ? Vec<VEC>::load(addend + r * D + c * VEC) : Vec<VEC>::fill(0.f);
         // phase 1: every branch's load is issued before any is used (a load consumed inside its own `if (k < K)`
         // block leaves one 16-byte load in flight per lane)
         Vec<VEC> vin[MRG_MIX_MAXK];
@@ -461,21 +464,21 @@ extern "C" int mrg_mix_finalize_fwd(const double* sums, const float* const* gamm
   return MRG_OK;
 }
 
-extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef, const float* w, float* out, int64_t rows, int D,
-                           void* stream) {
+extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef, const float* w, const float* addend, float* out,
+                           int64_t rows, int D, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!coef || !w || !out) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
   PtrPack ys{};
-  bool al = aligned16(out);
+  bool al = aligned16(out) && aligned16(addend);
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
   RowGeom g = row_geom(D, al);
   if (!g.ok) return MRG_E_SHAPE;
   size_t lds = (size_t)K * 2 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
-  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D)
+  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();

@@ -307,11 +307,11 @@ class ShardedSupernet:
         self.p_rel = kernels.GatherPlan(rel_idx, model._num_rel)
 
     # -- pieces ---------------------------------------------------------------------------
-    def _mixed(self, mixed_op, w, h, h_in, total_rows):
+    def _mixed(self, mixed_op, w, h, h_in, total_rows, addend=None):
         if (h.x if isinstance(h, K.Fan) else h).is_cuda:   # fused HIP epilogue with the statistics all-reduced in between
-            return mixed_op(w, self.s, h, h_in, group=self._stat_group(), total_rows=total_rows)
+            return mixed_op(w, self.s, h, h_in, group=self._stat_group(), total_rows=total_rows, addend=addend)
         h, h_in = (t.x if isinstance(t, K.Fan) else t for t in (h, h_in))
-        out = 0
+        out = 0 if addend is None else addend
         for wk, (op, bn, act) in zip(w, mixed_op._ops):
             out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
         return out
@@ -399,13 +399,17 @@ class ShardedSupernet:
         h_in = fan(self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M))
         states, off = [h_in], 0
         for _ in range(cell.n_first):
-            sN = _tsum(self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M) for j, h in enumerate(states))
+            sN = None
+            for j, h in enumerate(states):
+                sN = self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M, addend=sN)
             off += len(states)
             states.append(fan(sN))
         states = [fan(y) for y in self._middle_stage(cell, wm, states[1:], N)]
         off = 0
         for _ in range(cell.n_last):
-            sN = _tsum(self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N) for j, h in enumerate(states))
+            sN = None
+            for j, h in enumerate(states):
+                sN = self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N, addend=sN)
             off += len(states)
             states.append(fan(sN))
         states = [t.take() if isinstance(t, K.Fan) else t for t in states]

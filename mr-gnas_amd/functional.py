@@ -873,8 +873,8 @@ class _MixCfg:
     """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
     updated in place like torch does), which branches are all-zero, sharding info."""
 
-    def __init__(self, bns, present, group=None, total_rows=None):
-        self.bns, self.present, self.group, self.total_rows = bns, present, group, total_rows
+    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False):
+        self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
 
 
 class _MixedEpilogue(torch.autograd.Function):
@@ -885,12 +885,13 @@ class _MixedEpilogue(torch.autograd.Function):
         nz = sum(cfg.present)
         ys_nz = [f32c(t) for t in tensors[:nz]]
         gam, bet = list(tensors[nz:nz + K_]), list(tensors[nz + K_:nz + 2 * K_])
+        addend = f32c(tensors[nz + 2 * K_]) if cfg.has_addend else None
         it = iter(ys_nz)
         ys = [next(it) if p else None for p in cfg.present]
         ref = ys_nz[0] if ys_nz else None
         if ref is None:
             raise _lib.MrgnasError("mixed epilogue needs at least one non-zero branch to know the row count")
-        require_hip(w, *ys_nz, *gam, *bet)
+        require_hip(w, addend, *ys_nz, *gam, *bet)
         rows, D = ref.shape
         dev, st = ref.device, stream_of(ref)
         w = f32c(w)
@@ -924,7 +925,7 @@ class _MixedEpilogue(torch.autograd.Function):
                 coef[k, 2] = invstd
                 coef[k, 3] = b.running_mean * invstd
         out = torch.empty(rows, D, dtype=torch.float32, device=dev)
-        call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(out), rows, D, st), nbytes=4 * D * rows * (nz + 1))
+        call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(addend), ptr(out), rows, D, st), nbytes=4 * D * rows * (nz + 1 + (addend is not None)))
         ctx.cfg, ctx.training, ctx.total, ctx.nz = cfg, training, total, nz
         ctx.save_for_backward(w, coef, *ys_nz)
         return out
@@ -964,15 +965,16 @@ class _MixedEpilogue(torch.autograd.Function):
              nbytes=4 * D * rows * (1 + nz + n_out))
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
-        return (None, dw, *gys_nz, *dgam, *dbet)
+        return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
 
 
-def mixed_epilogue(ys, bns, w, group=None, total_rows=None):
-    """sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
-    all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine)."""
+def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None):
+    """addend + sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
+    all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine); addend: the output of the MixedOp this
+    one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel."""
     present = [y is not None for y in ys]
-    cfg = _MixCfg(list(bns), present, group, total_rows)
-    tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns]
+    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None)
+    tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)
 
 

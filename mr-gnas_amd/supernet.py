@@ -69,20 +69,20 @@ class MixedOp(nn.Module):
         self._ops = nn.ModuleList(nn.ModuleList([registry[name](args), nn.BatchNorm1d(feature_dim), nn.ReLU()])
                                   for name in operations)
 
-    def forward(self, weights, g, h, h_in, group=None, total_rows=None):
+    def forward(self, weights, g, h, h_in, group=None, total_rows=None, addend=None):
         """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
         BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
         materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
         if not (h.x if isinstance(h, K.Fan) else h).is_cuda:    # reference formulation (registry of non-HIP test operators)
             if isinstance(h, K.LazyRows):
                 h, h_in = h.materialize(), h_in.materialize()
-            total = 0
+            total = 0 if addend is None else addend
             for w, (op, bn, act) in zip(weights, self._ops):
                 total = total + w * act(bn(op(g, h, h_in).float()))
             return total
         if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
             ys = [op(g, h, h_in) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
         # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
         # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
         n = len(self._ops)
@@ -96,7 +96,7 @@ class MixedOp(nn.Module):
         nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
         if nstreams <= 1:
             ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
         fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
         for k, (op, _, _) in enumerate(self._ops):
@@ -113,7 +113,7 @@ class MixedOp(nn.Module):
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
-        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows)
+        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
 
 
 class _Stage(nn.Module):
@@ -149,7 +149,9 @@ class SuperCell(nn.Module):
     def _dense_stage(self, stage, states, weights, g, h_in, steps):
         off = 0
         for _ in range(steps):
-            s = _tsum(stage._ops[off + j](weights[off + j], g, h, h_in) for j, h in enumerate(states))
+            s = None                                   # the MixedOps feeding one state: each adds onto the previous one's output
+            for j, h in enumerate(states):
+                s = stage._ops[off + j](weights[off + j], g, h, h_in, addend=s)
             off += len(states)
             states.append(self._fan(s))
         return states
