@@ -15,6 +15,9 @@ namespace mrg {
 
 struct PtrPack { const float* p[MRG_MIX_MAXK]; };
 struct MutPack { float* p[MRG_MIX_MAXK]; };
+// optional per-candidate row scale applied to the candidate's output gradient as it is written (mix_bwd_apply_k):
+// gy_k[r] *= r < edge_rows[k] ? scale[k] * (rs[k] ? rs[k][r] : 1) : self_scale[k]      when on[k]
+struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK]; };
 
 // ---- column statistics: sums[k][0][c] = sum_r y_k[r][c], sums[k][1][c] = sum_r y_k[r][c]^2 (float64)
 template <int VEC, int LPR, int KMAX>
@@ -317,7 +320,7 @@ __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double 
 template <int VEC, int LPR, int KMAX>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
-                                                             const float* __restrict__ w, int64_t rows, int D) {
+                                                             const float* __restrict__ w, int64_t rows, int D, RowScalePack rsp) {
   extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
@@ -356,6 +359,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
               float xh = v[j] * c2[j] - c3[j];
               float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
               o[j] = (gr - c4[j] - xh * c5[j]) * c0[j];
+            }
+            if (rsp.on[k]) {                               // the consumer's row scale (f_comp: dz = g * c) folded into this store
+              const float ck = r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k];
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) o[j] = o[j] * ck;
             }
             o.store(gys.p[k] + r * D + c * VEC);
           }
@@ -532,7 +540,9 @@ extern "C" int mrg_mix_finalize_bwd(const float* red, int K, double total_rows, 
 }
 
 extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, float* const* gy_host, int K, const float* coef,
-                                 const float* coef2, const float* w, int64_t rows, int D, void* stream) {
+                                 const float* coef2, const float* w, const float* const* rs_host, const float* rs_scale_host,
+                                 const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host, int64_t rows, int D,
+                                 void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
@@ -547,12 +557,21 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
     any = any || gy_host[k] != nullptr;
   }
   if (!any) return MRG_OK;
+  RowScalePack rsp{};
+  if (rs_on_host) {
+    if (!rs_scale_host || !rs_self_host || !rs_edge_rows_host) return MRG_E_NULLPTR;
+    for (int k = 0; k < K; ++k) {
+      rsp.on[k] = rs_on_host[k];
+      rsp.rs[k] = rs_host ? rs_host[k] : nullptr;
+      rsp.scale[k] = rs_scale_host[k]; rsp.self_scale[k] = rs_self_host[k]; rsp.edge_rows[k] = rs_edge_rows_host[k];
+    }
+  }
   RowGeom gm = row_geom(D, al);
   if (!gm.ok) return MRG_E_SHAPE;
   size_t lds = (size_t)K * 6 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
-  hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D)
+  hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp)
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();

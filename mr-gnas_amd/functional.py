@@ -873,8 +873,9 @@ class _MixCfg:
     """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
     updated in place like torch does), which branches are all-zero, sharding info."""
 
-    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False):
+    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None):
         self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
+        self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self): folded into its gradient
 
 
 class _MixedEpilogue(torch.autograd.Function):
@@ -961,19 +962,38 @@ class _MixedEpilogue(torch.autograd.Function):
         it = iter(gys_nz)
         gys = [next(it) if p else None for p in cfg.present]
         n_out = sum(t is not None for t in gys_nz)
-        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rows, D, st),
+        rs = cfg.rowscale
+        if rs is not None and any(r is not None for r in rs):
+            import ctypes
+            on = (ctypes.c_int * K_)(*[int(r is not None) for r in rs])
+            rs_ptr = ptr_array([r[0] if r is not None else None for r in rs])
+            rs_edge = (ctypes.c_int64 * K_)(*[int(r[1]) if r is not None else 0 for r in rs])
+            rs_scale = (ctypes.c_float * K_)(*[float(r[2]) if r is not None else 1.0 for r in rs])
+            rs_self = (ctypes.c_float * K_)(*[float(r[3]) if r is not None else 1.0 for r in rs])
+        else:
+            on = rs_ptr = rs_edge = rs_scale = rs_self = None
+        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on, rows, D, st),
              nbytes=4 * D * rows * (1 + nz + n_out))
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
 
 
-def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None):
+def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_row_scales=False):
     """addend + sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
     all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine); addend: the output of the MixedOp this
     one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel."""
     present = [y is not None for y in ys]
-    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None)
+    # a candidate whose backward starts with a row scale of its incoming gradient (f_comp: dz = g * c) and whose output feeds
+    # ONLY this epilogue gets that scale folded into the epilogue's gradient store; its backward node is told to skip the pass
+    rowscale = [None] * len(ys)
+    if fold_row_scales:
+        for k, y in enumerate(ys):
+            spec = getattr(y, "_mrg_rowscale", None) if y is not None else None
+            if spec is not None and y.grad_fn is not None and getattr(y.grad_fn, "prescaled", None) is False:
+                rowscale[k] = spec
+                y.grad_fn.prescaled = True
+    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)
 
@@ -1020,6 +1040,7 @@ class Fork:
             self.main.wait_stream(st)
 
 
+FOLD_ROW_SCALE = os.environ.get("MRG_FOLD_ROW_SCALE", "1") == "1"          # lab switch: 0 = f_comp's dz pass stays a launch of its own
 GROUPED_SEGMENTS = os.environ.get("MRG_GROUPED_SEGMENTS", "1") == "1"    # lab switch: 0 = one launch per direction segment
 
 
@@ -1081,9 +1102,12 @@ class _DenseFilter(torch.autograd.Function):
                 Ws = [params[0], params[2], params[4]]
                 gWs = [torch.empty_like(W) for W in Ws]
                 gbs = [torch.empty_like(params[2 * i + 1]) if params[2 * i + 1] is not None else None for i in range(3)]
-                dz = torch.empty(M, D, dtype=torch.float32, device=s.device)
-                call("mrg_dense_filter_dz3", (kind, ptr(g), ptr(s), ptr(gate), ptr(norm), scale_edge, scale_self, ptr(dz), ptr(gs), b1, M, D, st),
-                     nbytes=4 * M * D * (5 if kind == 0 else 2))
+                if kind == 1 and getattr(ctx, "prescaled", False):
+                    dz = g                                  # the MixedOp epilogue wrote the gradient already multiplied by c
+                else:
+                    dz = torch.empty(M, D, dtype=torch.float32, device=s.device)
+                    call("mrg_dense_filter_dz3", (kind, ptr(g), ptr(s), ptr(gate), ptr(norm), scale_edge, scale_self, ptr(dz), ptr(gs), b1, M, D, st),
+                         nbytes=4 * M * D * (5 if kind == 0 else 2))
                 gwork = dict(nbytes=4 * M * 2 * D + 12 * D * D, flops=2 * M * D * D)
                 call("mrg_linear_bwd_input3", (ptr(dz), ptr_array(Ws), ptr(gs), ptr(_ws(wsi, s)), b0, b1, M, D, D, K_, int(kind == 0), st), **gwork)
                 if s_in is not None:
@@ -1116,9 +1140,12 @@ class _DenseFilter(torch.autograd.Function):
             W, rows, sl = w["W"], w["rows"], w["sl"]
             with fork.on(j):
                 st = stream_of(s)
-                # 1. dz (+ direct term of gs for the gated kinds)
-                call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(w["rs"]),
-                                             w["scale"], ptr(w["dz"]), ptr(gs[sl]), rows, D, st), nbytes=4 * rows * D * (5 if kind == 0 else 2))
+                # 1. dz (+ direct term of gs for the gated kinds); f_comp behind a MixedOp epilogue: the gradient arrives scaled
+                if kind == 1 and getattr(ctx, "prescaled", False):
+                    w["dz"] = g[sl]
+                else:
+                    call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(w["rs"]),
+                                                 w["scale"], ptr(w["dz"]), ptr(gs[sl]), rows, D, st), nbytes=4 * rows * D * (5 if kind == 0 else 2))
                 # 2. gs (+)= dz W[:, :D];  gs_in = dz W[:, D:]
                 gwork = dict(nbytes=4 * rows * 2 * D + 4 * D * D, flops=2 * rows * D * D)
                 call("mrg_linear_bwd_input", (ptr(w["dz"]), ptr(W), ptr(gs[sl]), ptr(w["wt"]), rows, D, D, K_, int(kind == 0), st), **gwork)
@@ -1166,8 +1193,14 @@ def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_s
     if s_in is not None and same_rows(s, s_in):
         W_in, W_out, W_self = _FoldHalves.apply(W_in, W_out, W_self)
         s_in = None
-    return _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
-                              W_in, b_in, W_out, b_out, W_self, b_self)
+    y = _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
+                           W_in, b_in, W_out, b_out, W_self, b_self)
+    if kind == 1 and FOLD_ROW_SCALE and y.grad_fn is not None and y.is_cuda:
+        # f_comp's backward begins with dz = g * c (c = norm / 3 on edge rows, self_scale on self rows): a MixedOp epilogue that is
+        # the only reader of y may write its gradient already scaled (mixed_epilogue(fold_row_scales=True)) and flip `prescaled`
+        y.grad_fn.prescaled = False
+        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale))
+    return y
 
 
 def dense_filter_single(s, s_in, W, b):

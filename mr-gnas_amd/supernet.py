@@ -82,7 +82,7 @@ class MixedOp(nn.Module):
             return total
         if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
             ys = [op(g, h, h_in) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
         # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
         # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
         n = len(self._ops)
@@ -96,7 +96,7 @@ class MixedOp(nn.Module):
         nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
         if nstreams <= 1:
             ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
         fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
         for k, (op, _, _) in enumerate(self._ops):
@@ -113,7 +113,7 @@ class MixedOp(nn.Module):
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
-        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend)
+        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
 
 
 class _Stage(nn.Module):
