@@ -250,9 +250,13 @@ int mrg_mix_finalize_bwd(const float *red, int K, double total_rows, int D, floa
 /* rs_on (HOST int[K], may be NULL = none): candidate k's output gradient is written already multiplied by its consumer's row
  * scale, gy_k[r] *= r < rs_edge_rows[k] ? rs_scale[k] * (rs[k] ? rs[k][r] : 1) : rs_self[k] -- exactly the `dz = g * c` pass of
  * f_comp_op's backward (mrg_dense_filter_dz, kind 1), which the caller then skips (bit-identical values). */
+/* rs_on[k] == 2: the gated form, mrg_dense_filter_dz kind 0 of f_dense_op_comp's backward: with gc = gy * c, gy_k receives
+ * dz = gc * s * gate * (1 - gate) and fold_gs[k] the direct term gc * gate (fold_s / fold_gate / fold_gs: HOST arrays of K
+ * device pointers, used for those k only). */
 int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *gy_host, int K,
                       const float *coef, const float *coef2, const float *w, const float *const *rs, const float *rs_scale,
-                      const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, int64_t rows, int D, void *stream);
+                      const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *fold_s,
+                      const float *const *fold_gate, float *const *fold_gs, int64_t rows, int D, void *stream);
 
 /* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
  * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)

@@ -17,7 +17,10 @@ struct PtrPack { const float* p[MRG_MIX_MAXK]; };
 struct MutPack { float* p[MRG_MIX_MAXK]; };
 // optional per-candidate row scale applied to the candidate's output gradient as it is written (mix_bwd_apply_k):
 // gy_k[r] *= r < edge_rows[k] ? scale[k] * (rs[k] ? rs[k][r] : 1) : self_scale[k]      when on[k]
-struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK]; };
+// on[k] == 2: the gated form (f_dense_comp, mrg_dense_filter_dz kind 0): with gc = gy * c, the candidate's gradient buffer receives
+// dz = gc * s * gate * (1 - gate) and gs_out[k] the direct term gc * gate of the gradient w.r.t. s.
+struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK];
+                      const float* s[MRG_MIX_MAXK]; const float* gate[MRG_MIX_MAXK]; float* gs_out[MRG_MIX_MAXK]; };
 
 // ---- column statistics: sums[k][0][c] = sum_r y_k[r][c], sums[k][1][c] = sum_r y_k[r][c]^2 (float64)
 template <int VEC, int LPR, int KMAX>
@@ -360,10 +363,22 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
               float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
               o[j] = (gr - c4[j] - xh * c5[j]) * c0[j];
             }
-            if (rsp.on[k]) {                               // the consumer's row scale (f_comp: dz = g * c) folded into this store
+            if (rsp.on[k]) {                               // the consumer's first backward pass (mrg_dense_filter_dz) folded into this store
               const float ck = r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k];
+              if (rsp.on[k] == 2) {                        // f_dense_comp: same expressions, same order as dense_dz_k<.., 0>
+                const Vec<VEC> sv = Vec<VEC>::load(rsp.s[k] + r * D + c * VEC), ga = Vec<VEC>::load(rsp.gate[k] + r * D + c * VEC);
+                Vec<VEC> o2;
 #pragma unroll
-              for (int j = 0; j < VEC; ++j) o[j] = o[j] * ck;
+                for (int j = 0; j < VEC; ++j) {
+                  const float gc = o[j] * ck;
+                  o2[j] = gc * ga[j];
+                  o[j] = gc * sv[j] * ga[j] * (1.0f - ga[j]);
+                }
+                o2.store(rsp.gs_out[k] + r * D + c * VEC);
+              } else {                                     // f_comp: dz = g * c
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = o[j] * ck;
+              }
             }
             o.store(gys.p[k] + r * D + c * VEC);
           }
@@ -541,8 +556,9 @@ extern "C" int mrg_mix_finalize_bwd(const float* red, int K, double total_rows, 
 
 extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, float* const* gy_host, int K, const float* coef,
                                  const float* coef2, const float* w, const float* const* rs_host, const float* rs_scale_host,
-                                 const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host, int64_t rows, int D,
-                                 void* stream) {
+                                 const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host,
+                                 const float* const* fold_s_host, const float* const* fold_gate_host, float* const* fold_gs_host,
+                                 int64_t rows, int D, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
@@ -564,6 +580,13 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
       rsp.on[k] = rs_on_host[k];
       rsp.rs[k] = rs_host ? rs_host[k] : nullptr;
       rsp.scale[k] = rs_scale_host[k]; rsp.self_scale[k] = rs_self_host[k]; rsp.edge_rows[k] = rs_edge_rows_host[k];
+      if (rsp.on[k] == 2) {
+        if (!fold_s_host || !fold_gate_host || !fold_gs_host || !fold_s_host[k] || !fold_gate_host[k] || !fold_gs_host[k]) return MRG_E_NULLPTR;
+        rsp.s[k] = fold_s_host[k]; rsp.gate[k] = fold_gate_host[k]; rsp.gs_out[k] = fold_gs_host[k];
+        al = al && aligned16(rsp.s[k]) && aligned16(rsp.gate[k]) && aligned16(rsp.gs_out[k]);
+      } else if (rsp.on[k] != 0 && rsp.on[k] != 1) {
+        return MRG_E_ENUM;
+      }
     }
   }
   RowGeom gm = row_geom(D, al);

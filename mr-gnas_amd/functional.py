@@ -970,10 +970,26 @@ class _MixedEpilogue(torch.autograd.Function):
             rs_edge = (ctypes.c_int64 * K_)(*[int(r[1]) if r is not None else 0 for r in rs])
             rs_scale = (ctypes.c_float * K_)(*[float(r[2]) if r is not None else 1.0 for r in rs])
             rs_self = (ctypes.c_float * K_)(*[float(r[3]) if r is not None else 1.0 for r in rs])
+            # gated consumers (f_dense_comp): their dz AND the direct term of their input gradient are written here; the buffer of
+            # the direct term is handed to the consumer's backward node (which runs later, maybe on a side stream)
+            gated = [r is not None and r[4] is not None for r in rs]
+            for k in range(K_):
+                if gated[k]:
+                    on[k] = 2
+            f_gs = [torch.empty_like(rs[k][4].saved_tensors[0]) if gated[k] else None for k in range(K_)]
+            f_s = ptr_array([rs[k][4].saved_tensors[0] if gated[k] else None for k in range(K_)])
+            f_gate = ptr_array([rs[k][4].saved_tensors[3] if gated[k] else None for k in range(K_)])
+            for k in range(K_):
+                if gated[k]:
+                    rs[k][4].gs_direct = f_gs[k]
+            f_gs_p = ptr_array(f_gs)
+            n_fold = sum(gated)
         else:
-            on = rs_ptr = rs_edge = rs_scale = rs_self = None
-        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on, rows, D, st),
-             nbytes=4 * D * rows * (1 + nz + n_out))
+            on = rs_ptr = rs_edge = rs_scale = rs_self = f_s = f_gate = f_gs_p = None
+            n_fold = 0
+        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
+                                   f_s, f_gate, f_gs_p, rows, D, st),
+             nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold))
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
@@ -991,7 +1007,7 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
         for k, y in enumerate(ys):
             spec = getattr(y, "_mrg_rowscale", None) if y is not None else None
             if spec is not None and y.grad_fn is not None and getattr(y.grad_fn, "prescaled", None) is False:
-                rowscale[k] = spec
+                rowscale[k] = spec[:4] + (y.grad_fn if spec[4] else None,)       # gated form: the node holds s / gate and receives gs
                 y.grad_fn.prescaled = True
     cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
@@ -1092,7 +1108,12 @@ class _DenseFilter(torch.autograd.Function):
         g = f32c(g)
         M, D = s.shape
         st = stream_of(s)
-        gs = torch.empty_like(s)
+        prescaled = getattr(ctx, "prescaled", False)       # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already
+        if prescaled and kind == 0:
+            gs = ctx.gs_direct
+            gs.record_stream(torch.cuda.current_stream())   # allocated by the epilogue's backward on ITS stream
+        else:
+            gs = torch.empty_like(s)
         gs_in = torch.empty_like(s) if s_in is not None else None
         K_ = 2 * D if s_in is not None else D
         lib = _lib.load()
@@ -1102,8 +1123,8 @@ class _DenseFilter(torch.autograd.Function):
                 Ws = [params[0], params[2], params[4]]
                 gWs = [torch.empty_like(W) for W in Ws]
                 gbs = [torch.empty_like(params[2 * i + 1]) if params[2 * i + 1] is not None else None for i in range(3)]
-                if kind == 1 and getattr(ctx, "prescaled", False):
-                    dz = g                                  # the MixedOp epilogue wrote the gradient already multiplied by c
+                if prescaled:
+                    dz = g
                 else:
                     dz = torch.empty(M, D, dtype=torch.float32, device=s.device)
                     call("mrg_dense_filter_dz3", (kind, ptr(g), ptr(s), ptr(gate), ptr(norm), scale_edge, scale_self, ptr(dz), ptr(gs), b1, M, D, st),
@@ -1141,7 +1162,7 @@ class _DenseFilter(torch.autograd.Function):
             with fork.on(j):
                 st = stream_of(s)
                 # 1. dz (+ direct term of gs for the gated kinds); f_comp behind a MixedOp epilogue: the gradient arrives scaled
-                if kind == 1 and getattr(ctx, "prescaled", False):
+                if prescaled:
                     w["dz"] = g[sl]
                 else:
                     call("mrg_dense_filter_dz", (kind, ptr(g[sl]), ptr(s[sl]), ptr(gate[sl]) if gate is not None else None, ptr(w["rs"]),
@@ -1195,11 +1216,12 @@ def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_s
         s_in = None
     y = _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
                            W_in, b_in, W_out, b_out, W_self, b_self)
-    if kind == 1 and FOLD_ROW_SCALE and y.grad_fn is not None and y.is_cuda:
-        # f_comp's backward begins with dz = g * c (c = norm / 3 on edge rows, self_scale on self rows): a MixedOp epilogue that is
-        # the only reader of y may write its gradient already scaled (mixed_epilogue(fold_row_scales=True)) and flip `prescaled`
+    if FOLD_ROW_SCALE and y.grad_fn is not None and y.is_cuda:
+        # the backward begins with an elementwise pass over the incoming gradient (f_comp: dz = g * c; f_dense_comp: dz = g c s gate
+        # (1 - gate) and the direct term g c gate; c = norm / 3 on edge rows, self_scale on self rows): a MixedOp epilogue that is
+        # the only reader of y writes its gradient in that form (mixed_epilogue(fold_row_scales=True)) and flips `prescaled`
         y.grad_fn.prescaled = False
-        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale))
+        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale), kind == 0)
     return y
 
 
