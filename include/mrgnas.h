@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 6   /* 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 7   /* 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -279,6 +279,12 @@ int64_t mrg_gemm_workspace_bytes(int K, int Nout);
  * for >= 65 536 rows, more than 128 output columns and a plain epilogue.  3 and 4 are tested comparison points: faster
  * or equal alone, not faster inside the multi-stream step.  Process-wide. */
 int mrg_gemm_set_mode(int mode);
+/* Store order of the split-core row GEMM's elementwise epilogues (bias / activation, gate, scale, accumulate):
+ * 1 (default): a 32-row strip of results goes through wave-private LDS and leaves as row-order 16-byte stores
+ * (1 KB of consecutive addresses per store instruction; the gate multiplicand / accumulate input are read the same way)
+ * whenever N % 4 == 0 and the rows of every [rows, N] operand are 16-byte aligned; 0: accumulator-order 4-byte stores
+ * (the comparison point; bit-identical results).  Process-wide. */
+int mrg_gemm_set_epilogue(int row_order);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);
 /* a_max_op.forward as ONE GEMM (reference models/operations_lp.py:230-235; SURVEY section 2b K_lin_relu_segmax):

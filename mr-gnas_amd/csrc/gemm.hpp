@@ -63,6 +63,8 @@ struct GemmArgs {
   // EPI_SEGSUM (no C): run sums of ReLU(acc + bias) at seg_part[head position * N + col], ReLU bit mask at relu_bits, see gemm_epilogue_segsum
   float* seg_part;
   unsigned* relu_bits; int bits_ld;
+  // split core, one-wave kernel: stores in row order through a wave-private LDS strip (gemm_epilogue_lds); set by the launcher
+  int epi_lds; int wave_lds_floats;
   GemmGroups grp;                     // split core, one-wave kernel only
 };
 
@@ -106,7 +108,8 @@ __device__ __forceinline__ void gemm_epilogue_segsum(const GemmArgs& a, f32x16 (
       const float x = acc[n][r] + bv;
       const bool pos = x > 0.f;
       const unsigned long long ball = __ballot(pos);          // lanes 0-31: this register's row of half 0, lanes 32-63: of half 1
-      if (li == 0 && eidv[r] >= 0 && a.relu_bits)
+      // a padding tile (gemm_pick_nt rounds 3 tiles up to 4, 5-6 up to 7) has no word in the row of bits_ld = ceil(N/32) words
+      if (li == 0 && eidv[r] >= 0 && a.relu_bits && (col0 >> 5) + n < a.bits_ld)
         a.relu_bits[(int64_t)eidv[r] * a.bits_ld + (col0 >> 5) + n] = lh ? (unsigned)(ball >> 32) : (unsigned)ball;
       if (seg[r] != cur) {                                   // uniform over the 32 lanes of a half wave
         if (cur >= 0 && cok) a.seg_part[head * a.N + col] = sum;
@@ -318,6 +321,112 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
       }
     }
   }
+}
+
+// ---- the same epilogues with the stores (and the [rows, N] inputs) in ROW order, through a wave-private LDS strip -----------
+// gemm_epilogue above stores an accumulator register as it stands: one global_store_dword per (row quad, column tile) =
+// two 128-byte pieces of two rows, 16 * NT store instructions per 32-row strip.  The row GEMM's store tail is bound by the
+// NUMBER of store instructions, not by their bytes (lab: the one-wave kernel at rows 272 115, K = N = 200 spends 0.09 of its
+// 0.237 ms there; MI355X_MICROARCH.md "attention epilogue store tail", cdna_hip_programming.md T21).  Here the strip is
+// written to LDS in the accumulator layout (ds_write_b32: 32 consecutive floats per half wave, conflict free) and read back as
+// float4 in row-major order, so one global_store_dwordx4 writes 1 KB of consecutive addresses: W / 8 store instructions per
+// strip (25 instead of 112 at W = 200), and the gate multiplicand / accumulate input are read the same way.
+// Arithmetic and its order per element are those of gemm_epilogue (bit-identical results): the bias add, the activation /
+// sigmoid and the row scale of EPI_SCALE happen before the LDS round trip, the products with row-major inputs after it.
+// stage: wave-private LDS, 32 * NT * 32 + 32 floats.  Requires N % 4 == 0 and 16-byte aligned rows of C / S / aux / Cin.
+constexpr int GEMM_STAGE_PAD = 32;       // the strip's 32 row scales (EPI_GATE)
+inline size_t gemm_stage_floats(int nt) { return (size_t)32 * nt * 32 + GEMM_STAGE_PAD; }
+
+template <int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int lane,
+                                                  float* __restrict__ stage) {
+  if (rowbase >= a.rows) return;                            // wave-uniform
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = (a.N - col0) < NT * 32 ? (a.N - col0) : NT * 32;                  // columns of this block: wave-uniform, % 4 == 0
+  const int w4 = W >> 2;
+  const int nrows = (int)((a.rows - rowbase) < 32 ? (a.rows - rowbase) : 32);
+  float* cs_lds = stage + 32 * NT * 32;
+  // ---- accumulator layout: bias, activation, (EPI_SCALE) row scale; then the strip goes to LDS as [32][W]
+  float cs[16];
+  if (EPI == EPI_GATE || EPI == EPI_SCALE) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int rc = row < nrows ? row : nrows - 1;
+      cs[r] = a.scale * (a.rowscale ? a.rowscale[rowbase + rc] : 1.0f);
+      if (EPI == EPI_GATE && li == 0) cs_lds[row] = cs[r];
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n * 32 + li;
+    const bool cok = col < W;
+    const float bv = a.bias ? a.bias[col0 + (cok ? col : 0)] : 0.f;
+    float* sp = stage + (4 * lh) * W + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = acc[n][r] + bv;
+      float v;
+      if (EPI == EPI_BIAS_ACT) v = (a.act == MRG_ACT_RELU) ? (x > 0.f ? x : 0.f) : (a.act == MRG_ACT_SIGMOID ? sigmoidf_fast(x) : x);
+      else if (EPI == EPI_GATE) v = sigmoidf_fast(x);
+      else if (EPI == EPI_SCALE) v = x * cs[r];
+      else v = x;
+      if (cok) sp[((r & 3) + 8 * (r >> 2)) * W] = v;
+    }
+  }
+  // (same wave: the LDS executes a wave's operations in order, no barrier)
+  // ---- row-major order: float4 q of the strip = row q / w4, columns 4 (q % w4) ...
+  const int total = nrows * w4;
+  const int sr = 64 / w4, sc = 64 - sr * w4;                 // what 64 float4 further means in (row, float4 column)
+  int r = lane / w4, c = lane - r * w4;
+  float* __restrict__ Cb = a.C + rowbase * a.ldc + col0;
+  const float* __restrict__ Sb = nullptr;
+  float* __restrict__ Xb = nullptr;
+  int ld_in = 0;
+  if (EPI == EPI_GATE) { Sb = a.S + rowbase * a.ld_s + col0; ld_in = a.ld_s; Xb = a.aux ? a.aux + rowbase * a.N + col0 : nullptr; }
+  if (EPI == EPI_ACCUM) { Sb = a.Cin + rowbase * a.ld_cin + col0; ld_in = a.ld_cin; }
+  constexpr int U = 5;                                       // float4 per lane in flight
+  for (int q0 = lane; q0 - lane < total; q0 += 64 * U) {
+    float4 v[U], in[U];
+    float csr[U];
+    int ro[U], co[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 64 * u;
+      ok[u] = q < total;
+      const int rr = ok[u] ? r : 0, cc = ok[u] ? c : 0;       // clamped: loads are unconditional, only the stores are guarded
+      ro[u] = rr; co[u] = cc * 4;
+      v[u] = *reinterpret_cast<const float4*>(stage + rr * W + cc * 4);
+      if (EPI == EPI_GATE || EPI == EPI_ACCUM) in[u] = *reinterpret_cast<const float4*>(Sb + (int64_t)rr * ld_in + cc * 4);
+      if (EPI == EPI_GATE) csr[u] = cs_lds[rr];
+      c += sc; r += sr;
+      if (c >= w4) { c -= w4; ++r; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 o = v[u];
+      if (EPI == EPI_GATE) {
+        o.x = v[u].x * in[u].x * csr[u]; o.y = v[u].y * in[u].y * csr[u]; o.z = v[u].z * in[u].z * csr[u]; o.w = v[u].w * in[u].w * csr[u];
+      } else if (EPI == EPI_ACCUM) {
+        o.x = v[u].x + in[u].x; o.y = v[u].y + in[u].y; o.z = v[u].z + in[u].z; o.w = v[u].w + in[u].w;
+      }
+      if (ok[u]) {
+        *reinterpret_cast<float4*>(Cb + (int64_t)ro[u] * a.ldc + co[u]) = o;
+        if (EPI == EPI_GATE && Xb) *reinterpret_cast<float4*>(Xb + (int64_t)ro[u] * a.N + co[u]) = v[u];
+      }
+    }
+  }
+}
+
+// host side: may this launch use gemm_epilogue_lds?
+template <int EPI>
+inline bool gemm_epilogue_lds_ok(const GemmArgs& a) {
+  if (EPI != EPI_BIAS_ACT && EPI != EPI_GATE && EPI != EPI_SCALE && EPI != EPI_ACCUM) return false;
+  if (a.N % 4 != 0 || a.ldc % 4 != 0 || !aligned16(a.C)) return false;
+  if (EPI == EPI_GATE && (a.ld_s % 4 != 0 || !aligned16(a.S) || (a.aux && !aligned16(a.aux)))) return false;
+  if (EPI == EPI_ACCUM && (a.ld_cin % 4 != 0 || !aligned16(a.Cin))) return false;
+  return true;
 }
 
 template <int NT, int MT, int GBK, int EPI, bool VEC4>

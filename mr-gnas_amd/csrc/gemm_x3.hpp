@@ -141,6 +141,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef MRG_VM
 }
 
+// lab switch (mrg_gemm_set_epilogue): 1 = row-order stores through LDS where the operands allow (default), 0 = accumulator-order stores
+inline int& gemm_epi_lds() { static int m = 1; return m; }
+
 constexpr int X3_THREADS = 256;     // 4 waves, one per SIMD
 constexpr int X3_SLOTS = 4;         // per-wave LDS ring of A slabs
 
@@ -154,7 +157,7 @@ constexpr int X3_SLOTS = 4;         // per-wave LDS ring of A slabs
 // With one wave per SIMD (MT = 2: 224 accumulator + ~200 other registers) every latency is covered
 // inside the wave's own instruction stream: the in-order vmcnt counter is waited on with the exact number
 // of younger operations (3 per column tile, 2*MT per A slab), never drained.
-template <int NT, int MT, int EPI, bool DUAL>
+template <int NT, int MT, int EPI, bool DUAL, bool LDSEPI>
 __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {   // a and Bp are re-pointed by a grouped launch
   constexpr int WROWS = 32 * MT, GBM = WROWS * (X3_THREADS / 64);
   constexpr int SLOT_CH = WROWS * 4;          // 16-byte chunks per ring slot
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
     arow2[i] = a.A2 + rc * a.K2;
     acol[i] = 4 * ((f & 3) ^ ((f >> 4) & 3));
   }
-  float* ring = smem + wave * (X3_SLOTS * SLOT_CH * 4);
+  float* ring = smem + wave * a.wave_lds_floats;        // wave-private region: the A ring, later the epilogue's strip
   auto fetch_a = [&](int slab) {
     const int k0 = slab * 16;
     float* dst = ring + (slab % X3_SLOTS) * (SLOT_CH * 4);
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void rowgemm_x3_k(GemmArgs a, const 
   for (int m = 0; m < MT; ++m) {
     if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc[m], roww + m * 32, col0, li, lh);
     else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc[m], roww + m * 32, col0, li, lh);
+    else if constexpr (LDSEPI) gemm_epilogue_lds<NT, EPI>(a, acc[m], roww + m * 32, col0, lane, ring);
     else gemm_epilogue<NT, EPI>(a, acc[m], roww + m * 32, col0, li, lh, row0 + GBM <= a.rows);
   }
   if (MRG_X3_DBG & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MRG_X3_STAMP(trace_slot, 3); }
@@ -385,11 +389,19 @@ inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st) {
     if (a.grp.tile0[3] == 0) return MRG_OK;
   }
   dim3 grid((unsigned)(a.grp.n > 0 ? a.grp.tile0[3] : (a.rows + gbm - 1) / gbm), (unsigned)(ntile / nt));
-  const size_t lds = (size_t)(X3_THREADS / 64) * X3_SLOTS * 32 * mt * 64;
+  const size_t ring_floats = (size_t)X3_SLOTS * 32 * mt * 16;
+  a.epi_lds = (gemm_epi_lds() && gemm_epilogue_lds_ok<EPI>(a)) ? 1 : 0;
+  a.wave_lds_floats = (int)((a.epi_lds && gemm_stage_floats(nt) > ring_floats) ? gemm_stage_floats(nt) : ring_floats);
+  const size_t lds = (size_t)(X3_THREADS / 64) * a.wave_lds_floats * sizeof(float);
+#define MRG_GOX3(NTV, MTV, DV, LV)                                                                                    \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3_k<NTV, MTV, EPI, DV, LV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((rowgemm_x3_k<NTV, MTV, EPI, DV, LV>), grid, dim3(X3_THREADS), lds, st, a, (const char*)Bp, ntile); \
+  } while (0)
 #define MRG_GOX2(NTV, MTV, DV)                                                                                        \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3_k<NTV, MTV, EPI, DV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((rowgemm_x3_k<NTV, MTV, EPI, DV>), grid, dim3(X3_THREADS), lds, st, a, (const char*)Bp, ntile); \
+    if constexpr (EPI == EPI_SEGMAX || EPI == EPI_SEGSUM) MRG_GOX3(NTV, MTV, DV, false);                              \
+    else { if (a.epi_lds) MRG_GOX3(NTV, MTV, DV, true); else MRG_GOX3(NTV, MTV, DV, false); }                         \
   } while (0)
 #define MRG_GOX(NTV)                                                                                                  \
   do {                                                                                                                \
@@ -404,6 +416,7 @@ inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st) {
   }
 #undef MRG_GOX
 #undef MRG_GOX2
+#undef MRG_GOX3
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MRG_OK : (int)e;
 }

@@ -725,6 +725,12 @@ extern "C" int mrg_gemm_set_mode(int mode) {
   return MRG_OK;
 }
 
+extern "C" int mrg_gemm_set_epilogue(int row_order) {
+  if (row_order != 0 && row_order != 1) return MRG_E_ENUM;
+  gemm_epi_lds() = row_order;
+  return MRG_OK;
+}
+
 extern "C" int mrg_linear_fwd(const float* X, const float* W, const float* bias, float* Y, void* ws, int64_t rows, int K, int Nout,
                               int act, void* stream) {
   if (rows < 0 || K <= 0 || Nout <= 0) return MRG_E_SHAPE;

@@ -377,7 +377,11 @@ extern "C" int mrg_build_graph(const int64_t* triples, int64_t T, int64_t N, int
                                int64_t* src, int64_t* dst, int64_t* etype, float* norm, int32_t* in_degree, int32_t* src32, int32_t* dst32,
                                int32_t* etype32, int32_t* max_degree, void* ws, int64_t ws_bytes, void* stream) {
   if (T < 0 || N < 0 || R < 0 || table_len < 0) return MRG_E_SHAPE;
-  if (T == 0) return MRG_OK;
+  if (T == 0) {                                   // an empty split still publishes its degree vector: all zeros
+    if (N > 0 && in_degree) MRG_HIP(hipMemsetAsync(in_degree, 0, (size_t)N * 4, (hipStream_t)stream));
+    if (max_degree) MRG_HIP(hipMemsetAsync(max_degree, 0, 4, (hipStream_t)stream));
+    return MRG_OK;
+  }
   if (N == 0) return MRG_E_SHAPE;
   if (!triples || !src || !dst || !etype || !in_degree) return MRG_E_NULLPTR;
   if (sorted && (bits_for((uint64_t)(2 * R)) + 2 * bits_for((uint64_t)(N - 1)) > 64)) return MRG_E_SHAPE;    // the 64-bit sort key does not fit

@@ -123,9 +123,13 @@ extern "C" int mrg_transe_score_fwd(const float* ent, const float* sub, const fl
 extern "C" int mrg_transe_score_bwd(const float* ent, const float* sub, const float* rel, const float* gscore, const float* score, float* gent,
                                     float* gobj, int64_t B, int64_t N, int D, void* stream) {
   if (B < 0 || N < 0 || D <= 0) return MRG_E_SHAPE;
-  if (B == 0 || N == 0) return MRG_OK;
-  if (!ent || !sub || !rel || !gscore || !score) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || N == 0) {                         // an empty batch / entity table: the gradients that do exist are zero
+    if (gent && N > 0 && hipMemsetAsync(gent, 0, (size_t)N * D * 4, st) != hipSuccess) return MRG_E_WORKSPACE;
+    if (gobj && B > 0 && hipMemsetAsync(gobj, 0, (size_t)B * D * 4, st) != hipSuccess) return MRG_E_WORKSPACE;
+    return MRG_OK;
+  }
+  if (!ent || !sub || !rel || !gscore || !score) return MRG_E_NULLPTR;
   if (gobj) {
     dim3 grid((unsigned)((D + TE_C - 1) / TE_C), (unsigned)((B + TE_B - 1) / TE_B));
     hipLaunchKernelGGL(transe_bwd_obj_k, grid, dim3(256), 0, st, ent, sub, rel, gscore, score, gobj, B, N, D);

@@ -17,16 +17,27 @@ edge- or node-shaped is replicated:
   replicated.
 
 Exchange steps (the only collectives):
-  1. per aggregator: all-reduce (sum | max) of the per-node partial accumulators
-     [N, D] built from local edges; each rank keeps its own node rows;
+  1. per middle MixedOp: ONE reduce-scatter (max) of a_max's per-node partial
+     accumulators and ONE reduce-scatter (sum) of [a_sum | a_mean]'s, [N, D] / [N, 2D]
+     built from the local edges, over EQUAL node chunks of ceil(N / P) rows (the
+     tensor is padded by < P rows): every rank receives the reduction of its own
+     node rows only -- half the bytes of an all-reduce.  Launched asynchronously as
+     soon as the partials exist, so the exchange of MixedOp i overlaps the
+     edge-parallel GEMMs of MixedOp i + 1.  Backward = the adjoint all-gather;
   2. per BatchNorm: all-reduce of [2, D] (sum x, sum x^2) forward and of
      (sum g, sum g*xhat) backward -- BN normalises over all M rows
      (reference models/cell_lp.py:21), so shards must share statistics;
-  3. per layer: all-gather of the [N, D] node embeddings (next layer's gather and
-     the scorer read rows of other ranks);
+  3. per layer: all_gather_into_tensor of the [N, D] node embeddings over the same
+     equal chunks (next layer's gather and the scorer read rows of other ranks);
+     backward = reduce-scatter (sum);
   4. per step: one flat all-reduce (sum) of all parameter / alpha gradients.
 Every collective is an autograd Function whose backward is its adjoint collective,
 so ``loss.backward()`` on each rank yields exact partial gradients.
+
+gloo (the CPU tests) has no reduce_scatter_tensor / all_gather_into_tensor: the two
+primitives are emulated there (all-reduce + slice, list all-gather) BELOW the
+equal-chunk padding code, so the CPU tests run the very same chunk arithmetic the
+RCCL path runs (world 2 / 3 / 8, N not divisible by the world size).
 """
 import numpy as np
 import torch
@@ -103,8 +114,33 @@ class EdgeShard(RelGraph):
 # ---------------------------------------------------------------------------
 # collectives with adjoint backward
 # ---------------------------------------------------------------------------
-def _backend_has_reduce_scatter(group):
-    return dist.get_backend(group) != "gloo"          # gloo (the CPU tests) has no reduce_scatter: all-reduce + slice there
+def _is_gloo(group):
+    return dist.get_backend(group) == "gloo"
+
+
+def reduce_scatter_tensor(out, padded, op, group, async_op=False):
+    """dist.reduce_scatter_tensor over equal chunks; on gloo (no such primitive) all-reduce + slice of the SAME padded
+    tensor, so callers run identical chunk arithmetic on both backends.  Returns the async work handle or None."""
+    if not _is_gloo(group):
+        return dist.reduce_scatter_tensor(out, padded, op=op, group=group, async_op=async_op)
+    tmp = padded.clone()
+    dist.all_reduce(tmp, op=op, group=group)
+    chunk, rank = out.shape[0], dist.get_rank(group)
+    out.copy_(tmp[rank * chunk:(rank + 1) * chunk])
+    return None
+
+
+def all_gather_into_tensor(full, mine, group):
+    """dist.all_gather_into_tensor over equal chunks; on gloo the list form into the same output tensor."""
+    if not _is_gloo(group):
+        dist.all_gather_into_tensor(full, mine, group=group)
+        return
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine.contiguous(), group=group)
+    chunk = mine.shape[0]
+    for r, p in enumerate(parts):
+        full[r * chunk:(r + 1) * chunk] = p
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -142,8 +178,8 @@ class Exchange:
 
 class _ReduceScatterRows(torch.autograd.Function):
     """part [N, C] on every rank (partial over the rank's local edges)  ->  own rows [n_own, C] of the reduction over
-    ranks (sum | max).  With RCCL this is ONE reduce_scatter_tensor over equal node chunks (half the bytes of the
-    round-1 all-reduce + slice); over gloo (CPU tests) all-reduce + slice.  Backward = the adjoint: an all-gather of the
+    ranks (sum | max): ONE reduce_scatter_tensor over equal node chunks (half the bytes of the round-1 all-reduce +
+    slice; emulated below the padding code on gloo).  Backward = the adjoint: an all-gather of the
     owners' gradient rows (max: only the ranks that attain the maximum keep it -- ties only occur at 0 behind a ReLU,
     where the ReLU mask removes the gradient anyway)."""
 
@@ -154,21 +190,16 @@ class _ReduceScatterRows(torch.autograd.Function):
         N, C = part.shape
         red = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM
         ctx.info, ctx.op, ctx.group = shard_info, op, group
-        if _backend_has_reduce_scatter(group):
-            if chunk * world != N:                                   # pad to equal chunks (a few rows at most)
-                padded = part.new_zeros(chunk * world, C) if op != "max" else part.new_full((chunk * world, C), float("-inf"))
-                padded[:N] = part
-            else:
-                padded = part
-            out = part.new_empty(chunk, C)
-            work = dist.reduce_scatter_tensor(out, padded, op=red, group=group, async_op=ex is not None)
-            if ex is not None:
-                ex.work = work
-            own = out[: cuts[rank + 1] - cuts[rank]]
+        if chunk * world != N:                                       # pad to equal chunks (fewer than `world` rows)
+            padded = part.new_zeros(chunk * world, C) if op != "max" else part.new_full((chunk * world, C), float("-inf"))
+            padded[:N] = part
         else:
-            full = part.clone()
-            dist.all_reduce(full, op=red, group=group)
-            own = full[cuts[rank]: cuts[rank + 1]]
+            padded = part
+        out = part.new_empty(chunk, C)
+        work = reduce_scatter_tensor(out, padded, red, group, async_op=ex is not None)
+        if ex is not None:
+            ex.work = work
+        own = out[: cuts[rank + 1] - cuts[rank]]
         if op == "max":
             ctx.save_for_backward(part, own)
         return own
@@ -187,15 +218,10 @@ class _ReduceScatterRows(torch.autograd.Function):
         else:
             payload = g
         W = payload.shape[1]
-        if _backend_has_reduce_scatter(ctx.group):
-            mine = payload if n_own == chunk else torch.cat((payload, payload.new_zeros(chunk - n_own, W)))
-            full = payload.new_empty(chunk * world, W)
-            dist.all_gather_into_tensor(full, mine.contiguous(), group=ctx.group)
-            full = full[:N]
-        else:
-            full = payload.new_zeros(N, W)
-            full[cuts[rank]: cuts[rank + 1]] = payload
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=ctx.group)
+        mine = payload if n_own == chunk else torch.cat((payload, payload.new_zeros(chunk - n_own, W)))
+        full = payload.new_empty(chunk * world, W)
+        all_gather_into_tensor(full, mine.contiguous(), ctx.group)
+        full = full[:N]
         if ctx.op == "max":
             return full[:, :C] * (part == full[:, C:]), None, None, None, None
         return full, None, None, None, None
@@ -215,15 +241,9 @@ class _AllGatherRows(torch.autograd.Function):
         world = len(cuts) - 1
         N, D = cuts[-1], x.shape[1]
         ctx.info, ctx.group = shard_info, group
-        if dist.get_backend(group) == "gloo":                       # CPU tests: list form
-            pad = torch.zeros(chunk, D, dtype=x.dtype, device=x.device)
-            pad[: x.shape[0]] = x
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad, group=group)
-            return torch.cat(parts, dim=0)[:N]
         mine = x if x.shape[0] == chunk else torch.cat((x, x.new_zeros(chunk - x.shape[0], D)))
         full = x.new_empty(chunk * world, D)
-        dist.all_gather_into_tensor(full, mine.contiguous(), group=group)
+        all_gather_into_tensor(full, mine.contiguous(), group)
         return full[:N]
 
     @staticmethod
@@ -232,14 +252,10 @@ class _AllGatherRows(torch.autograd.Function):
         world = len(cuts) - 1
         N, D = cuts[-1], g.shape[1]
         n_own = cuts[rank + 1] - cuts[rank]
-        if _backend_has_reduce_scatter(ctx.group):
-            padded = g.contiguous() if chunk * world == N else torch.cat((g, g.new_zeros(chunk * world - N, D)))
-            out = g.new_empty(chunk, D)
-            dist.reduce_scatter_tensor(out, padded, op=dist.ReduceOp.SUM, group=ctx.group)
-            return out[:n_own], None, None
-        g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g[cuts[rank]: cuts[rank + 1]], None, None
+        padded = g.contiguous() if chunk * world == N else torch.cat((g, g.new_zeros(chunk * world - N, D)))
+        out = g.new_empty(chunk, D)
+        reduce_scatter_tensor(out, padded, dist.ReduceOp.SUM, ctx.group)
+        return out[:n_own], None, None
 
 
 class _SyncBatchNorm(torch.autograd.Function):

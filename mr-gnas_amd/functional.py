@@ -29,8 +29,15 @@ def same_rows(a, b):
     `src_emb_in`, reference models/cell_lp.py:95-104).  Then W [s ; s_in] = (W[:, :D] + W[:, D:]) s: the
     operators fold the weight halves and run at half the inner dimension; the whole input gradient is returned
     through the first operand."""
-    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
-                      and a.stride() == b.stride() and a.dtype == b.dtype)
+    if a is None or b is None:
+        return False
+    if a is b:
+        return True
+    # aliases fold only when the whole input gradient may leave through the first operand: both need it or neither does
+    # (a detached alias next to a tracked one keeps the untied path, which routes each gradient to its own operand);
+    # empty tensors all share data_ptr 0 and are never aliases of each other
+    return (a.numel() > 0 and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+            and a.dtype == b.dtype and a.requires_grad == b.requires_grad)
 
 
 def _cnt(plan, name):
@@ -875,7 +882,7 @@ class _MixCfg:
 
     def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None):
         self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
-        self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self): folded into its gradient
+        self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self, gated node | None, node): folded into its gradient
 
 
 class _MixedEpilogue(torch.autograd.Function):
@@ -990,6 +997,10 @@ class _MixedEpilogue(torch.autograd.Function):
         call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
                                    f_s, f_gate, f_gs_p, rows, D, st),
              nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold))
+        if rs is not None:
+            for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
+                if rs[k] is not None and gys[k] is not None:
+                    rs[k][5].prescaled_ptr = gys[k].data_ptr()
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
@@ -1007,7 +1018,7 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
         for k, y in enumerate(ys):
             spec = getattr(y, "_mrg_rowscale", None) if y is not None else None
             if spec is not None and y.grad_fn is not None and getattr(y.grad_fn, "prescaled", None) is False:
-                rowscale[k] = spec[:4] + (y.grad_fn if spec[4] else None,)       # gated form: the node holds s / gate and receives gs
+                rowscale[k] = spec[:4] + (y.grad_fn if spec[4] else None, y.grad_fn)   # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node
                 y.grad_fn.prescaled = True
     cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
@@ -1109,6 +1120,10 @@ class _DenseFilter(torch.autograd.Function):
         M, D = s.shape
         st = stream_of(s)
         prescaled = getattr(ctx, "prescaled", False)       # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already
+        if prescaled and getattr(ctx, "prescaled_ptr", None) != g.data_ptr():
+            # y had a second consumer: autograd summed its (unscaled) gradient into the epilogue's pre-scaled one
+            raise _lib.MrgnasError("dense filter: the folded epilogue gradient was combined with another consumer's gradient; "
+                                   "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
         if prescaled and kind == 0:
             gs = ctx.gs_direct
             gs.record_stream(torch.cuda.current_stream())   # allocated by the epilogue's backward on ITS stream
@@ -1214,6 +1229,9 @@ def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_s
     if s_in is not None and same_rows(s, s_in):
         W_in, W_out, W_self = _FoldHalves.apply(W_in, W_out, W_self)
         s_in = None
+    norm = f32c(norm)        # ONE float32 contiguous [>= b1] vector for the forward, its backward and a folded epilogue gradient
+    if norm is not None and norm.numel() < int(b1):
+        raise _lib.MrgnasError(f"dense filter: edge norm has {norm.numel()} entries, the edge rows need {int(b1)}")
     y = _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
                            W_in, b_in, W_out, b_out, W_self, b_self)
     if FOLD_ROW_SCALE and y.grad_fn is not None and y.is_cuda:

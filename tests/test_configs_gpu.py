@@ -109,26 +109,37 @@ def supernet_case(ds, D, negative):
                 samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref)
 
 
+# full-size gradient bound relative to a tensor's largest entry (f32 step against the float64 oracle over 5.6e5 rows).  The
+# measured margins of every tensor are written to gpurun_out/parity_margins.json (kept: profiles/r3_parity_margins.json).
+GRAD_RTOL = 2e-3
+
+
 def check_step(hip, ref, what):
+    from conftest import record_margin
     assert np.isfinite(hip["loss"])
+    for nm in ("ent", "rel"):
+        record_margin(what, "output " + nm, rel_err(hip[nm], ref[nm]), 1.0, 1e-4)
+    record_margin(what, "loss", abs(hip["loss"] - ref["loss"]), max(1.0, abs(ref["loss"])), 1e-4 * max(1.0, abs(ref["loss"])))
     assert rel_err(hip["ent"], ref["ent"]) <= 1e-4, f"{what}: ent {rel_err(hip['ent'], ref['ent']):.3e}"
     assert rel_err(hip["rel"], ref["rel"]) <= 1e-4, f"{what}: rel"
     assert abs(hip["loss"] - ref["loss"]) <= 1e-4 * max(1.0, abs(ref["loss"])), f"{what}: loss {hip['loss']} vs {ref['loss']}"
     for i, (a, b) in enumerate(zip(hip["ga"], ref["ga"])):
         err, scale = grad_err(a, b)
-        assert err <= 2e-3 * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i}: {err:.3e} (scale {scale:.3e})"
+        record_margin(what, f"alpha grad {i}", err, scale, GRAD_RTOL * max(scale, 1e-8) + 1e-7)
+        assert err <= GRAD_RTOL * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i}: {err:.3e} (scale {scale:.3e})"
     bad, table = [], []
     for k, b in ref["g"].items():
         err, scale = grad_err(hip["g"][k], b)
         table.append((err / max(scale, 1e-6), err, scale, k))
-        tol = 2e-3 * max(scale, 1e-6) + 5e-6
+        tol = GRAD_RTOL * max(scale, 1e-6) + 5e-6
+        d = (hip["g"][k].double() - b.double()).abs()
+        record_margin(what, k, err, scale, tol, float((d > tol).double().mean()))
         if err <= tol:
             continue
         # A float32 and a float64 run can disagree on the sign of a BatchNorm output that is ~0, which flips one ReLU
         # mask bit: a hub row's whole upstream gradient then enters or leaves ONE entry of dbeta (measured: one
         # entry of one [200] bias off by 6e-3 of the tensor's max, identically in the plain and the sharded run).
         # Such isolated entries are tolerated: <= 0.5 % of a tensor's entries, each <= 2e-2 of the tensor's max.
-        d = (hip["g"][k].double() - b.double()).abs()
         outliers = float((d > tol).double().mean())
         if not (outliers <= 0.005 and err <= 2e-2 * max(scale, 1e-6)):
             bad.append(f"{k}: {err:.3e} (scale {scale:.3e}, {outliers:.2%} of entries beyond tolerance)")

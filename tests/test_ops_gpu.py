@@ -391,7 +391,8 @@ def test_span_sum_with_few_long_segments(E, nseg, D):
     assert torch.equal(out, K.span_gcs("copy", X.to(DEV), None, meta, plan))
 
 
-@pytest.mark.parametrize("N,E,R,D,hub", [(3000, 70000, 11, 200, False), (500, 90000, 7, 64, True), (4000, 20000, 5, 128, False), (64, 300, 3, 52, True)])
+@pytest.mark.parametrize("N,E,R,D,hub", [(3000, 70000, 11, 200, False), (500, 90000, 7, 64, True), (4000, 20000, 5, 128, False), (64, 300, 3, 52, True),
+                                         (700, 30000, 5, 96, False), (900, 25000, 5, 192, True)])
 def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
     """a_max as one GEMM with the ReLU + segmented-max epilogue (mrg_linear_relu_segmax_fwd) against linear -> ReLU ->
     segmented max as separate launches: outputs, argmax routing (ties included: half of the ReLU outputs are exact zeros) and
@@ -488,7 +489,10 @@ def test_fused_statistics_to_coefficients_is_bit_exact(rows, D, K_):
 
 
 @pytest.mark.parametrize("N,E,R,D,hub", [(3000, 70000, 11, 200, False), (500, 90000, 7, 64, True), (4000, 20000, 5, 128, False), (64, 300, 3, 52, True),
-                                         (40, 33, 2, 100, False)])
+                                         (40, 33, 2, 100, False),
+                                         # column-tile counts that gemm_pick_nt pads (3 -> 4, 5 / 6 -> 7): the padding tile has no ReLU-mask
+                                         # word (advisor r2: a stray store zeroed the next edge row's word 0)
+                                         (700, 30000, 5, 96, False), (700, 30000, 5, 160, True), (900, 25000, 5, 192, False), (300, 9000, 3, 68, False)])
 def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
     """a_mean as GEMM with the run-sum epilogue + heads reducer + bit-mask backward (no [E, D] messages) against linear ->
     ReLU -> span reducer: outputs and gradients within float summation-order tolerance (the association differs), the ReLU
@@ -525,5 +529,57 @@ def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
     # exact mask: rows whose message is dead in every column get a zero input gradient in both forms, and vice versa
     dead_f, dead_u = (res[True][1][:E] == 0), (res[False][1][:E] == 0)
     assert torch.equal(dead_f.all(1), dead_u.all(1))
+    # ... and per 32-column block of the mask words: the bias gradient sums gy * mask over all edges, so a zeroed word shows
+    gy_f = (res[True][3] - res[False][3]).abs().max()
+    assert float(gy_f) <= 2e-5 * max(1.0, float(res[False][3].abs().max()))
     ref = OO.a_mean(OGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32)), {"linear.weight": W0, "linear.bias": b0}, x0, None)
     close(res[True][0], ref, "fused a_mean vs oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 0, 200), (66000, 200, 200, 200), (513, 64, 0, 40), (259, 400, 0, 8), (65537, 128, 0, 452),
+                                             (300001, 128, 0, 128), (33, 200, 0, 200), (20000, 96, 0, 96), (9000, 52, 0, 300), (131073, 256, 0, 256)])
+def test_row_order_epilogue_is_bit_exact(rows, K1, K2, Nout):
+    """The split-core row GEMM's elementwise epilogues with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1),
+    the default) against the accumulator-order 4-byte stores: bias / ReLU / sigmoid, gate (+ stored gate), row scale,
+    accumulate -- bit-identical outputs; ragged last strips, partial last column tiles, two column blocks, both row-tile
+    shapes, dual-source K."""
+    from mr_gnas_amd._lib import call, ptr, stream_of
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + Nout + K2)
+    s = (torch.randn(rows, K1, generator=gen) * 2).to(DEV)
+    s_in = torch.randn(rows, K2, generator=gen).to(DEV) if K2 else None
+    K_ = K1 + K2
+    W = (torch.randn(Nout, K_, generator=gen) / K_ ** 0.5).to(DEV)
+    b = torch.randn(Nout, generator=gen).to(DEV)
+    norm = (torch.rand(rows, generator=gen) + 0.1).to(DEV)
+    gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+    base = torch.randn(rows, K1, generator=gen).to(DEV)
+    res = {}
+    try:
+        for order in (1, 0):
+            assert lib.mrg_gemm_set_epilogue(order) == 0
+            outs = []
+            if K2 == 0:
+                for act in (None, "relu", "sigmoid"):
+                    outs.append(K.linear(s, W, b, act))
+                # input gradient, plain and accumulating (gX += gY W)
+                for acc in (0, 1):
+                    gx = base.clone()
+                    ws = torch.empty(max(16, int(lib.mrg_linear_bwd_input_workspace_bytes(K1, Nout))), dtype=torch.uint8, device=DEV)
+                    call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(ws), rows, K1, Nout, K1, acc, stream_of(gx)))
+                    outs.append(gx)
+            if Nout == K1:                                   # dense filters: gate (kind 0, stores the gate) and scale (kind 1)
+                for kind in (0, 1):
+                    out = torch.empty(rows, Nout, device=DEV)
+                    gate = torch.empty(rows, Nout, device=DEV) if kind == 0 else None
+                    ws = torch.empty(max(16, int(lib.mrg_gemm_workspace_bytes(K_, Nout))), dtype=torch.uint8, device=DEV)
+                    call("mrg_dense_filter_fwd", (kind, ptr(s), ptr(s_in), ptr(W), ptr(b), ptr(norm), 1.0 / 3.0, ptr(out), ptr(gate), ptr(ws),
+                                                  rows, K1, stream_of(out)))
+                    outs += [out] + ([gate] if gate is not None else [])
+            res[order] = outs
+    finally:
+        lib.mrg_gemm_set_epilogue(1)
+    assert len(res[1]) == len(res[0]) and len(res[1]) > 0
+    for i, (x, y) in enumerate(zip(res[1], res[0])):
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))

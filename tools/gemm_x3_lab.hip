@@ -47,7 +47,36 @@ int main(int argc, char** argv) {
     printf("%-28s %8.3f ms  %7.1f TF/s (f32-equivalent)  err=%s\n", name, ms, 2.0 * rows * K * N / ms * 1e-9, hipGetErrorString(hipGetLastError()));
   };
   timeit("x3 (split + gemm)", [&] { launch_bsplit(B, K, 1, N, K, nt, Bp, 0); launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
-  timeit("x3 (gemm only)", [&] { launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  gemm_epi_lds() = 0;
+  timeit("x3 (gemm only, acc-order stores)", [&] { launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  std::vector<float> c0(rows * N);
+  hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
+  hipMemset(C, 0, rows * N * 4);
+  gemm_epi_lds() = 1;
+  timeit("x3 (gemm only, row-order stores)", [&] { launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0); });
+  {
+    std::vector<float> cx(rows * N);
+    hipMemcpy(cx.data(), C, cx.size() * 4, hipMemcpyDeviceToHost);
+    int64_t bad = 0;
+    for (size_t i = 0; i < cx.size(); ++i) bad += (cx[i] != c0[i]);
+    printf("row-order vs acc-order stores: %lld of %lld outputs differ\n", (long long)bad, (long long)cx.size());
+  }
+  {   // accumulate epilogue (C += ...) both ways
+    GemmArgs g = a; g.Cin = C2; g.ld_cin = N; g.bias = nullptr;
+    hipMemset(C2, 0, rows * N * 4);
+    gemm_epi_lds() = 0;
+    timeit("x3 accumulate, acc-order", [&] { launch_rowgemm_x3<EPI_ACCUM>(g, Bp, 0); });
+    gemm_epi_lds() = 1;
+    timeit("x3 accumulate, row-order", [&] { launch_rowgemm_x3<EPI_ACCUM>(g, Bp, 0); });
+    GemmArgs q = a; q.S = A1; q.ld_s = K1; q.aux = C2; q.scale = 1.f / 3; 
+    if (K1 == N) {
+      gemm_epi_lds() = 0;
+      timeit("x3 gate (+aux), acc-order", [&] { launch_rowgemm_x3<EPI_GATE>(q, Bp, 0); });
+      gemm_epi_lds() = 1;
+      timeit("x3 gate (+aux), row-order", [&] { launch_rowgemm_x3<EPI_GATE>(q, Bp, 0); });
+    }
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);      // C as the error check below expects it
+  }
   if (x3p_eligible(a)) {
     hipMemset(C, 0, rows * N * 4);
     timeit("x3 persistent (gemm only)", [&] { launch_rowgemm_x3p<EPI_BIAS_ACT>(a, Bp, 0); });
