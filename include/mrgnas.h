@@ -63,6 +63,12 @@ extern "C" {
 #define MRG_ACT_SIGMOID  2   /* the [B, N] score functions: sigmoid((sub * rel) all_ent^T) */
 
 int mrg_abi_version(void);
+/* Upper bound of the grid of the FLAT HBM-streaming kernels (compose, K-way sums, the MixedOp combine / statistics /
+ * gradient-reduction passes; 256-thread blocks that walk the tensors with a grid stride).  Default 512: the fastest streaming
+ * grid on MI355X (tools/stream_lab.hip: 5.9 TB/s, 2048 blocks 5.3).  64 <= blocks <= 4096 (the MixedOp reductions use at most
+ * 1024).  The row-per-wave kernels (gates, gathers, reducers) are not affected.  Process-wide; a tuning knob, results do not
+ * depend on it except for the summation order of the column reductions. */
+int mrg_set_stream_blocks(int blocks);
 const char *mrg_error_string(int code);
 /* Name of the code object's target, e.g. "gfx950". */
 const char *mrg_target_arch(void);
@@ -280,10 +286,11 @@ int64_t mrg_gemm_workspace_bytes(int K, int Nout);
  * or equal alone, not faster inside the multi-stream step.  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 /* Store order of the split-core row GEMM's elementwise epilogues (bias / activation, gate, scale, accumulate):
- * 1 (default): a 32-row strip of results goes through wave-private LDS and leaves as row-order 16-byte stores
- * (1 KB of consecutive addresses per store instruction; the gate multiplicand / accumulate input are read the same way)
- * whenever N % 4 == 0 and the rows of every [rows, N] operand are 16-byte aligned; 0: accumulator-order 4-byte stores
- * (the comparison point; bit-identical results).  Process-wide. */
+ * 0 (default): accumulator-order 4-byte stores; 1: a 32-row strip of results goes through wave-private LDS and leaves as
+ * row-order 16-byte stores (1 KB of consecutive addresses per store instruction; the gate multiplicand / accumulate input are
+ * read the same way) whenever N % 4 == 0 and the rows of every [rows, N] operand are 16-byte aligned.  Bit-identical results;
+ * measured slower for the plain epilogue and in the whole step, kept as a tested comparison point.
+ * Process-wide. */
 int mrg_gemm_set_epilogue(int row_order);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);

@@ -30,6 +30,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> (restype, argtypes); must list every function declared in include/mrgnas.h
 SIGNATURES = {
     "mrg_abi_version": (_I, []),
+    "mrg_set_stream_blocks": (_I, [_I]),
     "mrg_error_string": (ctypes.c_char_p, [_I]),
     "mrg_target_arch": (ctypes.c_char_p, []),
     "mrg_compose_fwd": (_I, [_I, _P, _P, _P, _L, _I, _P]),
@@ -122,6 +123,11 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.mrg_abi_version() != ABI_VERSION:
         raise MrgnasLibraryError(f"ABI version {lib.mrg_abi_version()} != expected {ABI_VERSION}; rebuild the library")
+    if os.environ.get("MRG_STREAM_BLOCKS"):          # lab: grid bound of the streaming kernels (mrg_set_stream_blocks)
+        if lib.mrg_set_stream_blocks(int(os.environ["MRG_STREAM_BLOCKS"])) != 0:
+            raise MrgnasLibraryError("MRG_STREAM_BLOCKS must be 64..4096")
+    if os.environ.get("MRG_GEMM_EPILOGUE"):          # lab: 0 = accumulator-order stores of the row GEMM (mrg_gemm_set_epilogue)
+        lib.mrg_gemm_set_epilogue(int(os.environ["MRG_GEMM_EPILOGUE"]))
     _lib = lib
     return lib
 

@@ -36,7 +36,7 @@ template <bool ACC>
 static void launch_sum(const SumPack& xs, int K, float* out, int64_t n, bool vec, hipStream_t st) {
   int64_t n4 = vec ? n / 4 : 0;
   if (n4 > 0) {
-    int grid = grid_for(n4, MRG_BLOCK * 2);
+    int grid = stream_grid_for(n4, MRG_BLOCK * 2);
     switch (K) {
 #define CASE(KK) case KK: hipLaunchKernelGGL((sum_k<KK, ACC>), dim3(grid), dim3(MRG_BLOCK), 0, st, xs, out, n4); break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)

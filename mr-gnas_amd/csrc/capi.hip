@@ -3,6 +3,13 @@
 
 extern "C" int mrg_abi_version(void) { return MRG_ABI_VERSION; }
 
+// lab / tuning knob: upper bound of the grid of the HBM-streaming kernels (common.hpp: stream_grid_for), 64..4096 blocks
+extern "C" int mrg_set_stream_blocks(int blocks) {
+  if (blocks < 64 || blocks > 4096) return MRG_E_SHAPE;
+  mrg::stream_blocks() = blocks;
+  return MRG_OK;
+}
+
 extern "C" const char* mrg_target_arch(void) { return "gfx950"; }
 
 extern "C" const char* mrg_error_string(int code) {

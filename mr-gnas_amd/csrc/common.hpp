@@ -160,6 +160,22 @@ inline void launch_ordered_reduce_ranges(const T* ws, T* out, const int* bounds,
   hipLaunchKernelGGL((ordered_reduce_k<T>), dim3((len + 63) / 64, n_ranges), dim3(1024), 0, st, ws, out, bs, out_stride, ld, len);
 }
 
+// Grid of the FLAT HBM-streaming kernels (compose, K-way sums, the MixedOp combine / statistics / gradient-reduction passes:
+// every lane walks consecutive float4 with a grid stride and nothing depends on a gathered index).
+// Measured on MI355X (tools/stream_lab.hip, 2 reads + 1 write over [558 771, 200] floats): 512 blocks of 256 threads, one
+// float4 per lane in flight, stream at 5.9 TB/s; 1024 blocks 5.6, 2048 blocks 5.3, and MORE loads in flight per lane are
+// slower still (U = 4: 4.7-5.1) -- fewer concurrent address windows per tensor keep more of each DRAM page's bursts together.
+// In the supernet step (profiles/r3_stream_grid.txt): mrg_sum_buffers 4.90 -> 4.50 ms, mrg_mix_fwd 3.72 -> 3.47, statistics
+// 3.10 -> 2.95.  The row-per-wave kernels (gates, gathers, reducers' backward, mrg_mix_bwd_apply with its up to 14 address
+// streams) are latency-bound per wave and LOSE with fewer blocks (gate_fwd 1.4 -> 3.1 ms at 512): they keep grid_for.
+inline int& stream_blocks() { static int b = 512; return b; }
+inline int stream_grid_for(int64_t work_items, int items_per_block) {
+  int64_t b = (work_items + items_per_block - 1) / items_per_block;
+  if (b < 1) b = 1;
+  if (b > stream_blocks()) b = stream_blocks();
+  return (int)b;
+}
+
 inline int grid_for(int64_t work_items, int items_per_block) {
   int64_t b = (work_items + items_per_block - 1) / items_per_block;
   if (b < 1) b = 1;

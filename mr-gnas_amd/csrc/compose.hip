@@ -96,7 +96,7 @@ extern "C" int mrg_compose_fwd(int op, const float* s, const float* hr, float* o
   hipStream_t st = (hipStream_t)stream;
   bool v4 = (n % 4 == 0) && aligned16(s) && aligned16(hr) && aligned16(out);
   int64_t nv = v4 ? n / 4 : n;
-  int grid = grid_for(nv, MRG_BLOCK * 4);
+  int grid = stream_grid_for(nv, MRG_BLOCK * 4);
 #define GO(V, O) hipLaunchKernelGGL((compose_fwd_k<V, O>), dim3(grid), dim3(MRG_BLOCK), 0, st, s, hr, out, nv)
   if (v4) { if (op == 0) GO(4, 0); else if (op == 1) GO(4, 1); else GO(4, 2); }
   else    { if (op == 0) GO(1, 0); else if (op == 1) GO(1, 1); else GO(1, 2); }
@@ -116,7 +116,7 @@ extern "C" int mrg_compose_bwd(int op, const float* gout, const float* s, const 
   hipStream_t st = (hipStream_t)stream;
   bool v4 = (n % 4 == 0) && aligned16(gout) && aligned16(s) && aligned16(hr) && aligned16(gs) && aligned16(ghr);
   int64_t nv = v4 ? n / 4 : n;
-  int grid = grid_for(nv, MRG_BLOCK * 4);
+  int grid = stream_grid_for(nv, MRG_BLOCK * 4);
 #define GO(V, O) hipLaunchKernelGGL((compose_bwd_k<V, O>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, s, hr, gs, ghr, nv)
   if (v4) { if (op == 0) GO(4, 0); else if (op == 1) GO(4, 1); else GO(4, 2); }
   else    { if (op == 0) GO(1, 0); else if (op == 1) GO(1, 1); else GO(1, 2); }
@@ -137,7 +137,7 @@ extern "C" int mrg_gather_compose_fwd(int op, const float* ent, const float* rel
   hipStream_t st = (hipStream_t)stream;
 #define CALL(V, L, K)                                                                                         \
   do {                                                                                                        \
-    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                           \
+    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                 \
     if (op == -1) hipLaunchKernelGGL((gather_compose_k<V, L, K, -1>), dim3(grid), dim3(MRG_BLOCK), 0, st, ent, rel, ent_idx, rel_idx, out, rows, D); \
     else if (op == 0) hipLaunchKernelGGL((gather_compose_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, ent, rel, ent_idx, rel_idx, out, rows, D); \
     else if (op == 1) hipLaunchKernelGGL((gather_compose_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, ent, rel, ent_idx, rel_idx, out, rows, D); \

@@ -153,7 +153,7 @@ static int dense_dz_launch(int kind, const float* g, const float* s, const float
   if (!gm.ok) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                                \
   do {                                                                                                                \
-    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                   \
+    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                         \
     if (kind == 0) hipLaunchKernelGGL((dense_dz_k<V, L, KM, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, g, s, gate, rowscale, scale, dz, gs, rows, D, edge_rows, scale_self); \
     else hipLaunchKernelGGL((dense_dz_k<V, L, KM, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, g, s, gate, rowscale, scale, dz, gs, rows, D, edge_rows, scale_self); \
   } while (0)

@@ -406,7 +406,7 @@ extern "C" int mrg_gate_fwd(const float* s, const float* s_in, const float* norm
   int grid = 1;
 #define CALL(V, L, K)                                                                                                   \
   do {                                                                                                                  \
-    grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                            \
+    grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                                   \
     if (grid < 3) grid = 3;                                                                                             \
     SegPlan p = make_plan(b0, b1, M, grid);                                                                             \
     if (s_in) hipLaunchKernelGGL((gate_fwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
@@ -438,7 +438,7 @@ extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in
   SegPlan p{};
 #define CALL(V, L, K)                                                                                                   \
   do {                                                                                                                  \
-    int grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                        \
+    int grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                               \
     if (grid < 3) grid = 3;                                                                                             \
     p = make_plan(b0, b1, M, grid);                                                                                     \
     if (M > 0) {                                                                                                        \

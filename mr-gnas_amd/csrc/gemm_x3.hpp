@@ -141,8 +141,12 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef MRG_VM
 }
 
-// lab switch (mrg_gemm_set_epilogue): 1 = row-order stores through LDS where the operands allow (default), 0 = accumulator-order stores
-inline int& gemm_epi_lds() { static int m = 1; return m; }
+// mrg_gemm_set_epilogue: 1 = row-order 16-byte stores through LDS where the operands allow, 0 (default) = accumulator-order stores.
+// Round 3 measured the store tail NOT to be bound by the number of store instructions: with 4.5x fewer (25 instead of 112 per
+// strip) the plain epilogue is 9 % slower alone (0.249 vs 0.228 ms at rows 272 115, K = N = 200; the LDS round trip is pure
+// overhead), the accumulate epilogue 5-8 % faster (its input is read in row order too), the gate epilogue equal; in the supernet
+// step the row GEMM entry points lose 0.9 ms / step in total (profiles/r3_rowgemm_epilogue.txt).  Kept as a tested option.
+inline int& gemm_epi_lds() { static int m = 0; return m; }
 
 constexpr int X3_THREADS = 256;     // 4 waves, one per SIMD
 constexpr int X3_SLOTS = 4;         // per-wave LDS ring of A slabs

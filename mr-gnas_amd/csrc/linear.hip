@@ -689,7 +689,7 @@ extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const 
     if (rc != MRG_OK) return rc;
   }
   const int64_t total = N * (int64_t)Nout;
-  hipLaunchKernelGGL(segmax_finalize_k, dim3(grid_for(total, 256 * 4)), dim3(256), 0, st, keys, self_rows, eid, out, arg, mx, total);
+  hipLaunchKernelGGL(segmax_finalize_k, dim3(stream_grid_for(total, 256 * 4)), dim3(256), 0, st, keys, self_rows, eid, out, arg, mx, total);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
 }
 
 static int mix_grid(int64_t rows, int lpr) {
-  int g = grid_for(rows, (MRG_BLOCK / lpr) * 8);
+  int g = stream_grid_for(rows, (MRG_BLOCK / lpr) * 8);
   return g > 1024 ? 1024 : g;                      // partial buffers are sized for 1024 blocks
 }
 
@@ -501,7 +501,7 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   size_t lds = (size_t)K * 2 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
-  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend)
+  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();

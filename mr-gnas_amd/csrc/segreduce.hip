@@ -245,7 +245,7 @@ static int seg_reduce_bwd_impl(int mode, const float* gout, const int32_t* dst, 
   if (!g.ok) return MRG_E_SHAPE;
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
-    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                    \
+    int grid = grid_for(rows, (MRG_BLOCK / L) * 4);                                                                           \
     if (mode == MRG_REDUCE_SUM) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 0>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
     else if (mode == MRG_REDUCE_MEAN) hipLaunchKernelGGL((seg_bwd_k<V, L, K, 1>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
     else hipLaunchKernelGGL((seg_bwd_k<V, L, K, 2>), dim3(grid), dim3(MRG_BLOCK), 0, st, gout, dst, in_degree, arg, gmsg, gself, relu_src, E, rows, D, relu_bits); \
