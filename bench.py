@@ -191,7 +191,7 @@ def kernel_table(stats):
             continue
         sec = r["ms"] / 1e3
         if name in MFMA_BOUND:
-            peak = MFMA_SPLIT_PEAK_TFS if MATRIX_CORE["mode"] == 0 else MFMA_F32_PEAK_TFS
+            peak = MFMA_F32_PEAK_TFS if MATRIX_CORE["mode"] == 1 else MFMA_SPLIT_PEAK_TFS
             ach, unit, bound = r["flops"] / sec / 1e12, "TFLOP/s", "mfma"
         elif name in L2_BOUND:
             ach, peak, unit, bound = r["bytes"] / sec / 1e9, L2_PEAK_GBS, "GB/s", "l2"
@@ -371,7 +371,7 @@ def main():
     global _lib
     from mr_gnas_amd import _lib
     lib = _lib.load()
-    MATRIX_CORE["mode"] = 1 if args.exact_f32 else int(os.environ.get("MRG_GEMM_MODE", "0"))    # lab: 3 / 4 = the opt-in split-core kernels
+    MATRIX_CORE["mode"] = 1 if args.exact_f32 else int(os.environ.get("MRG_GEMM_MODE", "0"))    # lab: 2 / 3 / 4 = the opt-in split-core kernels
     if lib.mrg_gemm_set_mode(MATRIX_CORE["mode"]) != 0:
         raise SystemExit("mrg_gemm_set_mode failed")
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 7   /* 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 7   /* 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -280,10 +280,11 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  *     mrg_gemm_set_mode(1).
  * ws: NULL, or mrg_gemm_workspace_bytes(K, Nout) bytes of device memory private to this call. */
 int64_t mrg_gemm_workspace_bytes(int K, int Nout);
-/* 0 (default): split core where possible; 1: exact-f32 core only; 3: split core on the persistent
- * transposed-accumulator kernel; 4: split core on the two-waves-per-SIMD kernel (64 rows x 4 / 3 column tiles per wave)
- * for >= 65 536 rows, more than 128 output columns and a plain epilogue.  3 and 4 are tested comparison points: faster
- * or equal alone, not faster inside the multi-stream step.  Process-wide. */
+/* 0 (default): split core where possible, on the kernel that shares the pre-split weight slabs of a 128-row workgroup through
+ * LDS (two workgroups per CU); 1: exact-f32 core only; 2: split core on the wave-autonomous one-wave-per-SIMD kernel (the
+ * default of rounds 1-2); 3: split core on the persistent transposed-accumulator kernel; 4: split core on the
+ * two-waves-per-SIMD kernel (64 rows x 4 / 3 column tiles per wave) for >= 65 536 rows, more than 128 output columns and a
+ * plain epilogue.  2, 3 and 4 are tested comparison points with bit-identical results.  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 /* Store order of the split-core row GEMM's elementwise epilogues (bias / activation, gate, scale, accumulate):
  * 0 (default): accumulator-order 4-byte stores; 1: a 32-row strip of results goes through wave-private LDS and leaves as

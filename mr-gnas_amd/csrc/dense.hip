@@ -116,8 +116,8 @@ extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in
   }
   launch_bsplit3(Bs, K, 1, D, K, gemm_pick_nt(D), outs, st);
   MRG_LAUNCH_CHECK();
-  if (kind == 0) return launch_rowgemm_x3<EPI_GATE>(a, outs[0], st);
-  return launch_rowgemm_x3<EPI_SCALE>(a, outs[0], st);
+  if (kind == 0) return launch_rowgemm_x3_mode<EPI_GATE>(a, outs[0], st);
+  return launch_rowgemm_x3_mode<EPI_SCALE>(a, outs[0], st);
 }
 
 // dz (and, for the gated kinds, the direct term of the gradient w.r.t. s):

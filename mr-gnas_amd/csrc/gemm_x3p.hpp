@@ -26,6 +26,7 @@
 #pragma once
 #include "gemm_x3.hpp"
 #include "gemm_x3w.hpp"
+#include "gemm_x3s.hpp"
 
 namespace mrg {
 
@@ -333,7 +334,19 @@ inline int launch_rowgemm_x3p(GemmArgs a, const void* Bp, hipStream_t st) {
 // mode 3: the same arithmetic on the persistent kernel of this file (comparison point);
 // mode 4: the same arithmetic on the two-waves-per-SIMD kernel of gemm_x3w.hpp where it applies (comparison point);
 // mode 1: exact-f32 core only (v_mfma_f32_32x32x2_f32) -- the comparison point of the tests and of bench.py.
+// mode 2: the same arithmetic on the wave-autonomous one-wave-per-SIMD kernel of gemm_x3.hpp (rounds 1-2's default).
+// Since round 3 the default split-core kernel is gemm_x3s.hpp (weight slabs shared through LDS, 128-row workgroups, two per
+// CU): bit-identical results; alone 0.191 vs 0.22-0.23 ms at rows 272 115, K = N = 200 and equal at 558 771 rows, but inside the
+// supernet step every row-GEMM entry point gains 9-22 % (input gradients 10.3 -> 8.4 ms, fused a_max / a_mean 4.1 -> 3.2,
+// dense-filter forward 6.5 -> 5.9; 68.2 -> 65.5 ms / step, profiles/r3_rowgemm_lds_weight.txt).
 inline int& gemm_mode() { static int m = 0; return m; }
+
+// the split-core row GEMM of the current mode for launches that prepared their own weight split (grouped launches, fused aggregators)
+template <int EPI>
+inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
+  if (gemm_mode() != 2 && x3s_eligible(a)) return launch_rowgemm_x3s<EPI>(a, Bp, st);
+  return launch_rowgemm_x3<EPI>(a, Bp, st);
+}
 
 inline size_t gemm_workspace_bytes(int K, int N) {
   const size_t split = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
@@ -364,7 +377,7 @@ inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStre
     if constexpr (EPI != EPI_GATE) {
       if (gemm_mode() == 4 && a.K2 == 0 && x3w_eligible(a)) return launch_rowgemm_x3w<EPI>(a, ws, st);
     }
-    return launch_rowgemm_x3<EPI>(a, ws, st);
+    return launch_rowgemm_x3_mode<EPI>(a, ws, st);
   }
   if (b_sk != 1) {                                   // present B^T row-major to the f32 core
     if (!ws) return MRG_E_WORKSPACE;

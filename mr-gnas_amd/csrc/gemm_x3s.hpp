@@ -1,0 +1,233 @@
+// Split-bf16 row GEMM with the weight operand staged through LDS: 128-row workgroups, two per CU.
+//
+// What rounds 2 and 3 measured on the wave-autonomous kernels (gemm_x3.hpp, gemm_x3w.hpp; profiles/r2_rowgemm_rounds.txt,
+// profiles/r3_rowgemm_epilogue.txt): a wave that keeps the pre-split B fragments of a whole k-slab in registers (84 of them for
+// seven column tiles) next to 224 accumulators owns its SIMD's register file, so a CU runs one workgroup whose prologue,
+// k-loop and store tail never overlap (MFMA busy 36 % of the wave cycles); and every wave streams the whole weight
+// (21 KB per slab) from L2 by itself -- 1.1 MB per 256-row block against 0.2 MB of activations.
+//
+// Here the four waves of a workgroup SHARE the weight slab: it travels L2 -> LDS once per workgroup by LDS-DMA (double
+// buffered, one barrier per slab) and the MFMA operands are read from there (ds_read_b128, conflict free: the pre-split
+// layout is already fragment order), so a wave needs only the fragments of the tile it is multiplying.  A wave owns 32 rows
+// x NT column tiles (NT * 16 accumulators); the activations are read straight into registers in fragment order (two
+// global_load_dwordx4 per slab and lane, two slabs ahead) and split in the shadow of the previous slab's MFMAs.  That is
+// <= 256 registers and 3 * NT * 3 KB of LDS per workgroup (the weight slabs two ahead, the activations three ahead -- a
+// wave's vector-memory operations complete in issue order, so the two depths are coupled): two workgroups share a CU, and
+// while one waits at its barrier, for its first slabs or for its stores, the other multiplies.
+// LDS-DMA addresses its destination through M0[15:0]: everything it writes lies below 64 KiB of the workgroup's LDS
+// (3 x 21 KB here).
+#pragma once
+#include "gemm_x3.hpp"
+
+// lab switches (tools/x3s_dbg_lab.hip, timing only -- wrong results): 1 no epilogue, 2 no A loads after the prologue,
+// 4 no B DMA after the prologue, 8 no barriers.  (A "no splits" switch left asynchronous register fills unconsumed and
+// faulted: every asm load's registers must be read after its wait -- see gemm_x3.hpp.)
+#ifndef MRG_X3S_DBG
+#define MRG_X3S_DBG 0
+#endif
+
+namespace mrg {
+
+template <int NT, int EPI, bool DUAL>
+__global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
+  constexpr int GBM = 128;
+  constexpr int NCH = NT * 3;                   // 1 KB chunks (64 lanes x 16 B) of one pre-split B slab of this column block
+  constexpr int BSLAB = NCH * 1024;
+  constexpr int NBW = (NCH + 3) / 4;            // DMA instructions per wave and slab
+  extern __shared__ __align__(16) char smem_b[];     // [3][BSLAB]: 63 KB for seven column tiles, below the DMA's 64 KiB
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int64_t row0 = (int64_t)blockIdx.x * GBM;
+  int sg = 0;
+  if (a.grp.n > 0) sg = ((int)blockIdx.x >= a.grp.tile0[1] ? 1 : 0) + ((int)blockIdx.x >= a.grp.tile0[2] ? 1 : 0);
+  sg = __builtin_amdgcn_readfirstlane(sg);
+  const char* __restrict__ Bq = Bp + (int64_t)sg * a.grp.bp_stride;
+  if (a.grp.n > 0) {                                     // grouped launch, as in rowgemm_x3_k (constant indices only)
+#define MRG_PICK(F) (sg == 0 ? a.grp.F[0] : (sg == 1 ? a.grp.F[1] : a.grp.F[2]))
+    row0 = MRG_PICK(lo) + (int64_t)((int)blockIdx.x - MRG_PICK(tile0)) * GBM;
+    a.rows = MRG_PICK(hi);
+    a.bias = MRG_PICK(bias);
+    a.scale = MRG_PICK(scale);
+    if (!MRG_PICK(use_rowscale)) a.rowscale = nullptr;
+#undef MRG_PICK
+  }
+  const int64_t roww = row0 + wave * 32;
+  const int col0 = blockIdx.y * (NT * 32);
+  const int K = a.K1 + a.K2;
+  const int nslab = (K + 15) >> 4;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  // ---- A: this lane's fragment of a slab = row li, k = slab * 16 + lh * 8 + {0..3, 4..7}: two 16-byte loads
+  int64_t rc = roww + li < a.rows ? roww + li : a.rows - 1;
+  if (rc < 0) rc = 0;
+  if (a.row_index) rc = a.row_index[rc];                 // gathered rows (EPI_SEGMAX / EPI_SEGSUM: edges in destination order)
+  const float* ar1 = a.A1 + rc * a.K1;
+  const float* ar2 = a.A2 + rc * a.K2;
+  auto a_ptr = [&](int k) -> const float* {
+    if (DUAL) {
+      const bool first = k < a.K1;
+      const int kk = first ? k : k - a.K1, ld = first ? a.K1 : a.K2;
+      return (first ? ar1 : ar2) + (kk + 4 <= ld ? kk : ld - 4);
+    }
+    return ar1 + (k + 4 <= K ? k : K - 4);               // beyond K: any finite values, the weight's rows there are zero
+  };
+  // asynchronous register fills, first read behind the matching counted s_waitcnt (see gemm_x3.hpp)
+  v4f xr[3][2];                                          // raw fragments: a ring of three slabs
+  auto load_a = [&](int slab, v4f (&x)[2]) {
+    const int sl = slab < nslab ? slab : nslab - 1;      // beyond the end: re-read the last slab (an asynchronous fill is never conditional)
+    const int k = sl * 16 + lh * 8;
+    const float* p0 = a_ptr(k);
+    const float* p1 = a_ptr(k + 4);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[0]) : "v"(p0));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[1]) : "v"(p1));
+  };
+  // ---- B: the slab's NCH chunks, NBW per wave (the last wave repeats the last chunk: same bytes to the same place)
+  const char* bcol = Bq + (int64_t)blockIdx.y * NT * 3072;
+  auto fetch_b = [&](int slab, int buf) {
+    const char* src = bcol + (int64_t)slab * ntile * 3072;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      int c = wave * NBW + i;
+      c = c < NCH ? c : NCH - 1;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 1024 + lane * 16), (lds_ptr_t)(smem_b + buf * BSLAB + c * 1024), 16, 0, 0);
+    }
+  };
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_b + (unsigned)lane * 16u;
+  u32x4 bq[2][3];
+  auto read_b = [&](int n, int buf, u32x4 (&q)[3]) {
+    const unsigned ad = lds0 + (unsigned)(buf * BSLAB + n * 3072);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(q[0]) : "v"(ad));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(q[1]) : "v"(ad));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(q[2]) : "v"(ad));
+  };
+  u32x4 ch, cm, cl, nh, nm, nl;
+  auto split_pair_of = [&](const v4f (&x)[2], int q, u32x4& H, u32x4& M, u32x4& L) {     // q = 0..3: floats 2q, 2q + 1 of the 8
+    const v4f& v = x[q >> 1];
+    unsigned h, m, l;
+    if (q & 1) split_pair(v.z, v.w, h, m, l); else split_pair(v.x, v.y, h, m, l);
+    H[q] = h; M[q] = m; L[q] = l;
+  };
+  auto nb_issued = [&](int j) { return (j >= -2 && j + 2 < nslab) ? NBW : 0; };   // B DMAs issued at the top of slab j (j < 0: prologue)
+
+  // ---- prologue, in the steady state's issue order: A(0) | B(0) A(1) | B(1) A(2)
+  load_a(0, xr[0]);
+  fetch_b(0, 0);
+  load_a(1, xr[1]);
+  if (nslab > 1) fetch_b(1, 1);
+  load_a(2, xr[2]);
+  wait_vmcnt(2 + nb_issued(-1) + 2);                         // A(0) and this wave's share of B(0) have landed
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair_of(xr[0], q, ch, cm, cl);
+  __builtin_amdgcn_s_barrier();                              // everybody's share of B(0) is in LDS
+
+  // One k-slab; R = s % 3 at compile time (ring positions of the raw fragments and of the B buffers).
+  // In-order vector-memory history of a wave at the top of slab s:  ... A(s+1) | B(s+1) A(s+2)      (B(s) in LDS: barrier)
+  //   top: issue B(s+2) into buffer (s+2) % 3 -- read last during slab s-1, every wave is past that barrier -- and A(s+3) into
+  //        the raw registers slab s-1 split from;
+  //   the splits need A(s+1): younger = B(s+1) A(s+2) B(s+2) A(s+3);
+  //   end: B(s+1) must be in LDS before the barrier: younger = A(s+2) B(s+2) A(s+3).
+  auto slab = [&](auto r_c, int s) {
+    constexpr int R = decltype(r_c)::value;
+    const bool has_next = s + 1 < nslab;
+    if (s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
+    if (!(MRG_X3S_DBG & 2)) load_a(s + 3, xr[R]);
+    read_b(0, R, bq[0]);
+    if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
+    if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (n + 1 < NT) {
+        read_b(n + 1, R, bq[(n + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");     // the three reads just issued may still be in flight
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next && n < 4) split_pair_of(xr[(R + 1) % 3], n, nh, nm, nl);   // VALU work in the shadow of this tile's MFMAs
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bq[n & 1][0]), Bm = __builtin_bit_cast(bf16x8, bq[n & 1][1]),
+                   Bl = __builtin_bit_cast(bf16x8, bq[n & 1][2]);
+      const bf16x8 Ah = __builtin_bit_cast(bf16x8, ch), Am = __builtin_bit_cast(bf16x8, cm), Al = __builtin_bit_cast(bf16x8, cl);
+      // small terms first, the leading term last (same order as rowgemm_x3_k: bit-identical results)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NT < 4 && has_next) {
+#pragma unroll
+      for (int q = NT; q < 4; ++q) split_pair_of(xr[(R + 1) % 3], q, nh, nm, nl);
+    }
+    if (has_next) {
+      ch = nh; cm = nm; cl = nl;
+      if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2);                       // this wave's share of B(s+1) is in LDS
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();   // ... and everybody's; all reads of this slab's buffer are done
+    }
+  };
+  int s = 0;
+  for (; s + 2 < nslab; s += 3) {
+    slab(std::integral_constant<int, 0>{}, s);
+    slab(std::integral_constant<int, 1>{}, s + 1);
+    slab(std::integral_constant<int, 2>{}, s + 2);
+  }
+  if (s < nslab) { slab(std::integral_constant<int, 0>{}, s); ++s; }
+  if (s < nslab) { slab(std::integral_constant<int, 1>{}, s); ++s; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's unused A fills: their registers must stay until they land
+  asm volatile("" :: "v"(xr[0][0]), "v"(xr[0][1]), "v"(xr[1][0]), "v"(xr[1][1]), "v"(xr[2][0]), "v"(xr[2][1]));
+
+  if ((MRG_X3S_DBG & 1) && acc[0][0] != 123.456f) return;
+  if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc, roww, col0, li, lh);
+  else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc, roww, col0, li, lh);
+  else gemm_epilogue<NT, EPI>(a, acc, roww, col0, li, lh, row0 + GBM <= a.rows);
+}
+
+inline bool x3s_eligible(const GemmArgs& a) { return x3_eligible(a) && a.rows > 0; }
+
+// Bp: the split of B prepared by launch_bsplit(..., nt = gemm_pick_nt(a.N), ...)
+template <int EPI>
+inline int launch_rowgemm_x3s(GemmArgs a, const void* Bp, hipStream_t st) {
+  if (a.rows <= 0) return MRG_OK;
+  if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
+  const int nt = gemm_pick_nt(a.N);
+  const int ntile = x3_tiles(a.N, nt);
+  const int gbm = 128;
+  if (a.grp.n > 0) {
+    a.grp.tile0[0] = 0;
+    for (int i = 0; i < 3; ++i) {
+      const int64_t r = i < a.grp.n && a.grp.hi[i] > a.grp.lo[i] ? a.grp.hi[i] - a.grp.lo[i] : 0;
+      a.grp.tile0[i + 1] = a.grp.tile0[i] + (int)((r + gbm - 1) / gbm);
+    }
+    if (a.grp.tile0[3] == 0) return MRG_OK;
+  }
+  dim3 grid((unsigned)(a.grp.n > 0 ? a.grp.tile0[3] : (a.rows + gbm - 1) / gbm), (unsigned)(ntile / nt));
+  const size_t lds = (size_t)3 * nt * 3 * 1024;
+#define MRG_GOS2(NTV, DV)                                                                                             \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s_k<NTV, EPI, DV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((rowgemm_x3s_k<NTV, EPI, DV>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);           \
+  } while (0)
+#define MRG_GOS(NTV) do { if (a.K2 > 0) MRG_GOS2(NTV, true); else MRG_GOS2(NTV, false); } while (0)
+  switch (nt) {
+    case 1: MRG_GOS(1); break;
+    case 2: MRG_GOS(2); break;
+    case 4: MRG_GOS(4); break;
+    default: MRG_GOS(7); break;
+  }
+#undef MRG_GOS
+#undef MRG_GOS2
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MRG_OK : (int)e;
+}
+
+}  // namespace mrg

@@ -685,7 +685,7 @@ extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const 
     a.row_index = eid; a.row_seg = dst; a.seg_out = keys;
     if (!x3_eligible(a)) return MRG_E_SHAPE;
     launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), bsplit, st);
-    const int rc = launch_rowgemm_x3<EPI_SEGMAX>(a, bsplit, st);
+    const int rc = launch_rowgemm_x3_mode<EPI_SEGMAX>(a, bsplit, st);
     if (rc != MRG_OK) return rc;
   }
   const int64_t total = N * (int64_t)Nout;
@@ -711,7 +711,7 @@ extern "C" int mrg_linear_relu_segsum_fwd(const float* X, const float* W, const 
   a.row_index = eid; a.row_seg = dst; a.seg_part = part; a.relu_bits = relu_bits; a.bits_ld = (Nout + 31) / 32;
   if (!x3_eligible(a)) return MRG_E_SHAPE;
   launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), ws, st);
-  return launch_rowgemm_x3<EPI_SEGSUM>(a, ws, st);
+  return launch_rowgemm_x3_mode<EPI_SEGSUM>(a, ws, st);
 }
 
 extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
@@ -720,7 +720,7 @@ extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
 }
 
 extern "C" int mrg_gemm_set_mode(int mode) {
-  if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return MRG_E_ENUM;
+  if (mode < 0 || mode > 4) return MRG_E_ENUM;
   gemm_mode() = mode;
   return MRG_OK;
 }
@@ -803,8 +803,8 @@ extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host
   }
   launch_bsplit3(Bs, 1, ldw, K, Nout, gemm_pick_nt(K), outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
   MRG_LAUNCH_CHECK();
-  if (accumulate) return launch_rowgemm_x3<EPI_ACCUM>(a, outs[0], st);
-  return launch_rowgemm_x3<EPI_BIAS_ACT>(a, outs[0], st);
+  if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
+  return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);
 }
 
 // gW[s][Nout][K1+K2] = gY[lo_s:hi_s]^T [X1 | X2][lo_s:hi_s], gbias[s] = column sums, for the three row ranges in one launch

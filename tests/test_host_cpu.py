@@ -43,7 +43,7 @@ def test_argument_errors_without_gpu():
     assert lib.mrg_distmult_score(None, None, None, None, None, None, 0, 8, None) == 0
     assert lib.mrg_distmult_score(None, P(16), P(16), P(16), P(16), P(16), 4, 8, None) == -1
     assert lib.mrg_distmult_score(P(16), P(16), P(16), P(16), P(16), P(16), 4, 0, None) == -2
-    assert lib.mrg_gemm_set_mode(7) == -3 and lib.mrg_gemm_set_mode(2) == -3 and lib.mrg_gemm_set_mode(0) == 0
+    assert lib.mrg_gemm_set_mode(7) == -3 and lib.mrg_gemm_set_mode(-1) == -3 and lib.mrg_gemm_set_mode(2) == 0 and lib.mrg_gemm_set_mode(0) == 0
     assert lib.mrg_gemm_workspace_bytes(400, 200) >= 400 * 200 * 4 and lib.mrg_gemm_workspace_bytes(0, 200) == 0
     assert lib.mrg_linear_fwd(P(16), P(16), None, P(16), None, 0, 8, 8, 0, None) == 0  # zero rows
     assert lib.mrg_linear_fwd(None, P(16), None, P(16), None, 4, 8, 8, 0, None) == -1

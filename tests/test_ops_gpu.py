@@ -261,7 +261,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     ref_gx = gy.double() @ W.double()
     errs = {}
     try:
-        for mode in (0, 1, 3, 4):                   # 3: persistent variant, 4: two waves / SIMD where eligible (both opt-in)
+        for mode in (0, 1, 2, 3, 4):                # 2: one-wave kernel, 3: persistent variant, 4: two waves / SIMD where eligible (all opt-in)
             assert lib.mrg_gemm_set_mode(mode) == 0
             if K2 == 0:
                 out = K.linear(x, W, b, None)
@@ -278,7 +278,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     finally:
         lib.mrg_gemm_set_mode(0)
     for i, scale in ((0, float(ref.abs().max())), (1, float(ref_gx.abs().max()))):
-        for mode in (0, 3, 4):
+        for mode in (0, 2, 3, 4):
             assert errs[mode][i] <= 1.5 * errs[1][i] + 1e-6 * scale, (mode, errs, scale)
             assert errs[mode][i] <= 2e-5 * scale
 
@@ -539,11 +539,12 @@ def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 0, 200), (66000, 200, 200, 200), (513, 64, 0, 40), (259, 400, 0, 8), (65537, 128, 0, 452),
                                              (300001, 128, 0, 128), (33, 200, 0, 200), (20000, 96, 0, 96), (9000, 52, 0, 300), (131073, 256, 0, 256)])
-def test_row_order_epilogue_is_bit_exact(rows, K1, K2, Nout):
-    """The split-core row GEMM's elementwise epilogues with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1),
-    the default) against the accumulator-order 4-byte stores: bias / ReLU / sigmoid, gate (+ stored gate), row scale,
-    accumulate -- bit-identical outputs; ragged last strips, partial last column tiles, two column blocks, both row-tile
-    shapes, dual-source K."""
+def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
+    """The three forms of the split-core row GEMM compute the same sums in the same order: the default kernel with the
+    weight slabs shared through LDS (mode 0, gemm_x3s.hpp), the wave-autonomous kernel (mode 2) with accumulator-order
+    stores and with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1)).  Bias / ReLU / sigmoid, gate (+ stored
+    gate), row scale, accumulate -- bit-identical outputs; ragged last strips, partial last column tiles, two column blocks,
+    both row-tile shapes, dual-source K."""
     from mr_gnas_amd._lib import call, ptr, stream_of
     lib = mr_gnas_amd._lib.load()
     gen = torch.Generator().manual_seed(rows + Nout + K2)
@@ -557,8 +558,8 @@ def test_row_order_epilogue_is_bit_exact(rows, K1, K2, Nout):
     base = torch.randn(rows, K1, generator=gen).to(DEV)
     res = {}
     try:
-        for order in (1, 0):
-            assert lib.mrg_gemm_set_epilogue(order) == 0
+        for order in ((0, 0), (2, 0), (2, 1)):
+            assert lib.mrg_gemm_set_mode(order[0]) == 0 and lib.mrg_gemm_set_epilogue(order[1]) == 0
             outs = []
             if K2 == 0:
                 for act in (None, "relu", "sigmoid"):
@@ -579,7 +580,42 @@ def test_row_order_epilogue_is_bit_exact(rows, K1, K2, Nout):
                     outs += [out] + ([gate] if gate is not None else [])
             res[order] = outs
     finally:
-        lib.mrg_gemm_set_epilogue(1)
-    assert len(res[1]) == len(res[0]) and len(res[1]) > 0
-    for i, (x, y) in enumerate(zip(res[1], res[0])):
-        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+        lib.mrg_gemm_set_epilogue(0)
+        lib.mrg_gemm_set_mode(0)
+    assert len(res[(0, 0)]) > 0
+    for other in ((2, 0), (2, 1)):
+        assert len(res[other]) == len(res[(0, 0)])
+        for i, (x, y) in enumerate(zip(res[(0, 0)], res[other])):
+            assert torch.equal(x, y), (other, i, float((x - y).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["max", "mean"])
+def test_fused_aggregators_are_bit_exact_across_split_core_kernels(kind):
+    """Fused a_max / a_mean (GEMM over gathered, destination-ordered edge rows with the segmented epilogue) on the default
+    LDS-weight kernel (gathered rows read straight into registers) against the wave-autonomous kernel (mode 2, gathered rows by
+    LDS-DMA): outputs and every gradient bit-identical."""
+    lib = mr_gnas_amd._lib.load()
+    N, E, R, D = 2500, 120000, 9, 200
+    gen = torch.Generator().manual_seed(77)
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N - 10, (E,), generator=gen)
+    dst[: E // 3] = 5                                               # a hub that spans many strips
+    et = torch.randint(0, R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32), device=DEV)
+    x0 = torch.randn(E + N, D, generator=gen)
+    W0 = torch.randn(D, D, generator=gen) / D ** 0.5
+    b0 = torch.randn(D, generator=gen) * 0.1
+    gout = torch.randn(N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for mode in (0, 2):
+            assert lib.mrg_gemm_set_mode(mode) == 0
+            x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
+            out = K.linear_relu_aggregate(kind, x, W, b, g)
+            out.backward(gout)
+            res[mode] = (out.detach(), x.grad, W.grad, b.grad)
+    finally:
+        lib.mrg_gemm_set_mode(0)
+    for a, b_, what in zip(res[0], res[2], ("out", "gx", "gW", "gb")):
+        assert torch.equal(a, b_), what

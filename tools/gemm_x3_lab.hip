@@ -6,6 +6,7 @@
 #include <vector>
 #include <algorithm>
 #include "gemm_x3p.hpp"
+#include "gemm_x3s.hpp"
 using namespace mrg;
 
 static float frand() { return (float)rand() / RAND_MAX - 0.5f; }
@@ -76,6 +77,25 @@ int main(int argc, char** argv) {
       timeit("x3 gate (+aux), row-order", [&] { launch_rowgemm_x3<EPI_GATE>(q, Bp, 0); });
     }
     launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);      // C as the error check below expects it
+  }
+  {
+    gemm_epi_lds() = 0;
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
+    std::vector<float> cref(rows * N), cs(rows * N);
+    hipMemcpy(cref.data(), C, cref.size() * 4, hipMemcpyDeviceToHost);
+    hipMemset(C, 0, rows * N * 4);
+    timeit("x3s LDS-B, 2 WG/CU (gemm only)", [&] { launch_rowgemm_x3s<EPI_BIAS_ACT>(a, Bp, 0); });
+    hipMemcpy(cs.data(), C, cs.size() * 4, hipMemcpyDeviceToHost);
+    int64_t bad = 0; double worst = 0;
+    for (size_t i = 0; i < cs.size(); ++i) { if (cs[i] != cref[i]) { ++bad; worst = std::max(worst, (double)fabs(cs[i] - cref[i])); } }
+    printf("x3s vs x3: %lld of %lld outputs differ (max |diff| %.3e)\n", (long long)bad, (long long)cs.size(), worst);
+    GemmArgs g = a; g.Cin = C2; g.ld_cin = N; g.bias = nullptr;
+    timeit("x3s accumulate", [&] { launch_rowgemm_x3s<EPI_ACCUM>(g, Bp, 0); });
+    if (K1 == N) {
+      GemmArgs q = a; q.S = A1; q.ld_s = K1; q.aux = C2; q.scale = 1.f / 3;
+      timeit("x3s gate (+aux)", [&] { launch_rowgemm_x3s<EPI_GATE>(q, Bp, 0); });
+    }
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
   }
   if (x3p_eligible(a)) {
     hipMemset(C, 0, rows * N * 4);
