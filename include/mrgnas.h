@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 7   /* 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables); 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -263,6 +263,33 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
                       const float *coef, const float *coef2, const float *w, const float *const *rs, const float *rs_scale,
                       const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *fold_s,
                       const float *const *fold_gate, float *const *fold_gs, int64_t rows, int D, void *stream);
+
+/* ---- Cell zero: the MixedOp over the compose candidates, recomputed from the tables ---------------------------------------------
+ * reference models/cell_lp.py:53-68 (Cell_Zero: ONE MixedOp over PRE_OPS), :25-33 (MixedOp.forward / op_forward),
+ * models/operations_lp.py:71-98 (pre_mult / pre_sub / pre_add) and the gather feeding them, models/model_search_lp.py:135-145:
+ *   out[r] = sum_k w[k] * ReLU(BN_k(ent[ent_idx[r]] (op_k) rel[rel_idx[r]]))          ops: MRG_COMPOSE_*, 1 <= K <= 3
+ * The candidates are elementwise functions of two cache-resident table rows, so no candidate output is ever stored: the
+ * statistics, combine and gradient passes recompute them, and the backward writes the two combined per-row gradients
+ *   g_ent_rows[r] = sum_k gy_k * d y_k / d ent-row,   g_rel_rows[r] = sum_k gy_k * d y_k / d rel-row
+ * which two mrg_span_gcs(COPY) launches turn into the table gradients.  The entry points mirror mrg_mix_colstats /
+ * mrg_mix_stats_coef / mrg_mix_fwd / mrg_mix_bwd_reduce / mrg_mix_bwd_apply (same workspaces, same coef / red / coef2 layouts,
+ * mrg_mix_finalize_fwd / _bwd in between, statistics may be all-reduced when the rows are sharded); coefficients, output and
+ * every gy_k are bit-identical with the stored form.  ops: HOST array of K codes. */
+int mrg_zero_colstats(const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx, const int *ops, int K,
+                      int64_t rows, int D, double *sums, void *ws, void *stream);
+int mrg_zero_stats_coef(const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx, const int *ops, int K,
+                        const float *const *gamma, const float *const *beta, float *const *running_mean,
+                        float *const *running_var, int64_t rows, double total_rows, int D, float eps, float momentum,
+                        float *coef, void *ws, void *stream);
+int mrg_zero_fwd(const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx, const int *ops, int K,
+                 const float *coef, const float *w, float *out, int64_t rows, int D, void *stream);
+int mrg_zero_bwd_reduce(const float *g, const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx,
+                        const int *ops, int K, const float *coef, const float *w, float *red, void *ws, int64_t rows, int D,
+                        void *stream);
+int mrg_zero_bwd_apply(const float *g, const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx,
+                       const int *ops, int K, const float *coef, const float *coef2, const float *w, float *g_ent_rows,
+                       float *g_rel_rows, int64_t rows, int D, void *stream);
+
 
 /* ---- dense linear on edge / node rows (fp32 MFMA) ---------------------------
  * nn.Linear inside a_max_op / a_mean_op (reference models/operations_lp.py:228,231,246)

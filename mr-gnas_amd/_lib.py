@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -56,6 +56,11 @@ SIGNATURES = {
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
     "mrg_mix_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
+    "mrg_zero_colstats": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
+    "mrg_zero_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
+    "mrg_zero_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
+    "mrg_zero_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_zero_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_finalize_bwd": (_I, [_P, _I, ctypes.c_double, _I, _P, _P, _P, _P, _P]),

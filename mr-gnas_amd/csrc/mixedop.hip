@@ -388,6 +388,293 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
   }
 }
 
+
+// =====================================================================================================================
+// Cell zero: the MixedOp over the compose candidates WITHOUT their [rows, D] outputs
+//   out = sum_k w_k * ReLU(BN_k(ent[ei[r]] (op_k) rel[ri[r]])),   op_k in {mult, sub, add}
+//   reference models/cell_lp.py:53-68 (Cell_Zero: one MixedOp over PRE_OPS), :25-33 (MixedOp), models/operations_lp.py:71-98
+//   (pre_*_op) and the gather that feeds them, models/model_search_lp.py:135-145.
+// Every candidate is an elementwise function of two table rows that stay cache resident (11.6 MB of entities, 0.4 MB of
+// relations at FB15k-237), so the statistics / combine / gradient passes RECOMPUTE y_k from the tables instead of reading
+// three stored [rows, D] tensors, and the backward emits the two combined per-row gradients (w.r.t. the entity row and
+// w.r.t. the relation row) for the table gradients' span sums instead of three gy_k that six span sums would read.
+// Per layer (rounds 1-2: 3 gather-compose launches + the generic epilogue on stored candidates): 27 [rows, D] passes -> 6.
+// Same values, same summation order per statistic as the stored form (mix_colstats_k / mix_bwd_reduce_k): the
+// coefficients, the output and every gy_k are bit-identical; only the association of the table gradients differs.
+struct ZeroSrc { const float* ent; const float* rel; const int32_t* ei; const int32_t* ri; int op[4]; int K; };
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> zero_val(int op, const Vec<VEC>& a, const Vec<VEC>& b) {
+  Vec<VEC> y;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) y[j] = op == MRG_COMPOSE_MULT ? a[j] * b[j] : (op == MRG_COMPOSE_SUB ? a[j] - b[j] : a[j] + b[j]);
+  return y;
+}
+
+constexpr int ZK = 3;      // at most three compose candidates
+
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void zero_colstats_k(ZeroSrc z, int64_t rows, int D, double* __restrict__ ws) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  __shared__ double red[RPB * 2 * WIDTH];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int K = z.K;
+  double s1[ZK][KMAX][VEC], s2[ZK][KMAX][VEC];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k)
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s1[k][q][j] = 0.0; s2[k][q][j] = 0.0; }
+  // the same row sequence per lane as mix_colstats_k (r, r + step, ...: four rows per trip, then the remainder): the sums
+  // of a column come out bit-identical with the stored form
+  const int64_t step = (int64_t)gridDim.x * RPB;
+  int64_t r = (int64_t)blockIdx.x * RPB + rw;
+  for (; r + 3 * step < rows; r += 4 * step) {
+    const float* a[4]; const float* b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = z.ent + (int64_t)z.ei[r + u * step] * D; b[u] = z.rel + (int64_t)z.ri[r + u * step] * D; }
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        Vec<VEC> va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { va[u] = Vec<VEC>::load(a[u] + c * VEC); vb[u] = Vec<VEC>::load(b[u] + c * VEC); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < ZK; ++k)
+            if (k < K) {
+              const Vec<VEC> y = zero_val<VEC>(z.op[k], va[u], vb[u]);
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) { double d = (double)y[j]; s1[k][q][j] += d; s2[k][q][j] += d * d; }
+            }
+      }
+    }
+  }
+  for (; r < rows; r += step) {
+    const float* a = z.ent + (int64_t)z.ei[r] * D;
+    const float* b = z.rel + (int64_t)z.ri[r] * D;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        const Vec<VEC> va = Vec<VEC>::load(a + c * VEC), vb = Vec<VEC>::load(b + c * VEC);
+#pragma unroll
+        for (int k = 0; k < ZK; ++k)
+          if (k < K) {
+            const Vec<VEC> y = zero_val<VEC>(z.op[k], va, vb);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { double d = (double)y[j]; s1[k][q][j] += d; s2[k][q][j] += d * d; }
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) {
+    if (k < K) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q) {
+        int c = sl + q * LPR;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          red[(rw * 2 + 0) * WIDTH + c * VEC + j] = s1[k][q][j];
+          red[(rw * 2 + 1) * WIDTH + c * VEC + j] = s2[k][q][j];
+        }
+      }
+      __syncthreads();
+      double* dst = ws + ((int64_t)blockIdx.x * K + k) * 2 * D;
+      for (int t = threadIdx.x; t < 2 * D; t += MRG_BLOCK) {
+        int which = t / D, c = t - which * D;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPB; ++q) acc += red[(q * 2 + which) * WIDTH + c];
+        dst[t] = acc;
+      }
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void zero_fwd_k(ZeroSrc z, const float* __restrict__ coef, const float* __restrict__ w,
+                                                        float* __restrict__ out, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // [K][2][D] scale, shift
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int K = z.K;
+  for (int t = threadIdx.x; t < K * 2 * D; t += MRG_BLOCK) {
+    int k = t / (2 * D), rem = t - k * 2 * D;
+    lds[t] = coef[(int64_t)k * 4 * D + rem];
+  }
+  __syncthreads();
+  float wk[ZK];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const float* a = z.ent + (int64_t)z.ei[r] * D;
+    const float* b = z.rel + (int64_t)z.ri[r] * D;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        const Vec<VEC> va = Vec<VEC>::load(a + c * VEC), vb = Vec<VEC>::load(b + c * VEC);
+        Vec<VEC> acc = Vec<VEC>::fill(0.f);
+#pragma unroll
+        for (int k = 0; k < ZK; ++k) {
+          if (k < K) {
+            const Vec<VEC> v = zero_val<VEC>(z.op[k], va, vb);
+            Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float zz = v[j] * sc[j] + sh[j];
+              acc[j] += wk[k] * (zz > 0.f ? zz : 0.f);
+            }
+          }
+        }
+        acc.store(out + r * D + c * VEC);
+      }
+    }
+  }
+}
+
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_reduce_k(const float* __restrict__ g, ZeroSrc z, const float* __restrict__ coef,
+                                                               const float* __restrict__ w, float* __restrict__ ws, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int K = z.K;
+  float* red = lds + K * 4 * D;                  // [RPB][3][WIDTH]
+  for (int t = threadIdx.x; t < K * 4 * D; t += MRG_BLOCK) lds[t] = coef[t];
+  __syncthreads();
+  float wk[ZK];
+  Vec<VEC> a0[ZK][KMAX], a1[ZK][KMAX], a2[ZK][KMAX];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) {
+    wk[k] = k < K ? w[k] : 0.f;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) { a0[k][q] = Vec<VEC>::fill(0.f); a1[k][q] = Vec<VEC>::fill(0.f); a2[k][q] = Vec<VEC>::fill(0.f); }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const float* a = z.ent + (int64_t)z.ei[r] * D;
+    const float* b = z.rel + (int64_t)z.ri[r] * D;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        const Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+        const Vec<VEC> va = Vec<VEC>::load(a + c * VEC), vb = Vec<VEC>::load(b + c * VEC);
+#pragma unroll
+        for (int k = 0; k < ZK; ++k) {
+          if (k < K) {
+            const Vec<VEC> v = zero_val<VEC>(z.op[k], va, vb);
+            const float* cf = lds + k * 4 * D + c * VEC;
+            const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D), c3 = Vec<VEC>::load(cf + 3 * D);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float zz = v[j] * c0[j] + c1[j];
+              float xh = v[j] * c2[j] - c3[j];
+              float rl = zz > 0.f ? zz : 0.f;
+              float gr = zz > 0.f ? wk[k] * gv[j] : 0.f;
+              a0[k][q][j] += gr;
+              a1[k][q][j] += gr * xh;
+              a2[k][q][j] += gv[j] * rl;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) {
+    if (k < K) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q) {
+        int c = sl + q * LPR;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          red[(rw * 3 + 0) * WIDTH + c * VEC + j] = a0[k][q][j];
+          red[(rw * 3 + 1) * WIDTH + c * VEC + j] = a1[k][q][j];
+          red[(rw * 3 + 2) * WIDTH + c * VEC + j] = a2[k][q][j];
+        }
+      }
+      __syncthreads();
+      float* dst = ws + ((int64_t)blockIdx.x * K + k) * 3 * D;
+      for (int t = threadIdx.x; t < 3 * D; t += MRG_BLOCK) {
+        int which = t / D, c = t - which * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int q2 = 0; q2 < RPB; ++q2) acc += red[(q2 * 3 + which) * WIDTH + c];
+        dst[t] = acc;
+      }
+    }
+  }
+}
+
+// gy_k = (gr - c1 - xhat * c2) * scale_k as in mix_bwd_apply_k, never stored:
+//   g_ent_rows[r] = sum_k gy_k * d y_k / d ent   (mult: rel row, sub / add: 1)
+//   g_rel_rows[r] = sum_k gy_k * d y_k / d rel   (mult: ent row, sub: -1, add: 1)          k = 0..K-1 order
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __restrict__ g, ZeroSrc z, const float* __restrict__ coef,
+                                                              const float* __restrict__ coef2, const float* __restrict__ w,
+                                                              float* __restrict__ ge_rows, float* __restrict__ gr_rows, int64_t rows, int D) {
+  extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int K = z.K;
+  for (int t = threadIdx.x; t < K * 6 * D; t += MRG_BLOCK) {
+    int k = t / (6 * D), rem = t - k * 6 * D;
+    lds[t] = rem < 4 * D ? coef[(int64_t)k * 4 * D + rem] : coef2[(int64_t)k * 2 * D + rem - 4 * D];
+  }
+  __syncthreads();
+  float wk[ZK];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const float* a = z.ent + (int64_t)z.ei[r] * D;
+    const float* b = z.rel + (int64_t)z.ri[r] * D;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      int c = sl + q * LPR;
+      if (c < dv) {
+        const Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
+        const Vec<VEC> va = Vec<VEC>::load(a + c * VEC), vb = Vec<VEC>::load(b + c * VEC);
+        Vec<VEC> ge = Vec<VEC>::fill(0.f), gr2 = Vec<VEC>::fill(0.f);
+#pragma unroll
+        for (int k = 0; k < ZK; ++k) {
+          if (k < K) {
+            const int op = z.op[k];
+            const Vec<VEC> v = zero_val<VEC>(op, va, vb);
+            const float* cf = lds + k * 6 * D + c * VEC;
+            const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D),
+                           c3 = Vec<VEC>::load(cf + 3 * D), c4 = Vec<VEC>::load(cf + 4 * D), c5 = Vec<VEC>::load(cf + 5 * D);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float zz = v[j] * c0[j] + c1[j];
+              float xh = v[j] * c2[j] - c3[j];
+              float gr = zz > 0.f ? wk[k] * gv[j] : 0.f;
+              const float o = (gr - c4[j] - xh * c5[j]) * c0[j];
+              ge[j] += op == MRG_COMPOSE_MULT ? o * vb[j] : o;
+              gr2[j] += op == MRG_COMPOSE_MULT ? o * va[j] : (op == MRG_COMPOSE_SUB ? -o : o);
+            }
+          }
+        }
+        if (ge_rows) ge.store(ge_rows + r * D + c * VEC);
+        if (gr_rows) gr2.store(gr_rows + r * D + c * VEC);
+      }
+    }
+  }
+}
+
 static int mix_grid(int64_t rows, int lpr) {
   int g = stream_grid_for(rows, (MRG_BLOCK / lpr) * 8);
   return g > 1024 ? 1024 : g;                      // partial buffers are sized for 1024 blocks
@@ -595,6 +882,152 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp)
+  MRG_DISPATCH_GEOM(gm, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+
+// ---- cell zero: the MixedOp over compose candidates recomputed from the tables -------------------------------------------------
+static int zero_src(ZeroSrc* z, const float* ent, const float* rel, const int32_t* ei, const int32_t* ri, const int* ops_host, int K) {
+  if (K < 1 || K > ZK || !ops_host) return MRG_E_SHAPE;
+  if (!ent || !rel || !ei || !ri) return MRG_E_NULLPTR;
+  z->ent = ent; z->rel = rel; z->ei = ei; z->ri = ri; z->K = K;
+  for (int k = 0; k < K; ++k) {
+    if (ops_host[k] < 0 || ops_host[k] > 2) return MRG_E_ENUM;
+    z->op[k] = ops_host[k];
+  }
+  return MRG_OK;
+}
+
+static int zero_colstats_blocks(const ZeroSrc& z, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out) {
+  if (rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (!ws) return MRG_E_WORKSPACE;
+  RowGeom g = row_geom(D, aligned16(z.ent) && aligned16(z.rel));
+  if (!g.ok) return MRG_E_SHAPE;
+  int grid = 1;
+#define CALL(V, L, KM)                                                                                    \
+  do {                                                                                                    \
+    grid = mix_grid(rows, L);                                                                             \
+    hipLaunchKernelGGL((zero_colstats_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), 0, st, z, rows, D, (double*)ws); \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  *grid_out = grid;
+  return MRG_OK;
+}
+
+extern "C" int mrg_zero_colstats(const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx, const int* ops_host, int K,
+                                 int64_t rows, int D, double* sums, void* ws, void* stream) {
+  ZeroSrc z{};
+  int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
+  if (rc != MRG_OK) return rc;
+  if (!sums) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 1;
+  rc = zero_colstats_blocks(z, rows, D, ws, st, &grid);
+  if (rc != MRG_OK) return rc;
+  const int len = K * 2 * D;
+  launch_ordered_reduce<double>((const double*)ws, sums, 0, grid, len, len, st);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_zero_stats_coef(const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx, const int* ops_host, int K,
+                                   const float* const* gamma_host, const float* const* beta_host, float* const* rmean_host,
+                                   float* const* rvar_host, int64_t rows, double total_rows, int D, float eps, float momentum, float* coef,
+                                   void* ws, void* stream) {
+  ZeroSrc z{};
+  int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
+  if (rc != MRG_OK) return rc;
+  if (D <= 0 || total_rows < 0) return MRG_E_SHAPE;
+  if (!coef || !gamma_host || !beta_host) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 1;
+  rc = zero_colstats_blocks(z, rows, D, ws, st, &grid);
+  if (rc != MRG_OK) return rc;
+  PtrPack ga{}, be{};
+  MutPack rm{}, rv{};
+  for (int k = 0; k < K; ++k) {
+    ga.p[k] = gamma_host[k]; be.p[k] = beta_host[k];
+    rm.p[k] = rmean_host ? rmean_host[k] : nullptr;
+    rv.p[k] = rvar_host ? rvar_host[k] : nullptr;
+    if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
+  }
+  hipLaunchKernelGGL(mix_reduce_finalize_fwd_k, dim3((D + 63) / 64, K), dim3(1024), 0, st, (const double*)ws, grid, ga, be, rm, rv, K,
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_zero_fwd(const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx, const int* ops_host, int K,
+                            const float* coef, const float* w, float* out, int64_t rows, int D, void* stream) {
+  ZeroSrc z{};
+  const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
+  if (rc != MRG_OK) return rc;
+  if (rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (rows == 0) return MRG_OK;
+  if (!coef || !w || !out) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  RowGeom g = row_geom(D, aligned16(ent) && aligned16(rel) && aligned16(out));
+  if (!g.ok) return MRG_E_SHAPE;
+  const size_t lds = (size_t)K * 2 * D * sizeof(float);
+  if (lds > 64 * 1024) return MRG_E_SHAPE;
+#define CALL(V, L, KM)                                                                                    \
+  hipLaunchKernelGGL((zero_fwd_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, z, coef, w, out, rows, D)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_zero_bwd_reduce(const float* g, const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx,
+                                   const int* ops_host, int K, const float* coef, const float* w, float* red, void* ws, int64_t rows, int D,
+                                   void* stream) {
+  ZeroSrc z{};
+  const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
+  if (rc != MRG_OK) return rc;
+  if (rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (!coef || !w || !red || (rows > 0 && !g)) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  RowGeom gm = row_geom(D, aligned16(g) && aligned16(ent) && aligned16(rel));
+  if (!gm.ok) return MRG_E_SHAPE;
+  int grid = 1;
+#define CALL(V, L, KM)                                                                                    \
+  do {                                                                                                    \
+    grid = mix_grid(rows, L);                                                                             \
+    size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
+    if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
+    hipLaunchKernelGGL((zero_bwd_reduce_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, z, coef, w, (float*)ws, rows, D); \
+  } while (0)
+  MRG_DISPATCH_GEOM(gm, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  const int len = K * 3 * D;
+  launch_ordered_reduce<float>((const float*)ws, red, 0, grid, len, len, st);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+extern "C" int mrg_zero_bwd_apply(const float* g, const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx,
+                                  const int* ops_host, int K, const float* coef, const float* coef2, const float* w, float* g_ent_rows,
+                                  float* g_rel_rows, int64_t rows, int D, void* stream) {
+  ZeroSrc z{};
+  const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
+  if (rc != MRG_OK) return rc;
+  if (rows < 0 || D <= 0) return MRG_E_SHAPE;
+  if (rows == 0 || (!g_ent_rows && !g_rel_rows)) return MRG_OK;
+  if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  RowGeom gm = row_geom(D, aligned16(g) && aligned16(ent) && aligned16(rel) && aligned16(g_ent_rows) && aligned16(g_rel_rows));
+  if (!gm.ok) return MRG_E_SHAPE;
+  const size_t lds = (size_t)K * 6 * D * sizeof(float);
+  if (lds > 64 * 1024) return MRG_E_SHAPE;
+#define CALL(V, L, KM)                                                                                    \
+  hipLaunchKernelGGL((zero_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, z, coef, coef2, w, g_ent_rows, g_rel_rows, rows, D)
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();

@@ -81,6 +81,11 @@ class MixedOp(nn.Module):
                 total = total + w * act(bn(op(g, h, h_in).float()))
             return total
         if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
+            if (K.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(self._ops) <= 3
+                    and all(isinstance(op, OPS._PreOp) for op, _, _ in self._ops)):
+                # ... and are never stored: statistics, combine and gradients recompute them from the two tables
+                return K.cell_zero_mixed([op.kind for op, _, _ in self._ops], h, h_in, [bn for _, bn, _ in self._ops], weights,
+                                         group, total_rows)
             ys = [op(g, h, h_in) for op, _, _ in self._ops]
             return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
         # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in

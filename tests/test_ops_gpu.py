@@ -619,3 +619,69 @@ def test_fused_aggregators_are_bit_exact_across_split_core_kernels(kind):
         lib.mrg_gemm_set_mode(0)
     for a, b_, what in zip(res[0], res[2], ("out", "gx", "gW", "gb")):
         assert torch.equal(a, b_), what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,E,R,D,train", [(3000, 90000, 11, 200, True), (400, 5000, 5, 64, True), (300, 3000, 4, 10, True), (500, 20000, 7, 200, False)])
+def test_cell_zero_recompute_matches_the_stored_candidates(N, E, R, D, train):
+    """Cell_Zero's MixedOp over PRE_OPS with the candidates recomputed from the tables (mrg_zero_*: no [rows, D] candidate is
+    stored) against three gather-compose launches + the generic epilogue: output, BatchNorm running statistics, alpha / gamma /
+    beta gradients bit-identical (same values, same summation order); the table gradients (the association of their sums
+    differs) within rounding, and against the plain torch formulation."""
+    from mr_gnas_amd import supernet as S
+    gen = torch.Generator().manual_seed(N + E + D)
+    ent0 = torch.randn(N, D, generator=gen)
+    rel0 = torch.randn(2 * R + 1, D, generator=gen)
+    ei = torch.randint(0, N, (E + N,), generator=gen).to(DEV)
+    ri = torch.randint(0, 2 * R + 1, (E + N,), generator=gen).to(DEV)
+    w0 = torch.softmax(torch.randn(3, generator=gen), 0)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for fused in (True, False):
+            K.CELL_ZERO_FUSED = fused
+            torch.manual_seed(5)
+            mixed = S.MixedOp(D, 0.0, O.PRE_OPS).to(DEV)
+            with torch.no_grad():
+                for _, bn, _ in mixed._ops:
+                    bn.weight.add_(0.1 * torch.randn_like(bn.weight)); bn.bias.add_(0.1 * torch.randn_like(bn.bias))
+                    bn.running_mean.add_(0.05); bn.running_var.mul_(1.3)
+            mixed.train(train)
+            ent, rel, w = (t.clone().to(DEV).requires_grad_(True) for t in (ent0, rel0, w0))
+            gp_e, gp_r = K.GatherPlan(ei, N), K.GatherPlan(ri, 2 * R + 1)
+            out = mixed(w, None, K.LazyRows(ent, gp_e), K.LazyRows(rel, gp_r))
+            out.backward(gout)
+            res[fused] = dict(out=out.detach(), w=w.grad, ent=ent.grad, rel=rel.grad,
+                              gam=[bn.weight.grad.clone() for _, bn, _ in mixed._ops], bet=[bn.bias.grad.clone() for _, bn, _ in mixed._ops],
+                              rm=[bn.running_mean.clone() for _, bn, _ in mixed._ops], rv=[bn.running_var.clone() for _, bn, _ in mixed._ops])
+            if fused:
+                model = mixed
+    finally:
+        K.CELL_ZERO_FUSED = True
+    a, b = res[True], res[False]
+    assert torch.equal(a["out"], b["out"]) and torch.equal(a["w"], b["w"])
+    for key in ("gam", "bet", "rm", "rv"):
+        for x, y in zip(a[key], b[key]):
+            assert torch.equal(x, y), key
+    for key in ("ent", "rel"):
+        close(a[key], b[key].cpu(), "cell zero table gradient " + key, rtol=2e-5, atol=2e-5 * float(b[key].abs().max()))
+    # the torch formulation (reference models/cell_lp.py:25-33 on pre_mult / pre_sub / pre_add of the gathered rows)
+    e64, r64, w64 = (t.double().to(DEV).requires_grad_(True) for t in (ent0, rel0, w0))
+    x, h = e64[ei.long()], r64[ri.long()]
+    ref = 0
+    for k, (y, (_, bn, _)) in enumerate(zip((x * h, x - h, x + h), model._ops)):
+        if train:
+            mu, var = y.mean(0), y.var(0, unbiased=False)
+        else:
+            mu, var = (bn.running_mean.double() - 0.0), bn.running_var.double()
+        if train:
+            z = (y - mu) / torch.sqrt(var + bn.eps) * bn.weight.double() + bn.bias.double()
+        else:
+            z = None
+        if z is not None:
+            ref = ref + w64[k] * torch.relu(z)
+    if train:
+        ref.backward(gout.double())
+        close(a["out"], ref.detach().float().cpu(), "cell zero vs torch float64", rtol=1e-4, atol=1e-5)
+        close(a["ent"], e64.grad.float().cpu(), "cell zero d ent vs torch float64", rtol=1e-4, atol=1e-4 * float(e64.grad.abs().max()))
+        close(a["rel"], r64.grad.float().cpu(), "cell zero d rel vs torch float64", rtol=1e-4, atol=1e-4 * float(r64.grad.abs().max()))
