@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables); 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -397,6 +397,15 @@ int mrg_dense_filter_dz3(int kind, const float *g, const float *s, const float *
 int64_t mrg_linear_bwd_input3_workspace_bytes(int K, int Nout);
 int mrg_linear_bwd_input3(const float *gY, const float *const *W, float *gX, void *ws, int64_t b0, int64_t b1, int64_t M,
                           int K, int Nout, int ldw, int accumulate, void *stream);
+/* The input gradient of TWO candidates that read the same rows as one product over the concatenated reduction dimension:
+ * gX rows of range s (+)= [gY1 | gY2] [W1[s][:, 0:K] ; W2[s][:, 0:K]] -- f_dense_comp and f_comp of one MixedOp (reference
+ * models/cell_lp.py:95-113; models/operations_lp.py:266-288, 356-390) leave ONE gradient w.r.t. their shared operand instead
+ * of two that a fan-in pass would add.  gY1, gY2: [M, Nout]; W1, W2: HOST arrays of three device pointers, each [Nout][ldw].
+ * Split core only (the workspace query returns 0 otherwise). */
+int64_t mrg_linear_bwd_input3_pair_workspace_bytes(int K, int Nout);
+int mrg_linear_bwd_input3_pair(const float *gY1, const float *gY2, const float *const *W1, const float *const *W2, float *gX,
+                               void *ws, int64_t b0, int64_t b1, int64_t M, int K, int Nout, int ldw, int accumulate,
+                               void *stream);
 int64_t mrg_linear_bwd_weight3_workspace_bytes(int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout);
 int mrg_linear_bwd_weight3(const float *gY, const float *X1, const float *X2, float *const *gW, float *const *gbias, void *ws,
                            int64_t b0, int64_t b1, int64_t M, int K1, int K2, int Nout, void *stream);

@@ -76,6 +76,8 @@ SIGNATURES = {
     "mrg_dense_filter_dz3": (_I, [_I, _P, _P, _P, _P, _F, _F, _P, _P, _L, _L, _I, _P]),
     "mrg_linear_bwd_input3_workspace_bytes": (_L, [_I, _I]),
     "mrg_linear_bwd_input3": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P]),
+    "mrg_linear_bwd_input3_pair_workspace_bytes": (_L, [_I, _I]),
+    "mrg_linear_bwd_input3_pair": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _P]),
     "mrg_linear_bwd_weight3_workspace_bytes": (_L, [_L, _L, _L, _I, _I, _I]),
     "mrg_linear_bwd_weight3": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _P]),
     "mrg_linear_relu_segsum_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -83,9 +83,13 @@ inline size_t x3_bsplit_bytes(int N, int K, int nt) { return (size_t)x3_slabs(K)
 // k = slab*16 + (lane/32)*8 + j).  Rows >= N and columns >= K are zero, which is also what makes the
 // clamped out-of-range A chunks harmless.  sk != 1 presents W^T without a transpose pass.
 // Up to three weights of the same shape in one launch (blockIdx.y): the direction segments of a dense filter.
-struct BSplit3 { const float* B[3]; u32x4* out[3]; };
+// Optional second source along k (the input gradient of two candidates in one product, [dz_a | dz_b] [W_a ; W_b]):
+// columns k >= ksplit come from B2 at k - ksplit (ksplit = 0: single source).
+struct BSplit3 { const float* B[3]; u32x4* out[3]; const float* B2[3]; int ksplit; };
 static __global__ void bsplit3_k(BSplit3 p, int64_t sn, int64_t sk, int N, int K, int ntile, int nslab) {
   const float* __restrict__ B = p.B[blockIdx.y];
+  const float* __restrict__ B2 = p.B2[blockIdx.y];
+  const int ksplit = (p.ksplit > 0 && B2) ? p.ksplit : K;
   u32x4* __restrict__ Bp = p.out[blockIdx.y];
   if (!B) return;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +98,10 @@ static __global__ void bsplit3_k(BSplit3 p, int64_t sn, int64_t sk, int N, int K
   const int n = tile * 32 + (lane & 31), k0 = slab * 16 + (lane >> 5) * 8;
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? B[n * sn + (k0 + j) * sk] : 0.f;
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    v[j] = (n < N && k < K) ? (k < ksplit ? B[n * sn + k * sk] : B2[n * sn + (k - ksplit) * sk]) : 0.f;
+  }
   u32x4 h, m, l;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -106,11 +113,13 @@ static __global__ void bsplit3_k(BSplit3 p, int64_t sn, int64_t sk, int N, int K
   o[0] = h; o[64] = m; o[128] = l;
 }
 
-inline void launch_bsplit3(const float* const* B, int64_t sn, int64_t sk, int N, int K, int nt, void* const* out, hipStream_t st) {
+inline void launch_bsplit3(const float* const* B, int64_t sn, int64_t sk, int N, int K, int nt, void* const* out, hipStream_t st,
+                           const float* const* B2 = nullptr, int ksplit = 0) {
   const int ntile = x3_tiles(N, nt), nslab = x3_slabs(K);
   const int total = nslab * ntile * 64;
   BSplit3 p{};
-  for (int i = 0; i < 3; ++i) { p.B[i] = B[i]; p.out[i] = (u32x4*)out[i]; }
+  for (int i = 0; i < 3; ++i) { p.B[i] = B[i]; p.out[i] = (u32x4*)out[i]; p.B2[i] = B2 ? B2[i] : nullptr; }
+  p.ksplit = B2 ? ksplit : 0;
   hipLaunchKernelGGL(bsplit3_k, dim3((total + 255) / 256, 3), dim3(256), 0, st, p, sn, sk, N, K, ntile, nslab);
 }
 

@@ -807,6 +807,49 @@ extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host
   return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);
 }
 
+// gX rows of the three ranges (+)= gY1 W1[s][:, 0:K] + gY2 W2[s][:, 0:K] as ONE product over the concatenated reduction
+// dimension, [gY1 | gY2] [W1 ; W2]: the input gradient of two candidates that read the same rows (f_dense_comp and f_comp of
+// one MixedOp, reference models/cell_lp.py:95-113, models/operations_lp.py:266-288,356-390) written once instead of two
+// gradients that a fan-in pass adds.
+static size_t bwd_input3_pair_each(int K, int Nout) { return (size_t)(((int64_t)x3_bsplit_bytes(K, 2 * Nout, gemm_pick_nt(K)) + 255) / 256 * 256); }
+
+extern "C" int64_t mrg_linear_bwd_input3_pair_workspace_bytes(int K, int Nout) {
+  if (K <= 0 || Nout <= 24 || Nout % 4 != 0 || gemm_mode() == 1) return 0;
+  return 3 * (int64_t)bwd_input3_pair_each(K, Nout);
+}
+
+extern "C" int mrg_linear_bwd_input3_pair(const float* gY1, const float* gY2, const float* const* W1_host, const float* const* W2_host, float* gX,
+                                          void* ws, int64_t b0, int64_t b1, int64_t M, int K, int Nout, int ldw, int accumulate, void* stream) {
+  if (K <= 0 || Nout <= 24 || Nout % 4 != 0 || ldw < K || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (M == 0) return MRG_OK;
+  if (!gY1 || !gY2 || !W1_host || !W2_host || !gX) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.A1 = gY1; a.K1 = Nout; a.A2 = gY2; a.K2 = Nout; a.C = gX; a.ldc = K; a.N = K; a.rows = M; a.act = MRG_ACT_NONE;
+  if (accumulate) { a.Cin = gX; a.ld_cin = K; }
+  if (!x3_eligible(a)) return MRG_E_SHAPE;
+  const int64_t lo[3] = {0, b0, b1}, hi[3] = {b0, b1, M};
+  const size_t each = bwd_input3_pair_each(K, Nout);
+  const float* Bs[3]; const float* Bs2[3]; void* outs[3];
+  a.grp.n = 3;
+  a.grp.bp_stride = (int64_t)each;
+  for (int i = 0; i < 3; ++i) {
+    const bool live = hi[i] > lo[i];
+    if (live && (!W1_host[i] || !W2_host[i])) return MRG_E_NULLPTR;
+    Bs[i] = live ? W1_host[i] : nullptr;
+    Bs2[i] = live ? W2_host[i] : nullptr;
+    outs[i] = (char*)ws + i * each;
+    a.grp.lo[i] = lo[i]; a.grp.hi[i] = live ? hi[i] : lo[i];
+    a.grp.scale[i] = 1.0f;
+  }
+  // B(n = k_in, k) = k < Nout ? W1[k * ldw + k_in] : W2[(k - Nout) * ldw + k_in]
+  launch_bsplit3(Bs, 1, ldw, K, 2 * Nout, gemm_pick_nt(K), outs, st, Bs2, Nout);
+  MRG_LAUNCH_CHECK();
+  if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
+  return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);
+}
+
 // gW[s][Nout][K1+K2] = gY[lo_s:hi_s]^T [X1 | X2][lo_s:hi_s], gbias[s] = column sums, for the three row ranges in one launch
 static bool wgrad3_ok(int K1, int K2, int Nout) {
   return Nout >= 4 && Nout <= 224 && Nout % 4 == 0 && K1 >= 4 && K1 % 4 == 0 && K2 >= 0 && K2 % 4 == 0;

@@ -1000,7 +1000,7 @@ class _MixedEpilogue(torch.autograd.Function):
         if rs is not None:
             for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
                 if rs[k] is not None and gys[k] is not None:
-                    rs[k][5].prescaled_ptr = gys[k].data_ptr()
+                    rs[k][5].prescaled_ptr[rs[k][6]] = gys[k].data_ptr()
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
@@ -1017,9 +1017,11 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
     if fold_row_scales:
         for k, y in enumerate(ys):
             spec = getattr(y, "_mrg_rowscale", None) if y is not None else None
-            if spec is not None and y.grad_fn is not None and getattr(y.grad_fn, "prescaled", None) is False:
-                rowscale[k] = spec[:4] + (y.grad_fn if spec[4] else None, y.grad_fn)   # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node
-                y.grad_fn.prescaled = True
+            node = y.grad_fn if y is not None else None
+            if spec is not None and node is not None and isinstance(getattr(node, "prescaled", None), list) and node.prescaled[spec[5]] is False:
+                # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node; [6] which of its outputs y is
+                rowscale[k] = spec[:4] + (node if spec[4] else None, node, spec[5])
+                node.prescaled[spec[5]] = True
     cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)
@@ -1223,8 +1225,8 @@ class _DenseFilter(torch.autograd.Function):
         g = f32c(g)
         M, D = s.shape
         st = stream_of(s)
-        prescaled = getattr(ctx, "prescaled", False)       # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already
-        if prescaled and getattr(ctx, "prescaled_ptr", None) != g.data_ptr():
+        prescaled = bool(getattr(ctx, "prescaled", [False])[0])   # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already
+        if prescaled and getattr(ctx, "prescaled_ptr", [None])[0] != g.data_ptr():
             # y had a second consumer: autograd summed its (unscaled) gradient into the epilogue's pre-scaled one
             raise _lib.MrgnasError("dense filter: the folded epilogue gradient was combined with another consumer's gradient; "
                                    "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
@@ -1342,9 +1344,123 @@ def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_s
         # the backward begins with an elementwise pass over the incoming gradient (f_comp: dz = g * c; f_dense_comp: dz = g c s gate
         # (1 - gate) and the direct term g c gate; c = norm / 3 on edge rows, self_scale on self rows): a MixedOp epilogue that is
         # the only reader of y writes its gradient in that form (mixed_epilogue(fold_row_scales=True)) and flips `prescaled`
-        y.grad_fn.prescaled = False
-        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale), kind == 0)
+        y.grad_fn.prescaled, y.grad_fn.prescaled_ptr = [False], [None]
+        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale), kind == 0, 0)
     return y
+
+
+DENSE_PAIR = os.environ.get("MRG_DENSE_PAIR", "1") == "1"       # lab switch: 0 = f_dense_comp and f_comp of a MixedOp as two autograd nodes
+
+
+class _DensePair(torch.autograd.Function):
+    """f_dense_comp and f_comp of ONE MixedOp as one autograd node (reference models/cell_lp.py:95-113: every first-stage MixedOp
+    applies both to the same (h, h_in); models/operations_lp.py:356-390, 266-288).  Forward: the two grouped row GEMMs of
+    _DenseFilter (gate epilogue / scale epilogue).  Backward: ONE input-gradient product over the concatenated reduction
+    dimension per operand, gs = direct term + [dz_d | dz_c] [W_d[:, :D] ; W_c[:, :D]] (mrg_linear_bwd_input3_pair) -- one
+    gradient w.r.t. the shared operand instead of two that the state's fan-in pass would add -- and the two weight gradients.
+    params: W_in, b_in, W_out, b_out, W_self, b_self of f_dense_comp, then W_in, W_out, W_self of f_comp (no biases)."""
+
+    @staticmethod
+    def forward(ctx, s, s_in, norm, b0, b1, *params):
+        s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
+        params = tuple(f32c(p) for p in params)
+        require_hip(s, s_in, norm, *params)
+        M, D = s.shape
+        st = stream_of(s)
+        K_ = 2 * D if s_in is not None else D
+        ws3 = int(_lib.load().mrg_dense_filter3_workspace_bytes(D, K_))
+        out_d, out_c, gate = torch.empty_like(s), torch.empty_like(s), torch.empty_like(s)
+        dW, dB, cW = [params[0], params[2], params[4]], [params[1], params[3], params[5]], list(params[6:9])
+        work = dict(flops=2 * M * K_ * D)
+        call("mrg_dense_filter_fwd3", (0, ptr(s), ptr(s_in), ptr_array(dW), ptr_array(dB), ptr(norm), 1.0 / 3.0, 1.0 / 3.0, ptr(out_d), ptr(gate),
+                                       ptr(_ws(ws3, s)), b0, b1, M, D, st), nbytes=4 * M * (K_ + 2 * D), **work)
+        call("mrg_dense_filter_fwd3", (1, ptr(s), ptr(s_in), ptr_array(cW), ptr_array([None, None, None]), ptr(norm), 1.0 / 3.0, 1.0, ptr(out_c), None,
+                                       ptr(_ws(ws3, s)), b0, b1, M, D, st), nbytes=4 * M * (K_ + D), **work)
+        ctx.cfg = (b0, b1)
+        ctx.save_for_backward(s, s_in, norm, gate, *params)
+        return out_d, out_c
+
+    @staticmethod
+    def backward(ctx, g_d, g_c):
+        s, s_in, norm, gate, *params = ctx.saved_tensors
+        b0, b1 = ctx.cfg
+        M, D = s.shape
+        st = stream_of(s)
+        g_d, g_c = f32c(g_d), f32c(g_c)
+        pres = list(getattr(ctx, "prescaled", [False, False]))
+        ptrs = getattr(ctx, "prescaled_ptr", [None, None])
+        for i, g in enumerate((g_d, g_c)):
+            if pres[i] and ptrs[i] != g.data_ptr():
+                raise _lib.MrgnasError("dense filter pair: the folded epilogue gradient was combined with another consumer's gradient; "
+                                       "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
+        K_ = 2 * D if s_in is not None else D
+        dW, cW = [params[0], params[2], params[4]], list(params[6:9])
+        # 1. dz of both candidates (+ the direct term of f_dense_comp's gs), unless the MixedOp epilogue's gradient store did it
+        if pres[0]:
+            dz_d, gs = g_d, ctx.gs_direct
+            gs.record_stream(torch.cuda.current_stream())
+        else:
+            dz_d, gs = torch.empty_like(s), torch.empty_like(s)
+            call("mrg_dense_filter_dz3", (0, ptr(g_d), ptr(s), ptr(gate), ptr(norm), 1.0 / 3.0, 1.0 / 3.0, ptr(dz_d), ptr(gs), b1, M, D, st),
+                 nbytes=4 * M * D * 5)
+        if pres[1]:
+            dz_c = g_c
+        else:
+            dz_c = torch.empty_like(s)
+            call("mrg_dense_filter_dz3", (1, ptr(g_c), ptr(s), None, ptr(norm), 1.0 / 3.0, 1.0, ptr(dz_c), None, b1, M, D, st), nbytes=4 * M * D * 2)
+        # 2. ONE product per operand: gs += [dz_d | dz_c] [W_d[:, :D] ; W_c[:, :D]],  gs_in = [dz_d | dz_c] [W_d[:, D:] ; W_c[:, D:]]
+        lib = _lib.load()
+        wsp = int(lib.mrg_linear_bwd_input3_pair_workspace_bytes(D, D))
+        gwork = dict(nbytes=4 * M * 3 * D + 24 * D * D, flops=4 * M * D * D)
+        call("mrg_linear_bwd_input3_pair", (ptr(dz_d), ptr(dz_c), ptr_array(dW), ptr_array(cW), ptr(gs), ptr(_ws(wsp, s)), b0, b1, M, D, D, K_, 1, st),
+             nbytes=4 * M * 4 * D + 24 * D * D, flops=4 * M * D * D)
+        gs_in = None
+        if s_in is not None:
+            gs_in = torch.empty_like(s)
+            call("mrg_linear_bwd_input3_pair", (ptr(dz_d), ptr(dz_c), ptr_array([W[:, D:] for W in dW]), ptr_array([W[:, D:] for W in cW]), ptr(gs_in),
+                                                ptr(_ws(wsp, s)), b0, b1, M, D, D, K_, 0, st), **gwork)
+        # 3. the weight gradients of the two candidates
+        wsw = int(lib.mrg_linear_bwd_weight3_workspace_bytes(b0, b1, M, D, K_ - D, D))
+        g_dW = [torch.empty_like(W) for W in dW]
+        g_dB = [torch.empty_like(params[2 * i + 1]) for i in range(3)]
+        g_cW = [torch.empty_like(W) for W in cW]
+        wwork = dict(nbytes=4 * M * (D + K_), flops=2 * M * K_ * D)
+        call("mrg_linear_bwd_weight3", (ptr(dz_d), ptr(s), ptr(s_in), ptr_array(g_dW), ptr_array(g_dB), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st), **wwork)
+        call("mrg_linear_bwd_weight3", (ptr(dz_c), ptr(s), ptr(s_in), ptr_array(g_cW), ptr_array([None, None, None]), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st),
+             **wwork)
+        grads_d = [t for pair in zip(g_dW, g_dB) for t in pair]
+        return (gs, gs_in, None, None, None, *grads_d, *g_cW)
+
+
+def dense_pair_available(D, tied):
+    """May f_dense_comp + f_comp run as one node (split core, grouped direction segments, every stage's workspace query answers)?"""
+    if not (DENSE_PAIR and GROUPED_SEGMENTS):
+        return False
+    lib = _lib.load()
+    K_ = D if tied else 2 * D
+    return (int(lib.mrg_dense_filter3_workspace_bytes(D, K_)) > 0 and int(lib.mrg_linear_bwd_input3_pair_workspace_bytes(D, D)) > 0
+            and int(lib.mrg_linear_bwd_weight3_workspace_bytes(1, 2, 3, D, K_ - D, D)) > 0)
+
+
+def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights):
+    """(f_dense_comp(s, s_in), f_comp(s, s_in)) as one autograd node; dense_params = (W_in, b_in, W_out, b_out, W_self, b_self),
+    comp_weights = (W_in, W_out, W_self).  Operands that are the same rows use the folded [D, D] weights."""
+    dW, dB = list(dense_params[0::2]), list(dense_params[1::2])
+    cW = list(comp_weights)
+    if s_in is not None and same_rows(s, s_in):
+        dW = list(_FoldHalves.apply(*dW))
+        cW = list(_FoldHalves.apply(*cW))
+        s_in = None
+    norm = f32c(norm)
+    if norm is not None and norm.numel() < int(b1):
+        raise _lib.MrgnasError(f"dense filter: edge norm has {norm.numel()} entries, the edge rows need {int(b1)}")
+    y_d, y_c = _DensePair.apply(s, s_in, norm, int(b0), int(b1), dW[0], dB[0], dW[1], dB[1], dW[2], dB[2], *cW)
+    if FOLD_ROW_SCALE and y_d.grad_fn is not None and y_d.is_cuda:
+        node = y_d.grad_fn
+        node.prescaled, node.prescaled_ptr = [False, False], [None, None]
+        y_d._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, 1.0 / 3.0, True, 0)
+        y_c._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, 1.0, False, 1)
+    return y_d, y_c
 
 
 def dense_filter_single(s, s_in, W, b):

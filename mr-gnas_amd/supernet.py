@@ -93,6 +93,9 @@ class MixedOp(nn.Module):
         n = len(self._ops)
         fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
         fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
+        # f_dense_comp and f_comp read the same (h, h_in): one autograd node whose backward leaves ONE gradient per operand
+        pair = self._dense_pair(fh.x)
+        paired = {}
         # The candidates are independent: they run round-robin on a few HIP streams so that the tail of one
         # kernel (a GEMM workgroup owns a whole CU) is filled by another candidate's kernels.  Autograd replays
         # each candidate's backward on the stream its forward ran on.
@@ -100,7 +103,16 @@ class MixedOp(nn.Module):
         # (launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows)
         nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
         if nstreams <= 1:
-            ys = [None if isinstance(op, OPS.f_zero_op) else op(g, fh.take(), fi.take()) for op, _, _ in self._ops]
+            ys = []
+            for k, (op, _, _) in enumerate(self._ops):
+                if isinstance(op, OPS.f_zero_op):
+                    ys.append(None)
+                elif pair is not None and k in pair:
+                    if not paired:
+                        paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take())
+                    ys.append(paired[k])
+                else:
+                    ys.append(op(g, fh.take(), fi.take()))
             return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
         fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
@@ -108,17 +120,37 @@ class MixedOp(nn.Module):
             if isinstance(op, OPS.f_zero_op):
                 ys.append(None)
                 continue
+            if pair is not None and k in pair and paired:
+                ys.append(paired[k])                   # computed with its partner
+                continue
             side = fork.stream(k)
             a, b = fh.take(), fi.take()
             if side is not fork.main:                  # h / h_in live in main-stream blocks and are read (forward and,
                 a.record_stream(side)                  # through the saved tensors, backward) on the side stream: the
                 b.record_stream(side)                  # allocator must not recycle them before that stream is done
             with torch.cuda.stream(side):
-                y = op(g, a, b)
+                if pair is not None and k in pair:
+                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b)
+                    y = paired[k]
+                    paired[pair[0] + pair[1] - k].record_stream(fork.main)
+                else:
+                    y = op(g, a, b)
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
         return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
+
+
+    def _dense_pair(self, x):
+        """(index of f_dense_comp, index of f_comp) when both are candidates of this MixedOp and may share a node, else None."""
+        if not x.is_cuda:
+            return None
+        d = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_dense_op_comp]
+        c = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_comp_op]
+        if len(d) != 1 or len(c) != 1:
+            return None
+        return (d[0], c[0])
+
 
 
 class _Stage(nn.Module):

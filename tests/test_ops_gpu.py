@@ -685,3 +685,43 @@ def test_cell_zero_recompute_matches_the_stored_candidates(N, E, R, D, train):
         close(a["out"], ref.detach().float().cpu(), "cell zero vs torch float64", rtol=1e-4, atol=1e-5)
         close(a["ent"], e64.grad.float().cpu(), "cell zero d ent vs torch float64", rtol=1e-4, atol=1e-4 * float(e64.grad.abs().max()))
         close(a["rel"], r64.grad.float().cpu(), "cell zero d rel vs torch float64", rtol=1e-4, atol=1e-4 * float(r64.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tied", [True, False])
+@pytest.mark.parametrize("N,E,R,D", [(2000, 150000, 9, 200), (300, 5000, 4, 64)])
+def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
+    """A first-stage MixedOp with f_dense_comp and f_comp as ONE autograd node (one input-gradient product over the
+    concatenated reduction dimension, mrg_linear_bwd_input3_pair) against the two operators as separate nodes: forward
+    bit-identical, every gradient within float32 summation-order tolerance; candidates on side streams (large case) and
+    on one stream (small case); tied operands (h is h_in) and distinct ones."""
+    from mr_gnas_amd import supernet as S
+    gen = torch.Generator().manual_seed(N + E + D + int(tied))
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    et = torch.randint(0, 2 * R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    h0 = torch.randn(E + N, D, generator=gen)
+    hin0 = h0 if tied else torch.randn(E + N, D, generator=gen)
+    w0 = torch.softmax(torch.randn(len(O.FIRST_OPS), generator=gen), 0)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    torch.manual_seed(3)
+    mixed = S.MixedOp(D, 0.0, O.FIRST_OPS).to(DEV)
+    S.xavier_init_(mixed)
+    res = {}
+    try:
+        for pair in (True, False):
+            K.DENSE_PAIR = pair
+            mixed.zero_grad(set_to_none=True)
+            h = h0.clone().to(DEV).requires_grad_(True)
+            hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
+            w = w0.clone().to(DEV).requires_grad_(True)
+            out = mixed(w, g, h, hin)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            res[pair] = [out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
+    finally:
+        K.DENSE_PAIR = True
+    assert torch.equal(res[True][0], res[False][0])
+    for i, (a, b) in enumerate(zip(res[True][1:], res[False][1:])):
+        close(a, b.cpu(), f"dense pair gradient {i}", rtol=3e-5, atol=3e-5 * max(1.0, float(b.abs().max())))
