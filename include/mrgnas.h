@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -469,6 +469,20 @@ int mrg_negative_sampling(const int64_t *pos, int64_t B, int rate, const int64_t
                           int64_t *samples, float *labels, void *stream);
 /* `uniq_v, edges = np.unique((src, dst), return_inverse=True)`, reference utils/utils_rgcn.py:97-101: uniq [<= min(2n,
  * num_nodes)] = the distinct node ids in ascending order, new_src / new_dst their ranks, count [1] (device) = len(uniq). */
+/* sample_edge_neighborhood (reference utils/utils_rgcn.py:30-71; `--edge_sampler neighbor`, search/mr_lp_search.py:323-324):
+ * sample_size dependent picks by neighbourhood expansion in ONE launch of one persistent workgroup.  Adjacency in the
+ * reference's append order (get_adj_and_degrees, :18-28) as a CSR: rowptr [N + 1], adj_edge / adj_other [2 T] (triple id and the
+ * vertex at its other end), degrees [N].  Draws are inputs: u_vertex [sample_size] float64 uniforms for the vertex picks
+ * (inverse cdf over sample_counts * seen), and EITHER tries [n_tries] -- the reference's own sequence of tried adjacency slots,
+ * rejected ones included (replay: bit-exact) -- OR u_edge [sample_size] float64 uniforms (one draw per pick selects uniformly
+ * among the vertex's unpicked entries: the reference's distribution without its rejection loop).  edges [sample_size] int32.
+ * status [3] int64: picks made, tries consumed, failure code (0 ok; 1 graph exhausted; 2 / 3 bad or missing tries).
+ * ws: mrg_sample_neighborhood_workspace_bytes(N, T). */
+int64_t mrg_sample_neighborhood_workspace_bytes(int64_t N, int64_t T);
+int mrg_sample_edge_neighborhood(const int32_t *rowptr, const int32_t *adj_edge, const int32_t *adj_other, const int32_t *degrees,
+                                 int64_t N, int64_t T, int64_t sample_size, const double *u_vertex, const int64_t *tries,
+                                 int64_t n_tries, const double *u_edge, int32_t *edges, int64_t *status, void *ws,
+                                 int64_t ws_bytes, void *stream);
 int64_t mrg_relabel_workspace_bytes(int64_t num_nodes);
 int mrg_relabel_nodes(const int64_t *src, const int64_t *dst, int64_t n, int64_t num_nodes, int64_t *uniq,
                       int64_t *new_src, int64_t *new_dst, int32_t *count, void *ws, int64_t ws_bytes, void *stream);

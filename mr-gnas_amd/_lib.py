@@ -97,6 +97,8 @@ SIGNATURES = {
     "mrg_chunk_plan_workspace_bytes": (_L, [_L, _L]),
     "mrg_chunk_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mrg_negative_sampling": (_I, [_P, _L, _I, _P, _P, _P, _P, _P]),
+    "mrg_sample_neighborhood_workspace_bytes": (_L, [_L, _L]),
+    "mrg_sample_edge_neighborhood": (_I, [_P, _P, _P, _P, _L, _L, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P]),
     "mrg_relabel_workspace_bytes": (_L, [_L]),
     "mrg_relabel_nodes": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _L, _P]),
     "mrg_multi_hot_labels": (_I, [_P, _P, _P, _P, _L, _L, _L, _F, _F, _P, _P]),

@@ -91,6 +91,147 @@ __global__ __launch_bounds__(256) void rank_filtered_k(const float* __restrict__
   if (threadIdx.x == 0) ranks[b] = 1 + red[0];
 }
 
+
+// ---- neighbourhood-expansion edge sampler (reference utils/utils_rgcn.py:30-71, `--edge_sampler neighbor`) ------------------------
+// sample_size DEPENDENT picks: every pick changes the weights of the next one.  One persistent 1024-thread workgroup walks the
+// picks; inside a pick everything that is not sequential by nature runs over the workgroup:
+//   weights w_v = sample_counts[v] * seen[v] (all ones over the vertices with sample_counts > 0 when their sum is 0)
+//   vertex  = searchsorted(cumsum(w / sum w), u, side='right')      -> integer prefix sums W_j and the first j with W_j > u * W
+//             (the reference's float64 cdf step j is W_j / W up to rounding: the two agree unless u lies within rounding distance
+//             of a step, probability < 1e-7 per draw; the golden replay pins the draws it uses)
+//   edge    = a uniformly chosen NOT YET PICKED entry of the vertex's adjacency list (the reference re-draws until it finds one):
+//             replay mode: the reference's own sequence of tried slots (int64, as many as it drew);
+//             random mode: ONE uniform u2 -> the floor(u2 * sample_counts[v])-th unpicked entry (the same distribution without
+//             rejection: sample_counts[v] IS the number of unpicked entries of v).
+// adjacency = CSR in the reference's append order (get_adj_and_degrees, :18-28): for triple i, (i, o) joins s's list, then (i, s) o's.
+// status[0] = number of picks made (== sample_size on success), status[1] = tries consumed (replay mode).
+constexpr int NS_THREADS = 1024;
+
+__device__ __forceinline__ int64_t ns_block_scan(int64_t v, int64_t* sh, int64_t* total) {   // exclusive prefix of v over the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int w = 0; w < NS_THREADS / 64; ++w) { const int64_t t = sh[w]; sh[w] = run; run += t; }
+    sh[NS_THREADS / 64] = run;
+  }
+  __syncthreads();
+  const int64_t excl = sh[wave] + x - v;
+  *total = sh[NS_THREADS / 64];
+  __syncthreads();                                          // sh is reused by the next scan
+  return excl;
+}
+
+__global__ __launch_bounds__(NS_THREADS) void sample_neighborhood_k(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ adj_edge,
+                                                                    const int32_t* __restrict__ adj_other, const int32_t* __restrict__ degrees,
+                                                                    int64_t N, int64_t T, int64_t S, const double* __restrict__ u_vertex,
+                                                                    const int64_t* __restrict__ tries, int64_t n_tries,
+                                                                    const double* __restrict__ u_edge, int32_t* __restrict__ edges,
+                                                                    int32_t* __restrict__ counts, unsigned char* __restrict__ seen,
+                                                                    unsigned char* __restrict__ picked, int64_t* __restrict__ status) {
+  __shared__ int64_t sh[NS_THREADS / 64 + 1];
+  __shared__ long long pick_v, pick_slot, try_pos;
+  __shared__ int fail;
+  const int tid = threadIdx.x;
+  for (int64_t v = tid; v < N; v += NS_THREADS) { counts[v] = degrees[v]; seen[v] = 0; }
+  for (int64_t e = tid; e < T; e += NS_THREADS) picked[e] = 0;
+  if (tid == 0) { try_pos = 0; fail = 0; status[0] = 0; status[1] = 0; }
+  __syncthreads();
+  const int64_t chunk = (N + NS_THREADS - 1) / NS_THREADS;
+  const int64_t lo = tid * chunk < N ? tid * chunk : N, hi = lo + chunk < N ? lo + chunk : N;
+  for (int64_t i = 0; i < S; ++i) {
+    // ---- the vertex
+    int64_t mine = 0;
+    for (int64_t v = lo; v < hi; ++v) mine += (int64_t)counts[v] * seen[v];
+    int64_t W;
+    int64_t before = ns_block_scan(mine, sh, &W);
+    bool uniform = false;
+    if (W == 0) {                                           // nothing seen yet (or every seen vertex is exhausted): uniform over the live vertices
+      uniform = true;
+      mine = 0;
+      for (int64_t v = lo; v < hi; ++v) mine += counts[v] != 0 ? 1 : 0;
+      before = ns_block_scan(mine, sh, &W);
+    }
+    if (W == 0) { if (tid == 0) fail = 1; __syncthreads(); break; }      // fewer incident edges than picks asked for
+    const double x = u_vertex[i] * (double)W;
+    if (tid == 0) pick_v = -1;
+    __syncthreads();
+    if (mine > 0 && (double)before <= x && x < (double)(before + mine)) {
+      int64_t run = before;
+      for (int64_t v = lo; v < hi; ++v) {
+        run += uniform ? (counts[v] != 0 ? 1 : 0) : (int64_t)counts[v] * seen[v];
+        if ((double)run > x) { pick_v = v; break; }
+      }
+    }
+    __syncthreads();
+    const bool none = pick_v < 0;                           // u * W rounded up to W: take the last vertex with weight
+    __syncthreads();                                        // everybody has read pick_v before anybody changes it
+    if (none) {
+      long long cand = -1;
+      for (int64_t v2 = lo; v2 < hi; ++v2) if (uniform ? counts[v2] != 0 : (counts[v2] != 0 && seen[v2])) cand = v2;
+      if (cand >= 0) atomicMax((long long*)&pick_v, cand);
+    }
+    __syncthreads();
+    const int64_t v = pick_v;
+    const int32_t a0 = rowptr[v], deg = rowptr[v + 1] - a0;
+    // ---- the edge
+    if (tries) {                                            // replay: the reference's own sequence of tried slots
+      if (tid == 0) {
+        int64_t slot = -1;
+        while (try_pos < n_tries) {
+          const int64_t t = tries[try_pos++];
+          if (t < 0 || t >= deg) { fail = 2; break; }
+          if (!picked[adj_edge[a0 + t]]) { slot = t; break; }
+        }
+        if (slot < 0 && !fail) fail = 3;
+        pick_slot = slot;
+      }
+      __syncthreads();
+    } else {                                                // random: the k-th unpicked entry, k = floor(u2 * sample_counts[v])
+      int64_t k = (int64_t)(u_edge[i] * (double)counts[v]);
+      if (k >= counts[v]) k = counts[v] - 1;
+      const int64_t per = ((int64_t)deg + NS_THREADS - 1) / NS_THREADS;
+      const int64_t l2 = tid * per < deg ? tid * per : deg, h2 = l2 + per < deg ? l2 + per : deg;
+      int64_t free_mine = 0;
+      for (int64_t t = l2; t < h2; ++t) free_mine += picked[adj_edge[a0 + t]] ? 0 : 1;
+      int64_t tot;
+      const int64_t fb = ns_block_scan(free_mine, sh, &tot);
+      if (tid == 0) pick_slot = -1;
+      __syncthreads();
+      if (free_mine > 0 && fb <= k && k < fb + free_mine) {
+        int64_t run = fb;
+        for (int64_t t = l2; t < h2; ++t) {
+          if (!picked[adj_edge[a0 + t]]) { if (run == k) { pick_slot = t; break; } ++run; }
+        }
+      }
+      __syncthreads();
+      if (tid == 0 && pick_slot < 0) fail = 4;
+      __syncthreads();
+    }
+    if (fail) break;
+    if (tid == 0) {
+      const int32_t e = adj_edge[a0 + pick_slot], o = adj_other[a0 + pick_slot];
+      edges[i] = e;
+      picked[e] = 1;
+      seen[v] = 1;
+      counts[v] -= 1;
+      counts[o] -= 1;
+      seen[o] = 1;
+      status[0] = i + 1;
+      status[1] = try_pos;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && fail) status[2] = fail;
+}
+
 }  // namespace mrg
 
 using namespace mrg;
@@ -157,6 +298,35 @@ extern "C" int mrg_rank_filtered(const float* pred, const float* labels, const i
   if (B == 0) return MRG_OK;
   if (!pred || !labels || !obj || !ranks) return MRG_E_NULLPTR;
   hipLaunchKernelGGL(rank_filtered_k, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, pred, labels, obj, N, ranks);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+
+// Workspace: sample_counts int32 [N], seen uint8 [N], picked uint8 [T].
+extern "C" int64_t mrg_sample_neighborhood_workspace_bytes(int64_t N, int64_t T) {
+  if (N < 0 || T < 0) return 0;
+  return (int64_t)((((size_t)N * 4 + 255) & ~(size_t)255) + (((size_t)N + 255) & ~(size_t)255) + (((size_t)T + 255) & ~(size_t)255) + 256);
+}
+
+extern "C" int mrg_sample_edge_neighborhood(const int32_t* rowptr, const int32_t* adj_edge, const int32_t* adj_other, const int32_t* degrees,
+                                            int64_t N, int64_t T, int64_t sample_size, const double* u_vertex, const int64_t* tries,
+                                            int64_t n_tries, const double* u_edge, int32_t* edges, int64_t* status, void* ws, int64_t ws_bytes,
+                                            void* stream) {
+  if (N <= 0 || T < 0 || sample_size < 0 || n_tries < 0) return MRG_E_SHAPE;
+  if (!status) return MRG_E_NULLPTR;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(status, 0, 3 * sizeof(int64_t), st) != hipSuccess) return MRG_E_WORKSPACE;
+  if (sample_size == 0) return MRG_OK;
+  if (!rowptr || !adj_edge || !adj_other || !degrees || !u_vertex || !edges) return MRG_E_NULLPTR;
+  if (!tries && !u_edge) return MRG_E_NULLPTR;
+  if (!ws || ws_bytes < mrg_sample_neighborhood_workspace_bytes(N, T)) return MRG_E_WORKSPACE;
+  char* base = (char*)ws;
+  int32_t* counts = (int32_t*)base;
+  unsigned char* seen = (unsigned char*)(base + (((size_t)N * 4 + 255) & ~(size_t)255));
+  unsigned char* picked = seen + (((size_t)N + 255) & ~(size_t)255);
+  hipLaunchKernelGGL(sample_neighborhood_k, dim3(1), dim3(NS_THREADS), 0, st, rowptr, adj_edge, adj_other, degrees, N, T, sample_size, u_vertex,
+                     tries, n_tries, u_edge, edges, counts, seen, picked, status);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }

@@ -10,7 +10,8 @@ Everything integer runs in the HIP kernels of ``csrc/sampling.hip`` / ``csrc/pla
 draws come from torch's device generator (the reference uses numpy's global generator; bit-equal streams are not
 possible across generators), but every function takes the draws as optional arguments and is bit-exact with the
 reference for the same draws -- that is what the tests replay.  The neighbourhood-expansion sampler
-(utils_rgcn.py:30-71, inherently sequential, not the reference's default) is not provided.
+(``sample_edge_neighborhood``, utils_rgcn.py:30-71, ``--edge_sampler neighbor``) is ``sample_size`` dependent picks: one
+launch of one persistent workgroup (``mrg_sample_edge_neighborhood``) over an adjacency CSR in the reference's append order.
 """
 import numpy as np
 import torch
@@ -22,6 +23,65 @@ from ._lib import call, load, ptr, require_hip, stream_of
 def sample_edge_uniform(n_triplets, sample_size, device, generator=None):
     """`np.random.choice(n_triplets, sample_size, replace=False)` (reference utils/utils_rgcn.py:73-76)."""
     return torch.randperm(int(n_triplets), device=device, generator=generator)[: int(sample_size)]
+
+
+class AdjIndex:
+    """``get_adj_and_degrees`` (reference utils/utils_rgcn.py:18-28) resident in HBM: the adjacency lists in the reference's
+    append order (for triple i: ``[i, o]`` joins s's list, then ``[i, s]`` joins o's) as a CSR, plus the degrees."""
+
+    def __init__(self, num_nodes, triplets):
+        t = triplets.long()
+        T, dev = int(t.shape[0]), t.device
+        self.N, self.T = int(num_nodes), T
+        vert = torch.stack((t[:, 0], t[:, 2]), dim=1).reshape(-1)            # entry 2i: s's list, entry 2i + 1: o's list
+        other = torch.stack((t[:, 2], t[:, 0]), dim=1).reshape(-1)
+        eid = torch.arange(T, device=dev).repeat_interleave(2)
+        order = torch.sort(vert, stable=True).indices                        # stable: append order inside every list
+        self.adj_edge = eid[order].to(torch.int32).contiguous()
+        self.adj_other = other[order].to(torch.int32).contiguous()
+        deg = torch.bincount(vert, minlength=self.N)
+        self.degrees = deg.to(torch.int32).contiguous()
+        rowptr = torch.zeros(self.N + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(deg, 0)
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        G.settle(dev)
+
+
+def sample_edge_neighborhood(adj, sample_size, draws=None, generator=None):
+    """Reference utils/utils_rgcn.py:30-71: `sample_size` edges by neighbourhood expansion (the sampled edges form a connected
+    graph).  `adj`: AdjIndex.  `draws`: dict(u_vertex=float64 [sample_size], tries=int64 [n]) replays the reference's own draws
+    (the uniform behind every `np.random.choice(..., p=...)` and the sequence of adjacency slots it tried, rejected ones
+    included): bit-exact.  Without draws the uniforms come from torch's device generator and the edge of a vertex is ONE draw
+    among its unpicked entries (the reference's distribution without its rejection loop).  Returns int64 edge ids."""
+    dev = adj.rowptr.device
+    S = int(sample_size)
+    draws = draws or {}
+    u_vertex = draws.get("u_vertex")
+    u_vertex = (torch.rand(S, dtype=torch.float64, device=dev, generator=generator) if u_vertex is None
+                else torch.as_tensor(u_vertex).to(dev).double().contiguous())
+    tries = draws.get("tries")
+    u_edge = None
+    if tries is None:
+        u_edge = torch.rand(S, dtype=torch.float64, device=dev, generator=generator)
+    else:
+        tries = torch.as_tensor(tries).to(dev).long().contiguous()
+    if u_vertex.numel() != S:
+        raise ValueError(f"sample_edge_neighborhood needs {S} vertex draws, got {u_vertex.numel()}")
+    require_hip(adj.rowptr, u_vertex, tries, u_edge)
+    edges = torch.empty(S, dtype=torch.int32, device=dev)
+    status = torch.zeros(3, dtype=torch.int64, device=dev)
+    nb = load().mrg_sample_neighborhood_workspace_bytes(adj.N, adj.T)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    call("mrg_sample_edge_neighborhood", (ptr(adj.rowptr), ptr(adj.adj_edge), ptr(adj.adj_other), ptr(adj.degrees), adj.N, adj.T, S, ptr(u_vertex),
+                                          ptr(tries), int(tries.numel()) if tries is not None else 0, ptr(u_edge), ptr(edges), ptr(status),
+                                          ptr(ws), nb, stream_of(edges)))
+    made, used, code = (int(v) for v in status.tolist())
+    if code != 0 or made != S:
+        raise RuntimeError({1: "sample_edge_neighborhood: the graph has fewer incident edges than sample_size",
+                            2: "sample_edge_neighborhood: a replayed adjacency slot is out of range",
+                            3: "sample_edge_neighborhood: the replayed tries ran out"}.get(code, f"sample_edge_neighborhood failed (code {code})")
+                           + f" after {made} of {S} picks")
+    return edges.long()
 
 
 def negative_sampling(pos_samples, num_entity, negative_rate, values=None, choices=None, generator=None):
@@ -62,19 +122,27 @@ def relabel_nodes(src, dst, num_nodes):
 
 
 def generate_sampled_graph_and_labels(triplets, sample_size, split_size, num_rels, negative_rate, num_nodes, sampler="uniform",
-                                      draws=None, generator=None):
+                                      draws=None, generator=None, adj=None):
     """One search-step sample (reference utils/utils_rgcn.py:79-118).  `triplets` [T, 3] int64 on the device.
     Returns ``(g, uniq_v, src, rel, node_norm, samples, labels)`` like the reference, with ``g`` a RelGraph that
     already carries ``edata['e_type']`` and the edge norm ``edata['norm']`` [E, 1] (what the search driver computes
     next with node_norm_to_edge_norm, search/mr_lp_search.py:30-36,214), everything resident in HBM.
-    `draws`: optional dict(edges, values, choices, split) replaying the reference's four random draws."""
-    if sampler != "uniform":
-        raise ValueError("Sampler type must be 'uniform' (the neighbourhood sampler is sequential host code)")
+    `draws`: optional dict(edges, values, choices, split) replaying the reference's four random draws; with
+    sampler="neighbor" (reference :92-93) the edge draw is dict(u_vertex, tries) instead of `edges` (sample_edge_neighborhood)
+    and `adj` may carry a prebuilt AdjIndex of `triplets` (the reference builds its adjacency lists once per run)."""
+    if sampler not in ("uniform", "neighbor"):
+        raise ValueError("Sampler type must be either 'uniform' or 'neighbor'.")
     draws = draws or {}
     dev = triplets.device
     T = int(triplets.shape[0])
     pick = draws.get("edges")
-    pick = sample_edge_uniform(T, sample_size, dev, generator) if pick is None else torch.as_tensor(pick).to(dev).long()
+    if pick is not None:
+        pick = torch.as_tensor(pick).to(dev).long()
+    elif sampler == "uniform":
+        pick = sample_edge_uniform(T, sample_size, dev, generator)
+    else:
+        adj = adj if adj is not None else AdjIndex(num_nodes, triplets)
+        pick = sample_edge_neighborhood(adj, sample_size, {k: draws[k] for k in ("u_vertex", "tries") if k in draws} or None, generator)
     edges = triplets[pick].long()
     uniq_v, src, dst = relabel_nodes(edges[:, 0], edges[:, 2], num_nodes)
     rel = edges[:, 1].contiguous()

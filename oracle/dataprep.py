@@ -2,7 +2,8 @@
 hot path: negative sampling, node relabelling and the sampled step graph (reference utils/utils_rgcn.py:79-118, 191-204),
 the sr2o label sets and dense targets (reference utils/process_data.py:4-31, utils/data_set.py:15-33) and the filtered
 ranking of predict() (reference train/mr_lp_train.py:290-299).  Random draws are explicit arguments.  Pinned by
-tests/golden/sampling_small.npz and labels_ranking_small.npz, which were produced by running the reference itself."""
+tests/golden/sampling_small.npz, sampling_neighbor_*.npz and labels_ranking_small.npz, which were produced by running the
+reference itself."""
 import collections
 
 import numpy as np
@@ -23,6 +24,47 @@ def negative_sampling(pos, num_entity, rate, values, choices):
     neg[subj, 0] = values[subj]
     neg[obj, 2] = values[obj]
     return np.concatenate((pos, neg)), labels
+
+
+def adjacency(num_nodes, triplets):
+    # reference utils/utils_rgcn.py:18-28 (get_adj_and_degrees): per vertex the [triple id, other end] pairs in append order
+    adj = [[] for _ in range(num_nodes)]
+    for i, (s, _, o) in enumerate(np.asarray(triplets)):
+        adj[s].append((i, o))
+        adj[o].append((i, s))
+    return [np.asarray(a, dtype=np.int64).reshape(-1, 2) for a in adj], np.array([len(a) for a in adj])
+
+
+def sample_edge_neighborhood(adj, degrees, n_triplets, sample_size, u_vertex, tries):
+    """Reference utils/utils_rgcn.py:30-71 with its draws given: u_vertex[i] is the uniform behind the i-th
+    np.random.choice(n, p=probabilities) (legacy choice: searchsorted of the normalised cumsum, side='right'); `tries` the
+    adjacency slots its np.random.choice(np.arange(m)) calls returned, rejected ones included."""
+    counts = np.array([d for d in degrees])
+    picked = np.zeros(n_triplets, dtype=bool)
+    seen = np.zeros(len(degrees), dtype=bool)
+    edges = np.zeros(sample_size, dtype=np.int32)
+    t = 0
+    for i in range(sample_size):
+        w = counts * seen
+        if np.sum(w) == 0:
+            w = np.ones_like(w)
+            w[np.where(counts == 0)] = 0
+        p = w / np.sum(w)
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        v = int(cdf.searchsorted(u_vertex[i], side="right"))
+        seen[v] = True
+        e, o = adj[v][tries[t]]
+        t += 1
+        while picked[e]:
+            e, o = adj[v][tries[t]]
+            t += 1
+        edges[i] = e
+        picked[e] = True
+        counts[v] -= 1
+        counts[o] -= 1
+        seen[o] = True
+    return edges
 
 
 def sampled_graph_and_labels(triplets, sample_size, split_size, num_rels, negative_rate, draws):

@@ -570,6 +570,60 @@ def case_sampling(name, Nall, T, R, sample, neg, seed):
     print("wrote sampling_%s: n=%d samples=%d" % (name, len(uniq_v), len(samples)))
 
 
+def case_sampling_neighbor(name, Nall, T, R, sample, neg, seed):
+    """Reference utils/utils_rgcn.py:30-71 (`sampler="neighbor"`) with numpy's global generator seeded.  Its draws are adaptive
+    (a rejection loop per pick), so they are recorded by REPLAYING the loop with the same numpy calls after re-seeding: the
+    uniform behind every np.random.choice(n, p=...) (legacy choice draws one random_sample() and searches the normalised cumsum)
+    and every adjacency slot np.random.choice(np.arange(m)) tried (legacy choice without p = randint(0, m)).  The replay is
+    asserted to reproduce the reference's edges, then the remaining three draws are read off the same stream."""
+    import utils.utils_rgcn as ur
+    rng = np.random.default_rng(seed)
+    tri = make_triples(Nall, T, R, rng, dup=0)
+    adj, deg = ur.get_adj_and_degrees(Nall, tri)
+    np.random.seed(seed)
+    ref_edges = ur.sample_edge_neighborhood(adj, deg, len(tri), sample)
+    np.random.seed(seed)
+    with np.errstate(divide="ignore"):
+        g, uniq_v, src_o, rel, node_norm, samples, labels = ur.generate_sampled_graph_and_labels(tri, sample, 0.5, R, adj, deg, neg, "neighbor")
+    # ---- replay with recorded draws
+    np.random.seed(seed)
+    counts, picked, seen = deg.copy(), np.zeros(len(tri), bool), np.zeros(Nall, bool)
+    u_vertex, tries, edges = [], [], []
+    for i in range(sample):
+        w = counts * seen
+        if w.sum() == 0:
+            w = np.ones_like(w)
+            w[np.where(counts == 0)] = 0
+        p = w / np.sum(w)
+        u = np.random.random_sample()
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        v = int(cdf.searchsorted(u, side="right"))
+        u_vertex.append(u)
+        seen[v] = True
+        while True:
+            t = int(np.random.randint(0, adj[v].shape[0]))
+            tries.append(t)
+            e, o = adj[v][t]
+            if not picked[e]:
+                break
+        edges.append(e)
+        picked[e] = True
+        counts[v] -= 1
+        counts[o] -= 1
+        seen[o] = True
+    assert np.array_equal(np.asarray(edges), ref_edges), "the recorded replay does not reproduce the reference's neighbourhood sample"
+    values = np.random.randint(len(uniq_v), size=sample * neg)
+    choices = np.random.uniform(size=sample * neg)
+    split = np.random.choice(np.arange(sample), size=int(sample * 0.5), replace=False)
+    s_, d_, _ = g.edges(form="all")
+    st = {"Nall": Nall, "R": R, "sample": sample, "neg": neg, "triples": tri, "edges": ref_edges, "draw_u_vertex": np.asarray(u_vertex),
+          "draw_tries": np.asarray(tries, dtype=np.int64), "draw_values": values, "draw_choices": choices, "draw_split": split,
+          "uniq_v": uniq_v, "src_o": src_o, "rel": rel, "node_norm": node_norm, "samples": samples, "labels": labels, "g_src": s_, "g_dst": d_}
+    np.savez_compressed(os.path.join(OUT, f"sampling_neighbor_{name}.npz"), **npify(st))
+    print("wrote sampling_neighbor_%s: n=%d picks=%d tries=%d" % (name, len(uniq_v), sample, len(tries)))
+
+
 def _install_train_driver_standins():
     """train/mr_lp_train.py imports three modules this image (and, for `dataloader`, the reference itself) lacks;
     none of them is touched by predict()."""
@@ -659,6 +713,8 @@ def main():
     case_ops("r300_d64_search", 300, 2000, 11, 64, "search", 6, star_only=True, seeded_inputs=True, skip=("pre_mult", "pre_sub"))
     case_supernet("d200_sampled", 14541, 60000, 237, 200, 100, 475, 2, 300, 33, seeded_params=True)
     case_sampling("small", 400, 3000, 7, 200, 10, 51)
+    case_sampling_neighbor("small", 400, 3000, 7, 200, 10, 53)
+    case_sampling_neighbor("dense", 60, 900, 5, 600, 2, 54)        # two thirds of all triples: long rejection runs, exhausted vertices
     case_labels_and_ranking("small", 150, 1200, 5, 64, 52)
 
 

@@ -32,6 +32,54 @@ def test_sampled_step_graph_matches_reference_draw_for_draw():
     assert torch.equal(s2.cpu(), z["ns_samples"]) and torch.equal(l2.cpu(), z["ns_labels"])
 
 
+@pytest.mark.parametrize("name", ["small", "dense"])
+def test_neighborhood_sampler_matches_reference_draw_for_draw(name):
+    """sample_edge_neighborhood (reference utils/utils_rgcn.py:30-71, `--edge_sampler neighbor`) in one launch of one persistent
+    workgroup: with the reference's own draws replayed (the uniform of every vertex pick, every adjacency slot it tried) the picked
+    edges and the whole sampled step graph are bit-identical with the reference's; `dense` picks two thirds of all triples
+    (long rejection runs, exhausted vertices, the all-ones restart of the weights)."""
+    z = load_golden("sampling_neighbor_" + name)
+    tri = z["triples"].to(DEV)
+    adj = SM.AdjIndex(z["Nall"], tri)
+    edges = SM.sample_edge_neighborhood(adj, z["sample"], {"u_vertex": z["draw_u_vertex"], "tries": z["draw_tries"]})
+    assert torch.equal(edges.cpu(), z["edges"].long())
+    draws = {"u_vertex": z["draw_u_vertex"], "tries": z["draw_tries"], "values": z["draw_values"], "choices": z["draw_choices"], "split": z["draw_split"]}
+    g, uniq_v, src_o, rel, node_norm, samples, labels = SM.generate_sampled_graph_and_labels(
+        tri, z["sample"], 0.5, z["R"], z["neg"], z["Nall"], sampler="neighbor", draws=draws, adj=adj)
+    assert torch.equal(uniq_v.cpu(), z["uniq_v"]) and torch.equal(src_o.cpu(), z["src_o"]) and torch.equal(rel.cpu(), z["rel"])
+    assert torch.equal(node_norm.cpu(), z["node_norm"])
+    assert torch.equal(samples.cpu(), z["samples"]) and torch.equal(labels.cpu(), z["labels"])
+    s, d, _ = g.edges(form="all")
+    assert torch.equal(s.cpu(), z["g_src"]) and torch.equal(d.cpu(), z["g_dst"])
+    # replayed tries that run out / point outside a list are reported, not read
+    with pytest.raises(RuntimeError):
+        SM.sample_edge_neighborhood(adj, z["sample"], {"u_vertex": z["draw_u_vertex"], "tries": z["draw_tries"][:5]})
+
+
+def test_neighborhood_sampler_with_device_draws_expands_a_neighbourhood():
+    """Without replayed draws (torch's device generator, one draw per edge pick among the vertex's unpicked entries): picks are
+    distinct triples, and every pick after a restart-free prefix touches a vertex that an earlier pick has seen -- the sample is
+    connected, which is the point of the scheme; also through generate_sampled_graph_and_labels at the driver's sizes."""
+    from mr_gnas_amd import synth
+    n, r, t = synth.SHAPES["fb15k237"]
+    tri = torch.from_numpy(synth.synth_kg(n, r, t, 0)).to(DEV)
+    adj = SM.AdjIndex(n, tri)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    for sample in (300, 3000):
+        e = SM.sample_edge_neighborhood(adj, sample, generator=gen)
+        assert e.numel() == sample and torch.unique(e).numel() == sample and int(e.min()) >= 0 and int(e.max()) < t
+        picked = tri[e].cpu().numpy()
+        seen = {int(picked[0, 0]), int(picked[0, 2])}
+        for s_, _, o_ in picked[1:]:
+            assert int(s_) in seen or int(o_) in seen           # connected growth (FB15k-237's giant component: no restart)
+            seen.update((int(s_), int(o_)))
+    g, uniq_v, src_o, rel, node_norm, samples, labels = SM.generate_sampled_graph_and_labels(tri, 3000, 0.5, r, 10, n, sampler="neighbor",
+                                                                                             generator=gen, adj=adj)
+    assert samples.shape == (11 * 3000, 3) and g.num_edges() == 3000 and g.number_of_nodes() == int(uniq_v.numel())
+    with pytest.raises(ValueError):
+        SM.generate_sampled_graph_and_labels(tri, 300, 0.5, r, 10, n, sampler="random-walk")
+
+
 def test_sampler_with_device_draws_has_the_reference_properties():
     """With torch's device generator (no numpy stream to replay): the scheme's invariants at the search driver's
     default and large sizes."""

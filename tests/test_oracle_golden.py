@@ -178,6 +178,15 @@ def test_data_preparation_oracle_matches_reference():
     s2, l2 = OD.negative_sampling(z["ns_pos"].numpy(), z["ns_num_entity"], 3, z["ns_values"].numpy(), z["ns_choices"].numpy())
     assert np.array_equal(s2, z["ns_samples"].numpy()) and np.array_equal(l2, z["ns_labels"].numpy())
 
+    for name in ("small", "dense"):                 # the neighbourhood-expansion sampler (utils_rgcn.py:30-71), draws replayed
+        z = load_golden("sampling_neighbor_" + name)
+        adj, deg = OD.adjacency(z["Nall"], z["triples"].numpy())
+        edges = OD.sample_edge_neighborhood(adj, deg, len(z["triples"]), z["sample"], z["draw_u_vertex"].numpy(), z["draw_tries"].numpy())
+        assert np.array_equal(edges, z["edges"].numpy())
+        draws = {"edges": edges, "values": z["draw_values"].numpy(), "choices": z["draw_choices"].numpy(), "split": z["draw_split"].numpy()}
+        g, uniq_v, src_o, rel, node_norm, samples, labels = OD.sampled_graph_and_labels(z["triples"].numpy(), z["sample"], 0.5, z["R"], z["neg"], draws)
+        assert np.array_equal(uniq_v, z["uniq_v"].numpy()) and np.array_equal(samples, z["samples"].numpy()) and torch.equal(g.src, z["g_src"])
+
     z = load_golden("labels_ranking_small")
     tr = OD.sr2o(z["train"].numpy(), z["R"])
     al = OD.sr2o(torch.cat((z["train"], z["valid"], z["test"])).numpy(), z["R"])
