@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fb15k237_supernet_full",
                     choices=["fb15k237_supernet_full", "fb15k237_supernet_30k", "fb15k237_supernet_300", "wn18rr_supernet_full",
-                             "fb15k237_fixed_d64"])
+                             "fb15k237_fixed_d64", "c5_fixed_cell"])
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--negative", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,16 +200,18 @@ class FixedStep:
     train/mr_lp_train.py:215-266): full training graph (un-sorted halves), feature_dim = init_fea_dim = 64, num_base_r = 23,
     batch 256, DistMult [B, N] scorer + BCELoss on label-smoothed dense targets (device LabelIndex), Adam."""
 
-    def __init__(self, args, device):
+    def __init__(self, args, device, shape="fb15k237", dim=64, init_dim=64, nbase=23):
+        """shape "synthetic10m" (BASELINE config 5: 10 M edges, 1 M nodes, 512 relation ids, D = 256) is SURVEY 8(d)'s
+        single-cell stress: the same README-genotype step at the largest single-GPU configuration (`--workload c5_fixed_cell`)."""
         from mr_gnas_amd import graph as G, sampler as SM, supernet as S, synth
-        N, R, T = synth.SHAPES["fb15k237"]
+        N, R, T = synth.SHAPES[shape]
         tri = synth.synth_kg(N, R, T, args.seed)
         torch.manual_seed(args.seed)
         self.g = G.build_train_graph(N, R, tri, device=device)
         self.E = self.g.num_edges()
         geno = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2), ('a_max', 5, 3),
                                        ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)], concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
-        self.model = S.FixedNetwork(device, geno, N, R, 64, 64, 23, dropout_cell=0.3, drop_aggr=0.1).to(device)
+        self.model = S.FixedNetwork(device, geno, N, R, dim, init_dim, nbase, dropout_cell=0.3, drop_aggr=0.1).to(device)
         S.xavier_init_(self.model)
         self.model.train()
         self.opt = torch.optim.Adam(self.model.parameters(), 1e-3)
@@ -451,6 +453,10 @@ def main():
         args.dim = 64
         step = FixedStep(args, device)
         barrier = lambda: None
+    elif args.workload == "c5_fixed_cell":
+        args.dim = 256
+        step = FixedStep(args, device, shape="synthetic10m", dim=256, init_dim=64, nbase=64)
+        barrier = lambda: None
     else:
         step = Step(args, device, build_step_inputs(args.workload, args.negative, args.seed))
         barrier = lambda: None
@@ -573,11 +579,13 @@ def main():
         out["hbm_bound_total"] = {"ms_per_step": round(tot_ms, 3), "achieved": round(tot_b / tot_ms, 1), "unit": "GB/s",
                                   "frac": round(tot_b / tot_ms / HBM_PEAK_GBS, 4), "frac_achievable": round(tot_b / tot_ms / HBM_ACHIEVABLE_GBS, 4)}
     out["kernels"] = table
-    fixed = args.workload == "fb15k237_fixed_d64"
+    fixed = args.workload in ("fb15k237_fixed_d64", "c5_fixed_cell")
     if fixed:
-        out["metric"] = "million edges/sec per fixed-genotype train step (FB15k-237, dim=64, batch 256)"
+        out["metric"] = ("million edges/sec per fixed-genotype train step (FB15k-237, dim=64, batch 256)" if args.workload == "fb15k237_fixed_d64"
+                         else "million edges/sec per fixed-genotype train step (synthetic KG 10M edges / 1M nodes / 512 relations, dim=256, batch 256)")
         out["config"]["layers"] = 1
         out["config"]["step"] = "fixed README genotype fwd + DistMult [B,N] + BCE + bwd + Adam"
+        out["config"]["hbm_peak_GiB"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
     if world == 1 and not sharded and not args.exact_f32 and not args.no_exact_f32_leg and not args.hip_graph and not fixed:
         # the same step with every GEMM on the exact-f32 MFMA pipe (v_mfma_f32_32x32x2_f32), next to the headline number
         lib.mrg_gemm_set_mode(1)
@@ -591,7 +599,7 @@ def main():
         lib.mrg_gemm_set_mode(0)
         out["exact_f32"] = {"ms_per_step": round(ms, 3), "value": round(E_total / ms / 1e3, 4), "unit": "M edges/s",
                             "matrix_core": "exact f32 MFMA (v_mfma_f32_32x32x2_f32) for every GEMM"}
-    if world == 1 and not sharded:
+    if world == 1 and not sharded and args.workload != "c5_fixed_cell":
         log("timing the fused compose+scatter kernel (north-star kernel) on the benchmark graph")
         out["north_star_kernel"] = north_star_kernel(step.g, args.dim, tag=args.workload.split("_")[0])
         if not args.no_c5:

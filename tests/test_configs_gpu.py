@@ -485,3 +485,106 @@ def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
         gt = torch.sigmoid(cat @ W.detach().double().t() + b.detach().double())
         gb += (go[sl].double() * s.detach()[sl].double() * gt * (1 - gt)).sum(0)
     assert float((b.grad.double() - gb).abs().max()) <= 1e-3 * max(1.0, float(gb.abs().max()))
+
+
+def test_c5_fixed_cell_readme_genotype(c5):
+    """SURVEY 8(d), config 5's single-cell stress: the README genotype's cell (reference README.md:26, models/model_lp.py:59-74)
+    forward + backward at E = 10 M, N = 1 M, D = 256 on one GPU -- every [M, D] tensor holds 2.8e9 elements (> 2^31).  Each of
+    its operators (pre_sub, f_sparse_comp, a_max, f_sparse_last) is checked against float64 on a row / destination sample from
+    the HIP inputs it actually received; the backward runs through autograd over the whole cell (every parameter gradient
+    finite and non-trivial) and the input gradient of the f_sparse_comp rows and of the a_max edge rows is checked on the sample."""
+    from oracle import ops as OO
+    D = 256
+    g, N, E, gen = c5["g"], c5["N"], c5["E"], c5["gen"]
+    M = E + N
+    src, dst, _ = g.edges(form="all")
+    geno = S.Genotype(alpha_cell=[("pre_sub", 1, 0), ("f_sparse_comp", 2, 1), ("f_sparse_comp", 3, 2), ("a_max", 4, 2), ("a_max", 5, 3),
+                                  ("f_sparse_last", 6, 5), ("f_sparse_last", 7, 5)], concat_node=[4, 5, 6, 7], score_func="sf_DisMult")
+    torch.manual_seed(2)
+    cell = S.FixedCell(D, 0.0, geno).to(DEV)
+    S.xavier_init_(cell)
+    cell.train()
+    x = torch.randn(M, D, device=DEV, generator=gen).requires_grad_(True)
+    hr = torch.randn(M, D, device=DEV, generator=gen)
+    keep = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            keep[name] = (inp[1], inp[2], out)
+            if out.requires_grad:
+                out.retain_grad()
+        return f
+    mods = {"pre_sub": cell._ops[0][0][0].op, "gate1": cell._ops[1][1][0].op, "amax": cell._ops[3][2][0].op, "last": cell._ops[5][5][0].op}
+    hs = [m.register_forward_hook(hook(k)) for k, m in mods.items()]
+    out = cell(g, x, hr)
+    for h_ in hs:
+        h_.remove()
+    assert out.shape == (N, D) and bool(torch.isfinite(out).all())
+    rows = torch.cat((torch.arange(0, 1024, device=DEV), torch.arange(M - 1024, M, device=DEV), torch.arange(E - 512, E + 512, device=DEV),
+                      torch.randint(0, M, (4096,), device=DEV, generator=gen)))
+    b0, b1 = g.bounds()
+    norm = g.norm_flat()
+
+    # pre_sub and f_sparse_comp: row-wise operators -> float64 on the sampled rows
+    a, b, got = keep["pre_sub"]
+    assert torch.equal(got[rows], a[rows] - b[rows])
+    a, b, got = keep["gate1"]
+    P = {k: v.detach().double() for k, v in mods["gate1"].state_dict().items()}
+
+    def gate_rows(a_, b_, r):
+        o = torch.empty(r.numel(), D, dtype=torch.float64, device=DEV)
+        for nm, m_ in (("in", r < b0), ("out", (r >= b0) & (r < b1)), ("self", r >= b1)):
+            if bool(m_.any()):
+                cat = torch.cat((a_[r[m_]].double(), b_[r[m_]].double()), 1)
+                z = (cat @ P[f"W_{nm}.weight"].t() + P[f"W_{nm}.bias"]) @ P[f"a_{nm}.weight"].t()
+                c = (norm[r[m_]].double().view(-1, 1) if nm != "self" else 1.0) / 3.0
+                o[m_] = torch.sigmoid(z) * a_[r[m_]].double() * c
+        return o
+    ref = gate_rows(a.detach(), b.detach(), rows)
+    assert rel_err(got.detach()[rows], ref) <= 1e-4, f"C5 cell f_sparse_comp: {rel_err(got.detach()[rows], ref):.3e}"
+
+    # a_max: destinations sampled, all their in-edges
+    a, _, got = keep["amax"]
+    nodes = torch.unique(torch.cat((torch.randint(0, N, (2048,), device=DEV, generator=gen), torch.bincount(dst, minlength=N).topk(16).indices)))
+    lut = torch.full((N,), -1, dtype=torch.long, device=DEV)
+    lut[nodes] = torch.arange(nodes.numel(), device=DEV)
+    eids = torch.nonzero(lut[dst] >= 0).view(-1)
+    Pm = {k: v.detach().double() for k, v in mods["amax"].state_dict().items()}
+    msg = torch.relu(a.detach()[eids].double() @ Pm["linear.weight"].t() + Pm["linear.bias"])
+    ref = torch.zeros(nodes.numel(), D, dtype=torch.float64, device=DEV).scatter_reduce(0, lut[dst[eids]].view(-1, 1).expand(-1, D), msg, "amax",
+                                                                                         include_self=False) + a.detach()[E + nodes].double()
+    assert rel_err(got.detach()[nodes], ref) <= 1e-4, f"C5 cell a_max: {rel_err(got.detach()[nodes], ref):.3e}"
+
+    # f_sparse_last on node rows
+    a, _, got = keep["last"]
+    Pl = {k: v.detach().double() for k, v in mods["last"].state_dict().items()}
+    nr = torch.randint(0, N, (4096,), device=DEV, generator=gen)
+    z = (a.detach()[nr].double() @ Pl["W.weight"].t() + Pl["W.bias"]) @ Pl["a.weight"].t()
+    assert rel_err(got.detach()[nr], torch.sigmoid(z) * a.detach()[nr].double()) <= 1e-4
+
+    # backward through the whole cell
+    gout = torch.randn(N, D, device=DEV, generator=gen)
+    out.backward(gout)
+    torch.cuda.synchronize()
+    for k, p in cell.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    assert float(x.grad.abs().max()) > 0 and bool(torch.isfinite(x.grad[rows]).all())
+    del keep, out, x, hr, gout
+    cell.zero_grad(set_to_none=True)
+    free()
+    # input gradient of f_sparse_comp at this size (row-wise -> float64 autograd on the sampled rows, same upstream gradient rows)
+    s = torch.randn(M, D, device=DEV, generator=gen).requires_grad_(True)
+    s_in = torch.randn(M, D, device=DEV, generator=gen).requires_grad_(True)
+    gM = torch.randn(M, D, device=DEV, generator=gen)
+    mods["gate1"](g, s, s_in).backward(gM)
+    a64, b64 = s.detach()[rows].double().requires_grad_(True), s_in.detach()[rows].double().requires_grad_(True)
+    o = torch.zeros(rows.numel(), D, dtype=torch.float64, device=DEV)
+    for nm, m_ in (("in", rows < b0), ("out", (rows >= b0) & (rows < b1)), ("self", rows >= b1)):
+        if bool(m_.any()):
+            zz = (torch.cat((a64[m_], b64[m_]), 1) @ P[f"W_{nm}.weight"].t() + P[f"W_{nm}.bias"]) @ P[f"a_{nm}.weight"].t()
+            c = (norm[rows[m_]].double().view(-1, 1) if nm != "self" else 1.0) / 3.0
+            o[m_] = torch.sigmoid(zz) * a64[m_] * c
+    o.backward(gM[rows].double())
+    assert rel_err(s.grad[rows], a64.grad) <= 1e-4 and rel_err(s_in.grad[rows], b64.grad) <= 1e-4
+    del s, s_in, gM
+    free()
