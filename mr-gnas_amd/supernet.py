@@ -57,7 +57,11 @@ def _xavier_param(*shape):
 # ---------------------------------------------------------------------------
 # supernet
 # ---------------------------------------------------------------------------
-MIXED_STREAMS = int(os.environ.get("MRG_MIXED_STREAMS", "4"))   # HIP streams the candidates of a MixedOp are spread over
+# HIP streams the candidates of a MixedOp are spread over.  Rounds 1-2 ran them on four: the one-wave row GEMM owns a CU's whole
+# register file, and other candidates' kernels filled its tails (71.4 -> 69.9 ms/step).  With the LDS-weight row GEMM (two
+# workgroups per CU) the step is the same on one stream as on four (62.3 / 62.8 vs 62.3 / 62.8 ms, profiles/r3_streams.txt), so the
+# default is ONE: no event traffic, no cross-stream allocator bookkeeping; 2-4 remain available.
+MIXED_STREAMS = int(os.environ.get("MRG_MIXED_STREAMS", "1"))
 
 
 class MixedOp(nn.Module):
