@@ -262,7 +262,11 @@ int mrg_mix_finalize_bwd(const float *red, int K, double total_rows, int D, floa
 int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *gy_host, int K,
                       const float *coef, const float *coef2, const float *w, const float *const *rs, const float *rs_scale,
                       const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *fold_s,
-                      const float *const *fold_gate, float *const *fold_gs, int64_t rows, int D, void *stream);
+                      const float *const *fold_gate, float *const *fold_gs, const int *fold_add_from, int64_t rows, int D,
+                      void *stream);
+/* fold_add_from (HOST array of K ints, NULL = none): for a gated candidate k (rs_on[k] == 2), the index q of the candidate
+ * whose OUTPUT is k's operand s (f_identity of the same MixedOp: y_host[q] == fold_s[k]); its gradient gy_q is added to
+ * fold_gs[k] and gy_host[q] may be NULL -- both are gradients w.r.t. the same rows. */
 
 /* ---- Cell zero: the MixedOp over the compose candidates, recomputed from the tables ---------------------------------------------
  * reference models/cell_lp.py:53-68 (Cell_Zero: ONE MixedOp over PRE_OPS), :25-33 (MixedOp.forward / op_forward),

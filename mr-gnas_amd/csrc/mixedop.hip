@@ -19,8 +19,11 @@ struct MutPack { float* p[MRG_MIX_MAXK]; };
 // gy_k[r] *= r < edge_rows[k] ? scale[k] * (rs[k] ? rs[k][r] : 1) : self_scale[k]      when on[k]
 // on[k] == 2: the gated form (f_dense_comp, mrg_dense_filter_dz kind 0): with gc = gy * c, the candidate's gradient buffer receives
 // dz = gc * s * gate * (1 - gate) and gs_out[k] the direct term gc * gate of the gradient w.r.t. s.
+// add_from[k] (gated candidates only, -1 = none): the index of ANOTHER candidate whose own gradient gy is ADDED to gs_out[k] instead
+// of being stored -- f_identity of the same MixedOp: its output IS the operand s of candidate k, so both are gradients w.r.t. the
+// same rows and the state's fan-in sum would add them anyway (one [rows, D] write here and one read there less).
 struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK];
-                      const float* s[MRG_MIX_MAXK]; const float* gate[MRG_MIX_MAXK]; float* gs_out[MRG_MIX_MAXK]; };
+                      const float* s[MRG_MIX_MAXK]; const float* gate[MRG_MIX_MAXK]; float* gs_out[MRG_MIX_MAXK]; int add_from[MRG_MIX_MAXK]; };
 
 // ---- column statistics: sums[k][0][c] = sum_r y_k[r][c], sums[k][1][c] = sum_r y_k[r][c]^2 (float64)
 template <int VEC, int LPR, int KMAX>
@@ -334,8 +337,18 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
   }
   __syncthreads();
   float wk[MRG_MIX_MAXK];
+  bool need[MRG_MIX_MAXK];                                 // gy_k is wanted: stored, or added into a gated candidate's gs_out
 #pragma unroll
-  for (int k = 0; k < MRG_MIX_MAXK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+    wk[k] = k < K ? w[k] : 0.f;
+    need[k] = k < K && gys.p[k] != nullptr;
+  }
+#pragma unroll
+  for (int k = 0; k < MRG_MIX_MAXK; ++k)
+    if (k < K && rsp.on[k] == 2 && rsp.add_from[k] >= 0) {
+#pragma unroll
+      for (int q = 0; q < MRG_MIX_MAXK; ++q) if (q == rsp.add_from[k]) need[q] = true;
+    }
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
@@ -346,23 +359,30 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           vin[k] = Vec<VEC>::fill(0.f);
-          if (k < K && gys.p[k] != nullptr && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+          if (k < K && need[k] && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
         }
+        Vec<VEC> ov[MRG_MIX_MAXK];                         // every wanted gy_k first: a gated candidate may add another one's
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
-          if (k < K && gys.p[k] != nullptr) {
+          ov[k] = Vec<VEC>::fill(0.f);
+          if (k < K && need[k]) {
             const Vec<VEC> v = vin[k];
             const float* cf = lds + k * 6 * D + c * VEC;
             const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D),
                            c3 = Vec<VEC>::load(cf + 3 * D), c4 = Vec<VEC>::load(cf + 4 * D), c5 = Vec<VEC>::load(cf + 5 * D);
-            Vec<VEC> o;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
               float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
-              o[j] = (gr - c4[j] - xh * c5[j]) * c0[j];
+              ov[k][j] = (gr - c4[j] - xh * c5[j]) * c0[j];
             }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          if (k < K && gys.p[k] != nullptr) {
+            Vec<VEC> o = ov[k];
             if (rsp.on[k]) {                               // the consumer's first backward pass (mrg_dense_filter_dz) folded into this store
               const float ck = r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k];
               if (rsp.on[k] == 2) {                        // f_dense_comp: same expressions, same order as dense_dz_k<.., 0>
@@ -373,6 +393,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
                   const float gc = o[j] * ck;
                   o2[j] = gc * ga[j];
                   o[j] = gc * sv[j] * ga[j] * (1.0f - ga[j]);
+                }
+                const int af = rsp.add_from[k];
+                if (af >= 0) {                             // + the gradient of the candidate whose output IS this one's operand s
+#pragma unroll
+                  for (int q = 0; q < MRG_MIX_MAXK; ++q)
+                    if (q == af) {
+#pragma unroll
+                      for (int j = 0; j < VEC; ++j) o2[j] += ov[q][j];
+                    }
                 }
                 o2.store(rsp.gs_out[k] + r * D + c * VEC);
               } else {                                     // f_comp: dz = g * c
@@ -845,7 +874,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
                                  const float* coef2, const float* w, const float* const* rs_host, const float* rs_scale_host,
                                  const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host,
                                  const float* const* fold_s_host, const float* const* fold_gate_host, float* const* fold_gs_host,
-                                 int64_t rows, int D, void* stream) {
+                                 const int* fold_add_from_host, int64_t rows, int D, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
@@ -861,6 +890,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
   }
   if (!any) return MRG_OK;
   RowScalePack rsp{};
+  for (int k = 0; k < MRG_MIX_MAXK; ++k) rsp.add_from[k] = -1;
   if (rs_on_host) {
     if (!rs_scale_host || !rs_self_host || !rs_edge_rows_host) return MRG_E_NULLPTR;
     for (int k = 0; k < K; ++k) {
@@ -870,6 +900,12 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
       if (rsp.on[k] == 2) {
         if (!fold_s_host || !fold_gate_host || !fold_gs_host || !fold_s_host[k] || !fold_gate_host[k] || !fold_gs_host[k]) return MRG_E_NULLPTR;
         rsp.s[k] = fold_s_host[k]; rsp.gate[k] = fold_gate_host[k]; rsp.gs_out[k] = fold_gs_host[k];
+        if (fold_add_from_host && fold_add_from_host[k] >= 0) {
+          const int q = fold_add_from_host[k];
+          if (q >= K || q == k || !y_host[q] || y_host[q] != rsp.s[k]) return MRG_E_SHAPE;      // only a candidate whose OUTPUT is this one's operand s
+          rsp.add_from[k] = q;
+          any = true;
+        }
         al = al && aligned16(rsp.s[k]) && aligned16(rsp.gate[k]) && aligned16(rsp.gs_out[k]);
       } else if (rsp.on[k] != 0 && rsp.on[k] != 1) {
         return MRG_E_ENUM;

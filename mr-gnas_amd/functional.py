@@ -880,8 +880,9 @@ class _MixCfg:
     """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
     updated in place like torch does), which branches are all-zero, sharding info."""
 
-    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None):
+    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None, identity=None):
         self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
+        self.identity = identity       # index of the candidate that returns its input unchanged (f_identity), or None
         self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self, gated node | None, node): folded into its gradient
 
 
@@ -964,12 +965,24 @@ class _MixedEpilogue(torch.autograd.Function):
             coef2.zero_()
         if red_local is not red:                      # sharded: parameter / alpha gradients stay local partial sums
             dw = red_local[:, 2].sum(dim=1)
-        need_y = ctx.needs_input_grad[2:2 + nz]
+        need_y = list(ctx.needs_input_grad[2:2 + nz])
+        rs = cfg.rowscale
+        # f_identity's output IS the operand s of the gated candidate (f_dense_comp) of the same MixedOp: its gradient is added into
+        # that candidate's direct term inside the apply kernel instead of being written and re-read by the state's fan-in sum
+        add_from = None
+        if (FOLD_IDENTITY and cfg.identity is not None and cfg.present[cfg.identity] and rs is not None):
+            pos = sum(cfg.present[:cfg.identity])
+            for k in range(K_):
+                if (rs[k] is not None and rs[k][4] is not None and need_y[pos] and k != cfg.identity
+                        and rs[k][4].saved_tensors[0].data_ptr() == ys[cfg.identity].data_ptr()
+                        and rs[k][4].saved_tensors[0].shape == ys[cfg.identity].shape):
+                    add_from = (k, cfg.identity)
+                    need_y[pos] = False                    # no gradient tensor of its own: None flows back to the alias
+                    break
         gys_nz = [torch.empty_like(y) if nd else None for y, nd in zip(ys_nz, need_y)]
         it = iter(gys_nz)
         gys = [next(it) if p else None for p in cfg.present]
         n_out = sum(t is not None for t in gys_nz)
-        rs = cfg.rowscale
         if rs is not None and any(r is not None for r in rs):
             import ctypes
             on = (ctypes.c_int * K_)(*[int(r is not None) for r in rs])
@@ -991,11 +1004,12 @@ class _MixedEpilogue(torch.autograd.Function):
                     rs[k][4].gs_direct = f_gs[k]
             f_gs_p = ptr_array(f_gs)
             n_fold = sum(gated)
+            f_add = (ctypes.c_int * K_)(*[(add_from[1] if (add_from is not None and k == add_from[0]) else -1) for k in range(K_)])
         else:
-            on = rs_ptr = rs_edge = rs_scale = rs_self = f_s = f_gate = f_gs_p = None
+            on = rs_ptr = rs_edge = rs_scale = rs_self = f_s = f_gate = f_gs_p = f_add = None
             n_fold = 0
         call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
-                                   f_s, f_gate, f_gs_p, rows, D, st),
+                                   f_s, f_gate, f_gs_p, f_add, rows, D, st),
              nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold))
         if rs is not None:
             for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
@@ -1006,7 +1020,10 @@ class _MixedEpilogue(torch.autograd.Function):
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
 
 
-def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_row_scales=False):
+FOLD_IDENTITY = os.environ.get("MRG_FOLD_IDENTITY", "1") == "1"     # lab switch: 0 = f_identity's gradient stays a tensor of its own
+
+
+def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_row_scales=False, identity=None):
     """addend + sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
     all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine); addend: the output of the MixedOp this
     one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel."""
@@ -1022,7 +1039,7 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
                 # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node; [6] which of its outputs y is
                 rowscale[k] = spec[:4] + (node if spec[4] else None, node, spec[5])
                 node.prescaled[spec[5]] = True
-    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale)
+    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale, identity)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)
 

@@ -117,7 +117,8 @@ class MixedOp(nn.Module):
                     ys.append(paired[k])
                 else:
                     ys.append(op(g, fh.take(), fi.take()))
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
+            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True,
+                                    identity=self._identity_index())
         fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
         for k, (op, _, _) in enumerate(self._ops):
@@ -142,8 +143,13 @@ class MixedOp(nn.Module):
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
-        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
+        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True,
+                                identity=self._identity_index())
 
+
+    def _identity_index(self):
+        ids = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_identity_op]
+        return ids[0] if len(ids) == 1 else None
 
     def _dense_pair(self, x):
         """(index of f_dense_comp, index of f_comp) when both are candidates of this MixedOp and may share a node, else None."""

@@ -710,8 +710,9 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
     S.xavier_init_(mixed)
     res = {}
     try:
-        for pair in (True, False):
-            K.DENSE_PAIR = pair
+        for pair in (True, False, "no identity fold", "neither"):
+            K.DENSE_PAIR = pair in (True, "no identity fold")
+            K.FOLD_IDENTITY = pair in (True, False)          # f_identity's gradient added into f_dense_comp's direct term / a tensor of its own
             mixed.zero_grad(set_to_none=True)
             h = h0.clone().to(DEV).requires_grad_(True)
             hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
@@ -721,7 +722,8 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
             torch.cuda.synchronize()
             res[pair] = [out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
     finally:
-        K.DENSE_PAIR = True
-    assert torch.equal(res[True][0], res[False][0])
-    for i, (a, b) in enumerate(zip(res[True][1:], res[False][1:])):
-        close(a, b.cpu(), f"dense pair gradient {i}", rtol=3e-5, atol=3e-5 * max(1.0, float(b.abs().max())))
+        K.DENSE_PAIR, K.FOLD_IDENTITY = True, True
+    for other in (False, "no identity fold", "neither"):
+        assert torch.equal(res[True][0], res[other][0])
+        for i, (a, b) in enumerate(zip(res[True][1:], res[other][1:])):
+            close(a, b.cpu(), f"dense pair gradient {i} vs {other}", rtol=3e-5, atol=3e-5 * max(1.0, float(b.abs().max())))
