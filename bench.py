@@ -37,7 +37,7 @@ MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (same guide; not the 2:1-spa
 MFMA_SPLIT_PEAK_TFS = round(MFMA_BF16_PEAK_TFS / 6, 1)
 MATRIX_CORE = {"mode": 0}
 MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight", "mrg_dense_filter_fwd", "mrg_linear_bwd_input2",
-              "mrg_dense_filter_fwd3", "mrg_linear_bwd_input3", "mrg_linear_bwd_weight3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd",
+              "mrg_dense_filter_fwd3", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_linear_bwd_weight3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd",
               "mrg_linear_relu_segreduce_fwd"}
 # Entry points whose algorithmic bytes are row gathers from tables that stay resident in L2 / Infinity Cache at the
 # benchmark shapes (11.6 MB entity table, 0.4 MB relation table): pricing those bytes against HBM gave "fractions"
@@ -48,7 +48,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # the guide's measured float4 copy rate: what an H
 # eight entry-point names, so "the entry point with the largest time" (rounds 1-2) named the wrong kernel.  `roofline` is the
 # family with the largest summed time: its summed algorithmic work / its summed time.
 KERNEL_FAMILIES = {
-    "row_gemm [rowgemm_x3s_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_dense_filter_fwd",
+    "row_gemm [rowgemm_x3s_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
                                  "mrg_dense_filter_fwd3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd"],
     "weight_gradient [wgrad_x3_k]": ["mrg_linear_bwd_weight", "mrg_linear_bwd_weight3"],
     "mixedop_epilogue [mix_colstats_k mix_fwd_k mix_bwd_reduce_k mix_bwd_apply_k]": [

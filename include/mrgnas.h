@@ -197,7 +197,7 @@ int mrg_fused_gcs(int mode, const float *X, const int32_t *xi, const float *Y, c
  * ext_scal (NULL ok): when given, meta.w is an element index and the scale is ext_scal[meta.w]
  * (per-call scales, e.g. upstream gradients, without rebuilding the packed metadata). */
 int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, const float *ext_scal, int64_t E, int span,
-                 const int32_t *span_slot, int64_t n_spans,
+                 const int32_t *span_slot, const int32_t *span_start, int64_t n_spans,
                  const int32_t *hub_seg, const int32_t *hub_first, const int32_t *hub_count, int64_t n_hubs,
                  int64_t n_slots, const int32_t *seg_len,
                  float *out, void *ws, int64_t nseg, int D, void *stream);
@@ -277,8 +277,9 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
  *   g_ent_rows[r] = sum_k gy_k * d y_k / d ent-row,   g_rel_rows[r] = sum_k gy_k * d y_k / d rel-row
  * which two mrg_span_gcs(COPY) launches turn into the table gradients.  The entry points mirror mrg_mix_colstats /
  * mrg_mix_stats_coef / mrg_mix_fwd / mrg_mix_bwd_reduce / mrg_mix_bwd_apply (same workspaces, same coef / red / coef2 layouts,
- * mrg_mix_finalize_fwd / _bwd in between, statistics may be all-reduced when the rows are sharded); coefficients, output and
- * every gy_k are bit-identical with the stored form.  ops: HOST array of K codes. */
+ * mrg_mix_finalize_fwd / _bwd in between, statistics may be all-reduced when the rows are sharded; ws: mrg_zero_workspace_bytes(D)).
+ * Same values as the stored form; the statistics are summed over more, smaller blocks (their order differs in the last bits).  ops: HOST array of K codes. */
+int64_t mrg_zero_workspace_bytes(int D);      /* ws of mrg_zero_colstats / _stats_coef / _bwd_reduce (up to 2048 blocks of partials) */
 int mrg_zero_colstats(const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx, const int *ops, int K,
                       int64_t rows, int D, double *sums, void *ws, void *stream);
 int mrg_zero_stats_coef(const float *ent, const float *rel, const int32_t *ent_idx, const int32_t *rel_idx, const int *ops, int K,
@@ -444,10 +445,15 @@ int mrg_build_graph(const int64_t *triples, int64_t T, int64_t N, int R, int sor
  * 2 * n_spans + nseg, counts [2] = {n_hubs, n_slots} (device memory; the host reads it once).  Same results as the
  * tensor formulation it replaces (mr-gnas_amd/graph.py:span_plan), which stays as the test's cross-check. */
 int64_t mrg_plan_workspace_bytes(int64_t E, int64_t nseg, int span);
-int mrg_span_plan_build(const int32_t *seg, int64_t E, int64_t nseg, int span,
-                        int32_t *perm, int32_t *seg_sorted, int32_t *seg_len, int32_t *span_slot,
+int mrg_span_plan_build(const int32_t *seg, int64_t E, int64_t nseg, int span, int snap,
+                        int32_t *perm, int32_t *seg_sorted, int32_t *seg_len, int32_t *span_slot, int32_t *span_start,
                         int32_t *hub_seg, int32_t *hub_first, int32_t *hub_count, int32_t *counts,
                         void *ws, int64_t ws_bytes, void *stream);
+/* span_start [n_spans + 1] (ABI 8): span i covers sorted elements [span_start[i], span_start[i + 1]).  A cut is nominally
+ * i * span; where that position falls inside a segment it moves to the nearer end of that segment if that is at most `snap`
+ * (0 .. span / 4; 0 = fixed spans) elements away, so segments up to 2 * snap long are never split over spans (no partial runs,
+ * workspace slots or hub-pass work for them) and every span stays within +- 2 * snap of the nominal length.  The last span may
+ * be empty. */
 /* meta[j] = {seg_sorted[j], xi[perm[j]] (perm[j] if xi NULL), yi[perm[j]] (0 if NULL), w} with w = float bits of
  * scal[perm[j]] (1.0f if scal NULL), or perm[j] itself when w_is_index != 0 (external per-call scales). */
 int mrg_span_meta_pack(const int32_t *perm, const int32_t *seg_sorted, const int32_t *xi, const int32_t *yi,

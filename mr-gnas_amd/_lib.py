@@ -49,13 +49,14 @@ SIGNATURES = {
     "mrg_seg_reduce_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_seg_reduce_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
-    "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
+    "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_sum_buffers": (_I, [_P, _I, _P, _L, _I, _P]),
     "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
     "mrg_mix_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
+    "mrg_zero_workspace_bytes": (_L, [_I]),
     "mrg_zero_colstats": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
     "mrg_zero_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
     "mrg_zero_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
@@ -92,7 +93,7 @@ SIGNATURES = {
     "mrg_build_graph_workspace_bytes": (_L, [_L]),
     "mrg_build_graph": (_I, [_P, _L, _L, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mrg_plan_workspace_bytes": (_L, [_L, _L, _I]),
-    "mrg_span_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mrg_span_plan_build": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "mrg_span_meta_pack": (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "mrg_chunk_plan_workspace_bytes": (_L, [_L, _L]),
     "mrg_chunk_plan_build": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),

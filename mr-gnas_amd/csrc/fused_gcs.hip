@@ -244,7 +244,8 @@ template <int VEC, int LPR, int KMAX, int MODE, int UOVR = 0>
 __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict__ X, const float* __restrict__ Y,
                                                         const int4* __restrict__ meta, const float* __restrict__ ext_scal,
                                                         int64_t E, int span, const int32_t* __restrict__ span_slot,
-                                                        int64_t n_spans, float* __restrict__ out, float* __restrict__ ws_val, int D) {
+                                                        const int32_t* __restrict__ span_start, int64_t n_spans, float* __restrict__ out,
+                                                        float* __restrict__ ws_val, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
   // elements whose row gathers are in flight per lane group.  UOVR (sub mode on big inputs): 6 instead of 8 -- measured on the
   // C5 shape (10 M elements, 1 GB table, D = 256) 2.13 ms against 2.42 ms, while the cache-resident FB15k-237 shape prefers 8
@@ -254,8 +255,10 @@ __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict_
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
   for (int64_t sp = (int64_t)blockIdx.x * RPB + rw; sp < n_spans; sp += (int64_t)gridDim.x * RPB) {
-    const int64_t start = sp * span;
-    const int64_t end = start + span < E ? start + span : E;
+    // spans cut at segment ends (mrg_span_plan_build's span_start): only segments longer than a span leave partial runs
+    const int64_t start = span_start ? span_start[sp] : sp * span;
+    const int64_t end = span_start ? span_start[sp + 1] : (start + span < E ? start + span : E);
+    if (start >= end) continue;                           // an empty span (the last cut moved to E)
     const int slot_first = span_slot[2 * sp], slot_last = span_slot[2 * sp + 1];
     Vec<VEC> acc[KMAX];
 #pragma unroll
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict_
 }  // namespace mrg
 
 extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void* meta, const float* ext_scal, int64_t E, int span,
-                            const int32_t* span_slot, int64_t n_spans, const int32_t* hub_seg, const int32_t* hub_first,
+                            const int32_t* span_slot, const int32_t* span_start, int64_t n_spans, const int32_t* hub_seg, const int32_t* hub_first,
                             const int32_t* hub_count, int64_t n_hubs, int64_t n_slots, const int32_t* seg_len, float* out,
                             void* ws, int64_t nseg, int D, void* stream) {
   if (mode != MRG_GCS_SUB && mode != MRG_GCS_MUL && mode != MRG_GCS_COPY && mode != MRG_GCS_NEGS) return MRG_E_ENUM;
@@ -341,14 +344,14 @@ extern "C" int mrg_span_gcs(int mode, const float* X, const float* Y, const void
   if (!g.ok) return MRG_E_SHAPE;
   const int4* m4 = (const int4*)meta;
 #define LAUNCH(V, L, K, M)                                                                                              \
-  hipLaunchKernelGGL((span_gcs_k<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, n_spans, out, ws_val, D)
+  hipLaunchKernelGGL((span_gcs_k<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, span_start, n_spans, out, ws_val, D)
 #define CALL(V, L, K)                                                                                                  \
   do {                                                                                                                 \
     int grid = grid_for(n_spans, MRG_BLOCK / L);                                                                       \
     if (E > 0 && n_spans > 0) switch (mode) {                                                                          \
       case MRG_GCS_SUB:                                                                                                \
         if (E >= ((int64_t)1 << 22))                                                                                   \
-          hipLaunchKernelGGL((span_gcs_k<V, L, K, MRG_GCS_SUB, 6>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, n_spans, out, ws_val, D); \
+          hipLaunchKernelGGL((span_gcs_k<V, L, K, MRG_GCS_SUB, 6>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, Y, m4, ext_scal, E, span, span_slot, span_start, n_spans, out, ws_val, D); \
         else LAUNCH(V, L, K, MRG_GCS_SUB);                                                                             \
         break;                                                                                                         \
       case MRG_GCS_MUL: LAUNCH(V, L, K, MRG_GCS_MUL); break;                                                           \

@@ -937,6 +937,20 @@ static int zero_src(ZeroSrc* z, const float* ent, const float* rel, const int32_
   return MRG_OK;
 }
 
+// The recomputing reductions gather two table rows per row through an index (a dependent load chain per row): they are
+// latency-bound per wave and want MORE blocks than the flat statistics kernels (512): up to 2048, which is what the
+// workspace (mrg_zero_workspace_bytes) is sized for.  Measured at FB15k-237, D = 200: statistics 307 -> see profiles/r3_cell_zero.txt.
+static int zero_grid(int64_t rows, int lpr) {
+  int64_t b = (rows + (MRG_BLOCK / lpr) * 8 - 1) / ((MRG_BLOCK / lpr) * 8);
+  if (b < 1) b = 1;
+  return (int)(b > 2048 ? 2048 : b);
+}
+
+extern "C" int64_t mrg_zero_workspace_bytes(int D) {
+  if (D <= 0) return 0;
+  return (int64_t)2048 * ZK * 3 * D * sizeof(double);
+}
+
 static int zero_colstats_blocks(const ZeroSrc& z, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out) {
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (!ws) return MRG_E_WORKSPACE;
@@ -945,7 +959,7 @@ static int zero_colstats_blocks(const ZeroSrc& z, int64_t rows, int D, void* ws,
   int grid = 1;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    grid = mix_grid(rows, L);                                                                             \
+    grid = zero_grid(rows, L);                                                                             \
     hipLaunchKernelGGL((zero_colstats_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), 0, st, z, rows, D, (double*)ws); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
@@ -1034,7 +1048,7 @@ extern "C" int mrg_zero_bwd_reduce(const float* g, const float* ent, const float
   int grid = 1;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    grid = mix_grid(rows, L);                                                                             \
+    grid = zero_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
     hipLaunchKernelGGL((zero_bwd_reduce_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, z, coef, w, (float*)ws, rows, D); \

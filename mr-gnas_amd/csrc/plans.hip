@@ -72,10 +72,35 @@ __global__ void set_i32_k(int32_t* p, int32_t v) { *p = v; }
 
 // flags of the first / last run of every span (graph.span_plan): a run is partial when its segment does not lie
 // wholly inside the span
-__global__ void span_flags_k(const int32_t* __restrict__ seg_s, const int32_t* __restrict__ segptr, int64_t E, int span, int64_t n_spans,
-                             int32_t* __restrict__ flags, int32_t* __restrict__ runseg) {
+// Cut i between spans i-1 and i (graph.span_plan_torch has the same rule): nominally i * span; when that position falls INSIDE a
+// segment, the cut moves to the NEARER end of that segment if it is at most `snap` (<= span / 4) elements away -- segments up to 2 * snap long
+// are then never split over spans (no partial runs, no workspace slots, no hub-pass work for them) while every span keeps
+// between 1/2 and 3/2 of the nominal length (balance).  Cuts stay strictly increasing (a move is < span / 2); only the LAST cut
+// may reach E, which leaves the last span empty.
+__device__ __forceinline__ int64_t span_cut(const int32_t* __restrict__ seg_s, const int32_t* __restrict__ segptr, int64_t E, int span,
+                                           int snap, int64_t n_spans, int64_t i) {
+  if (i <= 0) return 0;
+  if (i >= n_spans) return E;
+  const int64_t p = i * span, lim = snap;
+  if (lim <= 0) return p;
+  const int s = seg_s[p - 1];
+  const int64_t b = segptr[s], e = segptr[s + 1];
+  if (e <= p) return p;                                     // already a segment boundary
+  const int64_t fwd = e - p, bwd = p - b;
+  if (fwd <= bwd) return fwd <= lim ? e : p;
+  return bwd <= lim ? b : p;
+}
+__global__ void span_flags_k(const int32_t* __restrict__ seg_s, const int32_t* __restrict__ segptr, int64_t E, int span, int snap, int64_t n_spans,
+                             int32_t* __restrict__ flags, int32_t* __restrict__ runseg, int32_t* __restrict__ span_start) {
   for (int64_t sp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sp < n_spans; sp += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t start = sp * span, end = start + span < E ? start + span : E;
+    const int64_t start = span_cut(seg_s, segptr, E, span, snap, n_spans, sp), end = span_cut(seg_s, segptr, E, span, snap, n_spans, sp + 1);
+    span_start[sp] = (int32_t)start;
+    if (sp == n_spans - 1) span_start[n_spans] = (int32_t)E;
+    if (start >= end) {                                     // the last cut moved to E (the last segment is short): an empty span, no runs
+      flags[2 * sp] = 0; flags[2 * sp + 1] = 0;
+      runseg[2 * sp] = -1; runseg[2 * sp + 1] = -1;
+      continue;
+    }
     const int f = seg_s[start], l = seg_s[end - 1];
     const bool fp = (segptr[f] < start) || (segptr[f + 1] > end);
     const bool lp = (l != f) && (segptr[l + 1] > end);
@@ -242,12 +267,12 @@ extern "C" int64_t mrg_plan_workspace_bytes(int64_t E, int64_t nseg, int span) {
 
 // hub_seg is filled with -1 over its whole capacity (2 * n_spans + nseg) first: a consumer may launch with the CAPACITY as
 // the hub count (no device-to-host read of `counts`), the hub pass skips negative entries.
-extern "C" int mrg_span_plan_build(const int32_t* seg, int64_t E, int64_t nseg, int span, int32_t* perm, int32_t* seg_sorted,
-                                   int32_t* seg_len, int32_t* span_slot, int32_t* hub_seg, int32_t* hub_first, int32_t* hub_count,
-                                   int32_t* counts, void* ws, int64_t ws_bytes, void* stream) {
-  if (E < 0 || nseg < 0 || span < 1) return MRG_E_SHAPE;
+extern "C" int mrg_span_plan_build(const int32_t* seg, int64_t E, int64_t nseg, int span, int snap, int32_t* perm, int32_t* seg_sorted,
+                                   int32_t* seg_len, int32_t* span_slot, int32_t* span_start, int32_t* hub_seg, int32_t* hub_first,
+                                   int32_t* hub_count, int32_t* counts, void* ws, int64_t ws_bytes, void* stream) {
+  if (E < 0 || nseg < 0 || span < 1 || snap < 0 || snap > span / 4) return MRG_E_SHAPE;
   if (!counts || (nseg > 0 && !seg_len)) return MRG_E_NULLPTR;
-  if (E > 0 && (!seg || !perm || !seg_sorted || !span_slot)) return MRG_E_NULLPTR;
+  if (E > 0 && (!seg || !perm || !seg_sorted || !span_slot || !span_start)) return MRG_E_NULLPTR;
   if (nseg > 0 && (!hub_seg || !hub_first || !hub_count)) return MRG_E_NULLPTR;
   if (!ws || ws_bytes < mrg_plan_workspace_bytes(E, nseg, span)) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -284,7 +309,7 @@ extern "C" int mrg_span_plan_build(const int32_t* seg, int64_t E, int64_t nseg, 
   if (E > 0) {
     tb = tmp_bytes;
     MRG_HIP(rocprim::radix_sort_pairs(tmp, tb, seg, seg_sorted, (const int32_t*)iota, perm, (size_t)E, 0, bits_for((uint64_t)(nseg - 1)), st));
-    hipLaunchKernelGGL(span_flags_k, dim3(blocks_for(n_spans)), dim3(256), 0, st, seg_sorted, segptr, E, span, n_spans, flags, runseg);
+    hipLaunchKernelGGL(span_flags_k, dim3(blocks_for(n_spans)), dim3(256), 0, st, seg_sorted, segptr, E, span, snap, n_spans, flags, runseg, span_start);
     tb = tmp_bytes;
     MRG_HIP(rocprim::exclusive_scan(tmp, tb, flags, slot_id, 0, (size_t)cap, rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(span_slots_k, dim3(blocks_for(cap)), dim3(256), 0, st, flags, slot_id, runseg, cap, span_slot, slot_seg, n_slots);

@@ -773,7 +773,8 @@ def span_gcs(mode, X, Y, meta, plan, ext_scal=None):
     ws = _ws(_ws_bytes("mrg_seg_reduce_workspace_bytes", n_slots, D), X) if n_slots > 0 else None
     rows_y = Y.shape[0] if Y is not None else 0
     nb = E * (8 + 4 * D) + 4 * (nseg + 1) + 4 * D * (rows_y + nseg)
-    call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), ptr(ext_scal), E, plan["span"], ptr(plan["span_slot"]), plan["n_spans"],
+    call("mrg_span_gcs", (GCS[mode], ptr(X), ptr(Y), ptr(meta), ptr(ext_scal), E, plan["span"], ptr(plan["span_slot"]), ptr(plan.get("span_start")),
+                          plan["n_spans"],
                           ptr(plan["hub_seg"]), ptr(plan["hub_first"]), ptr(plan["hub_count"]), n_hubs, n_slots,
                           ptr(plan["seg_len"]), ptr(out), ptr(ws), nseg, D, stream_of(X)), nbytes=nb)
     return out
@@ -1077,7 +1078,7 @@ class _CellZeroMixed(torch.autograd.Function):
         src = (ptr(ent), ptr(rel), ptr(gp_e.idx32), ptr(gp_r.idx32), opc, K_)
         gathered = rows * (8 * D + 8)
         if training:
-            ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), ent)
+            ws = _ws(_ws_bytes("mrg_zero_workspace_bytes", D), ent)
             track = bn0.track_running_stats
             rm = ptr_array([b.running_mean if track else None for b in bns])
             rv = ptr_array([b.running_var if track else None for b in bns])
@@ -1115,7 +1116,7 @@ class _CellZeroMixed(torch.autograd.Function):
         rows, D = g.shape
         dev, st = g.device, stream_of(g)
         src = (ptr(ent), ptr(rel), ptr(gp_e.idx32), ptr(gp_r.idx32), ctx.opc, K_)
-        ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
+        ws = _ws(_ws_bytes("mrg_zero_workspace_bytes", D), g)
         red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
         call("mrg_zero_bwd_reduce", (ptr(g), *src, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, st), nbytes=4 * D * rows)
         red_local = red

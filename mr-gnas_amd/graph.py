@@ -212,7 +212,24 @@ def auto_span(E, nseg):
     return max(SPAN_ELEMS, int(min(E / nseg / 8, E / 8192, 8 * SPAN_ELEMS)) // 32 * 32)
 
 
-def span_plan(seg, nseg, span=None):
+SPAN_SNAP = os.environ.get("MRG_SPAN_SNAP")          # lab: fixed cut displacement bound (0 = fixed spans)
+
+
+def auto_snap(E, nseg, span):
+    """How far a span cut may move to reach a segment boundary (span_cut in csrc/plans.hip).  Moving cuts removes the partial runs of
+    short segments (no workspace slots, no hub-pass work for them) but unbalances the spans; measured (profiles/r3_north_star_spans.txt):
+    where the segments are short (C5: 5 elements on average) it pays, 2.24 -> 2.14 ms; where they are long enough that cuts move
+    far (FB15k-237: 19 on average, moves up to 24) it costs, 91 -> 101 us.  So: segments of up to ~2 average lengths are kept whole,
+    never more than span / 4 of displacement, and nothing when the average segment is longer than span / 8."""
+    if SPAN_SNAP is not None:
+        return min(int(SPAN_SNAP), span // 4)
+    avg = E / max(nseg, 1)
+    if avg > span / 8:
+        return 0
+    return int(min(span // 4, max(1, round(avg))))
+
+
+def span_plan(seg, nseg, span=None, snap=None):
     """Plan for mrg_span_gcs (include/mrgnas.h): elements sorted by segment, cut into spans of
     `span` consecutive sorted elements.  Only the first / last run of a span can be a partial
     segment; those get consecutive workspace slots (numbered in span order, so the slots of one
@@ -220,49 +237,64 @@ def span_plan(seg, nseg, span=None):
     builder (mrg_span_plan_build: histogram -> scan -> stable sort -> marking kernels), CPU tensors through the
     tensor formulation span_plan_torch."""
     span = auto_span(int(seg.numel()), int(nseg)) if span is None else span
+    snap = auto_snap(int(seg.numel()), int(nseg), span) if snap is None else min(int(snap), span // 4)
     if _hip_ready(seg):
-        return _hip_span_plan(seg, nseg, span)
-    return span_plan_torch(seg, nseg, span)
+        return _hip_span_plan(seg, nseg, span, snap)
+    return span_plan_torch(seg, nseg, span, snap)
 
 
-def _hip_span_plan(seg, nseg, span):
+def _hip_span_plan(seg, nseg, span, snap):
     from ._lib import call, load, ptr, stream_of
     dev, E, nseg = seg.device, int(seg.numel()), int(nseg)
     s32 = (seg if seg.dtype == torch.int32 else seg.to(torch.int32)).contiguous()
     n_spans = (E + span - 1) // span
     i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
-    perm, seg_s, seg_len, span_slot = i32(E), i32(E), i32(nseg), i32(2 * n_spans)
+    perm, seg_s, seg_len, span_slot, span_start = i32(E), i32(E), i32(nseg), i32(2 * n_spans), i32(n_spans + 1)
     cap = 2 * n_spans + nseg
     hs, hf, hc = i32(cap), i32(cap), i32(cap)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     nb = load().mrg_plan_workspace_bytes(E, nseg, int(span))
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
-    call("mrg_span_plan_build", (ptr(s32), E, nseg, int(span), ptr(perm), ptr(seg_s), ptr(seg_len), ptr(span_slot), ptr(hs), ptr(hf), ptr(hc),
-                                 ptr(counts), ptr(ws), nb, stream_of(seg)))
+    if E == 0:
+        span_start.zero_()
+    call("mrg_span_plan_build", (ptr(s32), E, nseg, int(span), int(snap), ptr(perm), ptr(seg_s), ptr(seg_len), ptr(span_slot), ptr(span_start), ptr(hs),
+                                 ptr(hf), ptr(hc), ptr(counts), ptr(ws), nb, stream_of(seg)))
     return _Plan({"perm": perm[:E], "seg_sorted": seg_s[:E], "seg_len": seg_len[:nseg], "span": int(span), "n_spans": int(n_spans),
-                  "span_slot": span_slot, "hub_seg": hs, "hub_first": hf, "hub_count": hc, "E": E, "nseg": nseg,
+                  "span_slot": span_slot, "span_start": span_start[:n_spans + 1], "hub_seg": hs, "hub_first": hf, "hub_count": hc, "E": E, "nseg": nseg,
                   "cap_hubs": cap, "cap_slots": 2 * n_spans},
                  counts, ("n_hubs", "n_slots"))
 
 
-def span_plan_torch(seg, nseg, span=None):
+def span_plan_torch(seg, nseg, span=None, snap=None):
     """The tensor formulation of the span plan (pure torch ops; any device)."""
     dev = seg.device
     seg = seg.long()
     E, nseg = int(seg.numel()), int(nseg)
     span = auto_span(E, nseg) if span is None else span
+    snap = auto_snap(E, nseg, span) if snap is None else min(int(snap), span // 4)
     perm = torch.argsort(seg, stable=True)
     seg_s = seg[perm]
     seg_len = torch.bincount(seg, minlength=nseg)
     segptr = torch.zeros(nseg + 1, dtype=torch.long, device=dev)
     segptr[1:] = torch.cumsum(seg_len, 0)
     n_spans = (E + span - 1) // span
-    start = torch.arange(n_spans, device=dev) * span
-    end = torch.clamp(start + span, max=E)
+    # cuts between spans: nominally i * span; a cut that falls inside a segment moves to the nearer end of that segment when it is at
+    # most `snap` elements away (segments up to 2 * snap long are never split) -- the rule of span_cut in csrc/plans.hip
+    cuts = torch.arange(n_spans + 1, device=dev) * span
+    cuts[-1:] = E
+    if n_spans > 1 and snap > 0:
+        p = cuts[1:-1]
+        s_ = seg_s[p - 1]
+        b_, e_ = segptr[s_], segptr[s_ + 1]
+        fwd, bwd, lim = e_ - p, p - b_, snap
+        moved = torch.where(fwd <= bwd, torch.where(fwd <= lim, e_, p), torch.where(bwd <= lim, b_, p))
+        cuts[1:-1] = torch.where(e_ <= p, p, moved)
+    start, end = cuts[:-1], cuts[1:]
     if n_spans:
-        f, l = seg_s[start], seg_s[end - 1]
-        f_part = (segptr[f] < start) | (segptr[f + 1] > end)
-        l_part = (l != f) & (segptr[l + 1] > end)
+        live = end > start                                  # the last cut may have moved to E: an empty span, no runs
+        f, l = seg_s[torch.clamp(start, max=max(E - 1, 0))], seg_s[torch.clamp(end - 1, min=0)]
+        f_part = live & ((segptr[f] < start) | (segptr[f + 1] > end))
+        l_part = live & (l != f) & (segptr[l + 1] > end)
     else:
         f = l = torch.zeros(0, dtype=torch.long, device=dev)
         f_part = l_part = torch.zeros(0, dtype=torch.bool, device=dev)
@@ -283,7 +315,7 @@ def span_plan_torch(seg, nseg, span=None):
     hub_first = torch.cat((hub_first, torch.zeros_like(empty)))
     i32 = lambda t: t.to(torch.int32).contiguous()
     return {"perm": perm, "seg_sorted": i32(seg_s), "seg_len": i32(seg_len), "span": int(span), "n_spans": int(n_spans),
-            "span_slot": i32(span_slot), "hub_seg": i32(hub_seg), "hub_first": i32(hub_first), "hub_count": i32(hub_count),
+            "span_slot": i32(span_slot), "span_start": i32(cuts), "hub_seg": i32(hub_seg), "hub_first": i32(hub_first), "hub_count": i32(hub_count),
             "n_hubs": int(hub_seg.numel()), "n_slots": int(slot_seg.numel()), "E": E, "nseg": nseg}
 
 

@@ -111,22 +111,27 @@ def supernet_case(ds, D, negative):
 
 # full-size gradient bound relative to a tensor's largest entry (f32 step against the float64 oracle over 5.6e5 rows).  The
 # measured margins of every tensor are written to gpurun_out/parity_margins.json (kept: profiles/r3_parity_margins.json).
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 2e-3       # per tensor (worst measured without a ReLU / arg-max flip: 2.0e-3, a_max linear.weight); flips: the outlier clause below
+GRAD_MEDIAN = 2.5e-4   # over the tensors of a step: 2x the measured median (C3: 1.1e-4)
+GRAD_P90 = 1e-3        # ... and 2x the measured 90th percentile (C3: 4.8e-4)
+ALPHA_RTOL = 5e-4      # architecture-parameter gradients: measured <= 1.2e-4
+OUT_RTOL = 1e-5        # outputs and loss: measured <= 1.8e-6 (north_star asks for 1e-4)
 
 
 def check_step(hip, ref, what):
     from conftest import record_margin
     assert np.isfinite(hip["loss"])
     for nm in ("ent", "rel"):
-        record_margin(what, "output " + nm, rel_err(hip[nm], ref[nm]), 1.0, 1e-4)
-    record_margin(what, "loss", abs(hip["loss"] - ref["loss"]), max(1.0, abs(ref["loss"])), 1e-4 * max(1.0, abs(ref["loss"])))
-    assert rel_err(hip["ent"], ref["ent"]) <= 1e-4, f"{what}: ent {rel_err(hip['ent'], ref['ent']):.3e}"
-    assert rel_err(hip["rel"], ref["rel"]) <= 1e-4, f"{what}: rel"
-    assert abs(hip["loss"] - ref["loss"]) <= 1e-4 * max(1.0, abs(ref["loss"])), f"{what}: loss {hip['loss']} vs {ref['loss']}"
+        record_margin(what, "output " + nm, rel_err(hip[nm], ref[nm]), 1.0, OUT_RTOL)
+    record_margin(what, "loss", abs(hip["loss"] - ref["loss"]), max(1.0, abs(ref["loss"])), OUT_RTOL * max(1.0, abs(ref["loss"])))
+    # north_star's bound is 1e-4; measured at full size (profiles/r3_parity_margins.json): outputs 1.6-1.8e-6, loss 2-4e-7 -> held to 1e-5
+    assert rel_err(hip["ent"], ref["ent"]) <= OUT_RTOL, f"{what}: ent {rel_err(hip['ent'], ref['ent']):.3e}"
+    assert rel_err(hip["rel"], ref["rel"]) <= OUT_RTOL, f"{what}: rel"
+    assert abs(hip["loss"] - ref["loss"]) <= OUT_RTOL * max(1.0, abs(ref["loss"])), f"{what}: loss {hip['loss']} vs {ref['loss']}"
     for i, (a, b) in enumerate(zip(hip["ga"], ref["ga"])):
         err, scale = grad_err(a, b)
-        record_margin(what, f"alpha grad {i}", err, scale, GRAD_RTOL * max(scale, 1e-8) + 1e-7)
-        assert err <= GRAD_RTOL * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i}: {err:.3e} (scale {scale:.3e})"
+        record_margin(what, f"alpha grad {i}", err, scale, ALPHA_RTOL * max(scale, 1e-8) + 1e-7)
+        assert err <= ALPHA_RTOL * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i}: {err:.3e} (scale {scale:.3e})"
     bad, table = [], []
     for k, b in ref["g"].items():
         err, scale = grad_err(hip["g"][k], b)
@@ -143,6 +148,14 @@ def check_step(hip, ref, what):
         outliers = float((d > tol).double().mean())
         if not (outliers <= 0.005 and err <= 2e-2 * max(scale, 1e-6)):
             bad.append(f"{k}: {err:.3e} (scale {scale:.3e}, {outliers:.2%} of entries beyond tolerance)")
+    # the distribution over the tensors with a real gradient (max |g| > 1e-4) is held to 2x what was measured, so a regression INSIDE
+    # the per-tensor bound shows: measured median 5e-5 .. 1.1e-4, 90th percentile 3.0e-4 .. 4.8e-4 (C2 / C4 / C3)
+    rels = sorted(r for r, _, scale, _ in table if scale > 1e-4)
+    if len(rels) >= 20:
+        med, p90 = rels[len(rels) // 2], rels[int(0.9 * len(rels))]
+        record_margin(what, "gradients: median relative error", med, 1.0, GRAD_MEDIAN)
+        record_margin(what, "gradients: 90th percentile relative error", p90, 1.0, GRAD_P90)
+        assert med <= GRAD_MEDIAN and p90 <= GRAD_P90, f"{what}: gradient error distribution median {med:.2e} p90 {p90:.2e}"
     table.sort(reverse=True)
     print(f"{what}: worst relative gradient errors: " + "; ".join(f"{k} {r:.2e}" for r, _, _, k in table[:8]))
     assert not bad, f"{what}: {len(bad)} parameter gradients off: " + " | ".join(bad[:12])

@@ -154,7 +154,7 @@ def test_library_is_not_older_than_its_sources():
     assert os.path.getmtime(_lib.LIB_PATH) >= newest, "libmrgnas_hip.so is older than its sources: run __graft_entry__.build()"
 
 
-@pytest.mark.parametrize("span", [1, 4, 64])
+@pytest.mark.parametrize("span", [1, 4, 64, 7, 33])
 def test_span_plan_emulation(span):
     """Emulate mrg_span_gcs on the CPU from the plan alone and compare with index_add."""
     rng = np.random.default_rng(span)
@@ -162,7 +162,8 @@ def test_span_plan_emulation(span):
     seg = torch.from_numpy(rng.integers(0, nseg - 4, size=E))          # last segments stay empty
     seg[:200] = 3                                                        # a hub spanning many spans
     x = torch.randn(E, D, dtype=torch.float64)
-    p = G.span_plan(seg, nseg, span=span)
+    snap = span // 4
+    p = G.span_plan(seg, nseg, span=span, snap=snap)
     meta = G.span_meta(p, torch.arange(E), None, None)
     assert meta.shape == (E, 4) and meta.dtype == torch.int32
     assert torch.equal(meta[:, 0], p["seg_sorted"]) and torch.all(meta[1:, 0] >= meta[:-1, 0])
@@ -170,8 +171,19 @@ def test_span_plan_emulation(span):
     out = torch.zeros(nseg, D, dtype=torch.float64)
     ws = torch.zeros(max(p["n_slots"], 1), D, dtype=torch.float64)
     written = torch.zeros(nseg, dtype=torch.long)
+    cuts = p["span_start"].tolist()
+    assert cuts[0] == 0 and cuts[-1] == E and all(x < y for x, y in zip(cuts, cuts[1:-1])) and cuts[-2] <= cuts[-1]   # only the LAST span may be empty
+    # a cut is nominal (i * span) or moved by at most snap (= span / 4 here) to a segment boundary; no segment of length <= 2 * snap is ever split
+    segptr = np.concatenate(([0], np.cumsum(np.bincount(seg.numpy(), minlength=nseg))))
+    for i, c in enumerate(cuts[1:-1], start=1):
+        assert abs(c - i * span) <= snap and (c == i * span or c in segptr)
+    for v in range(nseg):
+        if 0 < segptr[v + 1] - segptr[v] <= 2 * snap:
+            assert not any(segptr[v] < c < segptr[v + 1] for c in cuts), f"segment {v} of length <= span / 2 is split"
     for sp in range(p["n_spans"]):
-        a, b = sp * span, min((sp + 1) * span, E)
+        a, b = cuts[sp], cuts[sp + 1]
+        if a >= b:
+            continue
         sf, sl_ = int(p["span_slot"][2 * sp]), int(p["span_slot"][2 * sp + 1])
         acc, cur, first = torch.zeros(D, dtype=torch.float64), int(meta[a, 0]), True
 

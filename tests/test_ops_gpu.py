@@ -659,10 +659,13 @@ def test_cell_zero_recompute_matches_the_stored_candidates(N, E, R, D, train):
     finally:
         K.CELL_ZERO_FUSED = True
     a, b = res[True], res[False]
-    assert torch.equal(a["out"], b["out"]) and torch.equal(a["w"], b["w"])
+    # same values; the recomputing statistics / gradient reductions sum over more blocks than the stored form's (order of the
+    # float64 / float32 partial sums): equal to rounding, not bit for bit
+    close(a["out"], b["out"].cpu(), "cell zero output", rtol=2e-6, atol=2e-6)
+    close(a["w"], b["w"].cpu(), "cell zero d alpha", rtol=2e-5, atol=2e-5 * float(b["w"].abs().max()))
     for key in ("gam", "bet", "rm", "rv"):
         for x, y in zip(a[key], b[key]):
-            assert torch.equal(x, y), key
+            close(x, y.cpu(), "cell zero " + key, rtol=2e-5, atol=2e-5 * max(1e-3, float(y.abs().max())))
     for key in ("ent", "rel"):
         close(a[key], b[key].cpu(), "cell zero table gradient " + key, rtol=2e-5, atol=2e-5 * float(b[key].abs().max()))
     # the torch formulation (reference models/cell_lp.py:25-33 on pre_mult / pre_sub / pre_add of the gathered rows)

@@ -29,13 +29,15 @@ def _segments(E, nseg, hub, empties, seed):
                                                        (7, 7, 1, False, 0), (300000, 23, 96, True, 0)])
 def test_span_plan_hip_equals_tensor_formulation(E, nseg, span, hub, empties):
     seg = _segments(E, nseg, hub, empties, E + nseg)
-    got = G.span_plan(seg, nseg, span)
-    ref = G.span_plan_torch(seg, nseg, span)
+    snap = span // 4 if (E + nseg) % 2 == 0 else 0              # both forms: cuts moved to segment ends / fixed spans
+    got = G.span_plan(seg, nseg, span, snap)
+    ref = G.span_plan_torch(seg, nseg, span, snap)
     assert got["n_hubs"] == ref["n_hubs"] and got["n_slots"] == ref["n_slots"] and got["n_spans"] == ref["n_spans"]
     assert torch.equal(got["perm"].long(), ref["perm"].long())
     for k in ("seg_sorted", "seg_len"):
         assert torch.equal(got[k], ref[k]), k
     assert torch.equal(got["span_slot"][: 2 * ref["n_spans"]], ref["span_slot"])
+    assert torch.equal(got["span_start"], ref["span_start"])
     nh = ref["n_hubs"]
     for k in ("hub_seg", "hub_first", "hub_count"):
         assert torch.equal(got[k][:nh], ref[k]), k

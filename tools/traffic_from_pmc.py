@@ -43,6 +43,22 @@ ENTRY_KERNELS = {
     "mrg_linear_relu_segmax_fwd": ["rowgemm_x3_k<7, 2, 4", "segmax_finalize_k"],
     "mrg_linear_relu_segsum_fwd": ["rowgemm_x3_k<7, 2, 5"],
 }
+# round 3: the default split-core kernel is rowgemm_x3s_k<NT, EPI, DUAL> (EPI 0 bias/act, 1 gate, 2 scale, 3 accumulate, 4 segmax, 5 segsum)
+ENTRY_KERNELS.update({
+    "mrg_linear_bwd_input": ["rowgemm_x3s_k<7, 0, false"],
+    "mrg_dense_filter_fwd": ["rowgemm_x3s_k<7, 1, false"],
+    "mrg_dense_filter_fwd3": ["rowgemm_x3s_k<7, 1,@max|rowgemm_x3s_k<7, 2,@max"],
+    "mrg_linear_bwd_input3": ["rowgemm_x3s_k<7, 0, false@max|rowgemm_x3s_k<7, 3, false@max"],
+    "mrg_linear_bwd_input3_pair": ["rowgemm_x3s_k<7, 3, true@max|rowgemm_x3s_k<7, 0, true@max"],
+    "mrg_linear_relu_segmax_fwd": ["rowgemm_x3s_k<7, 4", "segmax_finalize_k"],
+    "mrg_linear_relu_segsum_fwd": ["rowgemm_x3s_k<7, 5"],
+    "mrg_zero_stats_coef": ["zero_colstats_k", "mix_reduce_finalize_fwd_k"],
+    "mrg_zero_fwd": ["zero_fwd_k"],
+    "mrg_zero_bwd_reduce": ["zero_bwd_reduce_k"],
+    "mrg_zero_bwd_apply": ["zero_bwd_apply_k"],
+    "mrg_span_gcs": ["span_gcs_k<4, 64, 1, 2|span_gcs_k<4, 64, 1, 1|span_gcs_k<4, 64, 1, 3"],
+    "mrg_seg_reduce_bwd_bits": ["seg_bwd_bits_k"],
+})
 NORTH_STAR = "span_gcs_k<4, 64, 1, 0,"            # MODE = SUB only runs in bench.py's north-star passes (last parameter: prefetch-depth override)
 
 
@@ -87,7 +103,7 @@ def main():
            "per_launch_bytes": {}, "device_kernels": {}}
     for (name, grid), v in kern.items():
         if name.startswith(("mrg::", "span_", "seg_", "mix_", "gate_", "compose_", "rowgemm", "wgrad", "sum_k", "dense_", "distmult",
-                            "gather_", "bsplit", "ordered_reduce", "plan_", "graph_", "sample_", "score_", "rank_", "linrelu")) or "mrg" in name:
+                            "gather_", "bsplit", "ordered_reduce", "plan_", "graph_", "sample_", "score_", "rank_", "linrelu", "zero_")) or "mrg" in name:
             res["device_kernels"][f"{name} [grid {grid}]"] = v
     for entry, subs in ENTRY_KERNELS.items():
         total, found = 0.0, False
@@ -112,6 +128,14 @@ def main():
         res["per_launch_bytes"]["north_star:fb15k237"] = kern[ns[0]]["bytes_per_dispatch"]
         if len(ns) > 1:
             res["per_launch_bytes"]["north_star:c5_synthetic10m"] = kern[ns[-1]]["bytes_per_dispatch"]
+    # HBM-side bytes of ONE step: every dispatch of the profiled command except the north-star / calibration passes, divided by the
+    # number of steps it ran (bench.py --steps 1 --warmup 1: warm-up + instrumented + timed = 3)
+    steps = int(sys.argv[6]) if len(sys.argv) >= 7 else 3
+    skip = (NORTH_STAR, "compose_fwd_k")
+    tot = sum(v["bytes_per_dispatch"] * v["dispatches"] for (name, grid), v in kern.items() if not any(x in name for x in skip))
+    res["step_total"] = {"steps_in_profile": steps, "bytes_per_step": int(tot / steps), "GB_per_step": round(tot / steps / 1e9, 1),
+                         "excluded": "north-star passes (span_gcs_k MODE sub) and the compose_fwd_k calibration launches"}
+    print("HBM-side bytes per step: %.1f GB (%d steps in the profile)" % (tot / steps / 1e9, steps))
     if len(sys.argv) >= 6:                                         # self-check against a known byte count
         D, M = int(sys.argv[4]), int(sys.argv[5])
         got, want = res["per_launch_bytes"].get("mrg_compose_fwd"), 12 * D * M
