@@ -25,6 +25,11 @@
 #ifndef MRG_X3S_DBG
 #define MRG_X3S_DBG 0
 #endif
+// lab: s_sleep(127) repetitions (~3.5 us each) the SECOND workgroup of every CU waits in the first round (blocks 256..511 share
+// their CUs with blocks 0..255 under round-robin dispatch): desynchronises the two workgroups of a CU.  0 = off.
+#ifndef MRG_X3S_STAGGER
+#define MRG_X3S_STAGGER 0
+#endif
 
 namespace mrg {
 
@@ -57,6 +62,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   const int col0 = blockIdx.y * (NT * 32);
   const int K = a.K1 + a.K2;
   const int nslab = (K + 15) >> 4;
+  if (MRG_X3S_STAGGER > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < MRG_X3S_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     }
   };
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_b + (unsigned)lane * 16u;
-  u32x4 bq[2][3];
+  u32x4 bq2[2][2][3];                                    // [double buffer][tile of the pair][plane]
   auto read_b = [&](int n, int buf, u32x4 (&q)[3]) {
     const unsigned ad = lds0 + (unsigned)(buf * BSLAB + n * 3072);
     asm volatile("ds_read_b128 %0, %1" : "=v"(q[0]) : "v"(ad));
@@ -139,29 +147,68 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     const bool has_next = s + 1 < nslab;
     if (s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
     if (!(MRG_X3S_DBG & 2)) load_a(s + 3, xr[R]);
-    read_b(0, R, bq[0]);
+    // Column tiles in PAIRS: the twelve MFMAs of a pair alternate between its two accumulators (a dependent MFMA issued back to
+    // back waits for its predecessor's result; with another accumulator's MFMA in between the pipe stays busy) and the VALU
+    // instructions of the A split are spread between them (sched_group_barrier: 1 MFMA, then up to 3 VALU) instead of
+    // standing in front of the MFMAs.  Each accumulator still receives its six terms in the same order: bit-identical results.
+    constexpr int NP = (NT + 1) / 2;
+    constexpr int SPP = (4 + NP - 1) / NP;                    // split pairs handled in the shadow of one tile pair
+    read_b(0, R, bq2[0][0]);
+    if (NT > 1) read_b(1, R, bq2[0][1]);
     if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
     if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      if (n + 1 < NT) {
-        read_b(n + 1, R, bq[(n + 1) & 1]);
-        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");     // the three reads just issued may still be in flight
+    for (int pp = 0; pp < NP; ++pp) {
+      constexpr int dummy = 0; (void)dummy;
+      const int n0 = 2 * pp, n1 = 2 * pp + 1;
+      if (pp + 1 < NP) {
+        read_b(n0 + 2, R, bq2[(pp + 1) & 1][0]);
+        if (n1 + 2 < NT) {
+          read_b(n1 + 2, R, bq2[(pp + 1) & 1][1]);
+          asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // the reads just issued may still be in flight
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        }
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (has_next && n < 4) split_pair_of(xr[(R + 1) % 3], n, nh, nm, nl);   // VALU work in the shadow of this tile's MFMAs
-      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bq[n & 1][0]), Bm = __builtin_bit_cast(bf16x8, bq[n & 1][1]),
-                   Bl = __builtin_bit_cast(bf16x8, bq[n & 1][2]);
+      if (has_next) {
+#pragma unroll
+        for (int q = pp * SPP; q < (pp + 1) * SPP && q < 4; ++q) split_pair_of(xr[(R + 1) % 3], q, nh, nm, nl);
+      }
       const bf16x8 Ah = __builtin_bit_cast(bf16x8, ch), Am = __builtin_bit_cast(bf16x8, cm), Al = __builtin_bit_cast(bf16x8, cl);
-      // small terms first, the leading term last (same order as rowgemm_x3_k: bit-identical results)
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[n], 0, 0, 0);
+      const bf16x8 Bh0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][0]), Bm0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][1]),
+                   Bl0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][2]);
+      if (n1 < NT) {
+        const bf16x8 Bh1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][0]), Bm1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][1]),
+                     Bl1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][2]);
+        // small terms first, the leading term last (same order per accumulator as rowgemm_x3_k)
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[n1], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[n1], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[n1], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[n1], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[n1], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[n0], 0, 0, 0);
+        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[n1], 0, 0, 0);
+      } else {
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[n0], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[n0], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[n0], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[n0], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[n0], 0, 0, 0);
+        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[n0], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // ... then up to three VALU
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (NT < 4 && has_next) {
