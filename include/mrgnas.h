@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 8   /* 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate), mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -234,7 +234,22 @@ int mrg_distmult_score(const float *ent, const float *rel, const int32_t *s_idx,
  * Statistics may be all-reduced between colstats/finalize (and reduce/finalize) when rows
  * are sharded over GPUs.  Needs K*6*D*4 <= 64 KiB of LDS. */
 int64_t mrg_mix_workspace_bytes(int K, int D);
-int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, double *sums, void *ws, void *stream);
+/* `gated` (HOST pointer, NULL or k < 0 = none) of the five entry points that read the candidates: candidate k is the gated
+ * filter f_dense_op_comp (reference models/operations_lp.py:356-390) and is NOT stored -- y_host[k] holds its gate
+ * sigmoid(W [s ; s_in] + b) (mrg_dense_filter_fwd3 with out == NULL) and its value is recomputed wherever it is read as
+ *   y_k[r][c] = gate[r][c] * s[r][c] * rowscale[r]
+ * -- the expression and the order of the row GEMM's gate epilogue, so coefficients, output and gradients are those of the
+ * stored form bit for bit.  rowscale covers ALL rows: the caller expands scale_edge * norm[r] on edge rows and scale_self on
+ * self rows once per graph (in float32, as the epilogue multiplies them).  One [rows, D] write per MixedOp and two reads of its
+ * backward less; s is the MixedOp's input state.
+ * In mrg_mix_bwd_apply, when rs_on[k] == 2 for this k, fold_s[k] must be `s` and fold_gate[k] must be y_host[k]. */
+typedef struct mrg_gated_branch {
+  int32_t k;
+  const float *s;          /* [rows, D] device */
+  const float *rowscale;   /* [rows] device */
+} mrg_gated_branch;
+int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, double *sums, void *ws,
+                     const mrg_gated_branch *gated, void *stream);
 int mrg_mix_finalize_fwd(const double *sums, const float *const *gamma_host, const float *const *beta_host,
                          float *const *rmean_host, float *const *rvar_host, int K, double total_rows, int D,
                          float eps, float momentum, float *coef, void *stream);
@@ -243,14 +258,14 @@ int mrg_mix_finalize_fwd(const double *sums, const float *const *gamma_host, con
  * step.  Bit-identical coefficients and running statistics.  ws: mrg_mix_workspace_bytes(K, D). */
 int mrg_mix_stats_coef(const float *const *y, const float *const *gamma, const float *const *beta,
                        float *const *running_mean, float *const *running_var, int K, int64_t rows, double total_rows,
-                       int D, float eps, float momentum, float *coef, void *ws, void *stream);
+                       int D, float eps, float momentum, float *coef, void *ws, const mrg_gated_branch *gated, void *stream);
 /* out = (addend ? addend : 0) + sum_k w[k] ReLU(y_k scale_k + shift_k).  addend (may be NULL, may NOT alias out): the output
  * of the MixedOp this one is summed with -- a state fed by several MixedOps (reference models/cell_lp.py:104-113) is
  * accumulated here instead of by separate full-size add kernels. */
 int mrg_mix_fwd(const float *const *y_host, int K, const float *coef, const float *w, const float *addend, float *out,
-                int64_t rows, int D, void *stream);
+                int64_t rows, int D, const mrg_gated_branch *gated, void *stream);
 int mrg_mix_bwd_reduce(const float *g, const float *const *y_host, int K, const float *coef, const float *w,
-                       float *red, void *ws, int64_t rows, int D, void *stream);
+                       float *red, void *ws, int64_t rows, int D, const mrg_gated_branch *gated, void *stream);
 int mrg_mix_finalize_bwd(const float *red, int K, double total_rows, int D, float *coef2,
                          float *const *dgamma_host, float *const *dbeta_host, float *dw, void *stream);
 /* rs_on (HOST int[K], may be NULL = none): candidate k's output gradient is written already multiplied by its consumer's row
@@ -263,7 +278,7 @@ int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *
                       const float *coef, const float *coef2, const float *w, const float *const *rs, const float *rs_scale,
                       const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *fold_s,
                       const float *const *fold_gate, float *const *fold_gs, const int *fold_add_from, int64_t rows, int D,
-                      void *stream);
+                      const mrg_gated_branch *gated, void *stream);
 /* fold_add_from (HOST array of K ints, NULL = none): for a gated candidate k (rs_on[k] == 2), the index q of the candidate
  * whose OUTPUT is k's operand s (f_identity of the same MixedOp: y_host[q] == fold_s[k]); its gradient gy_q is added to
  * fold_gs[k] and gy_host[q] may be NULL -- both are gradients w.r.t. the same rows. */
@@ -387,7 +402,8 @@ int mrg_dense_filter_fwd(int kind, const float *s, const float *s_in, const floa
  * rows [0, b0) use W[0] / bias[0], [b0, b1) W[1] / bias[1] (edge rows: c = scale_edge * norm[row]), [b1, M) W[2] / bias[2]
  * (self rows: c = scale_self).  W / bias: HOST arrays of three device pointers (bias entries may be NULL).  Split core
  * only: mrg_dense_filter3_workspace_bytes(D, K) returns 0 when the shape does not qualify (then use the per-segment
- * entry point).  Same arithmetic per row as mrg_dense_filter_fwd: results are bit-identical. */
+ * entry point).  Same arithmetic per row as mrg_dense_filter_fwd: results are bit-identical.
+ * kind 0 with out == NULL: only the gate is stored; the MixedOp epilogue recomputes the output (mrg_gated_branch). */
 int64_t mrg_dense_filter3_workspace_bytes(int D, int K);
 int mrg_dense_filter_fwd3(int kind, const float *s, const float *s_in, const float *const *W, const float *const *bias,
                           const float *norm, float scale_edge, float scale_self, float *out, float *gate, void *ws,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -53,19 +53,19 @@ SIGNATURES = {
     "mrg_sum_buffers": (_I, [_P, _I, _P, _L, _I, _P]),
     "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),
-    "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P]),
+    "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
-    "mrg_mix_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
+    "mrg_mix_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P, _P]),
     "mrg_zero_workspace_bytes": (_L, [_I]),
     "mrg_zero_colstats": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
     "mrg_zero_stats_coef": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, ctypes.c_double, _I, _F, _F, _P, _P, _P]),
     "mrg_zero_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
     "mrg_zero_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_zero_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
-    "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),
-    "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P]),
     "mrg_mix_finalize_bwd": (_I, [_P, _I, ctypes.c_double, _I, _P, _P, _P, _P, _P]),
-    "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "mrg_dense_filter_fwd": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
     "mrg_dense_filter_dz": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "mrg_gemm_workspace_bytes": (_L, [_I, _I]),
@@ -228,6 +228,20 @@ def ptr_array(tensors):
     for i, t in enumerate(tensors):
         arr[i] = None if t is None else t.data_ptr()
     return arr
+
+
+class GatedBranch(ctypes.Structure):
+    """include/mrgnas.h: mrg_gated_branch."""
+    _fields_ = [("k", ctypes.c_int32), ("s", ctypes.c_void_p), ("rowscale", ctypes.c_void_p)]
+
+
+def gated_branch(spec):
+    """HOST mrg_gated_branch for spec = (k, s, rowscale [rows]), or None.  Returns the by-reference argument (which keeps the
+    structure alive for the call)."""
+    if spec is None:
+        return None
+    k, s, rowscale = spec
+    return ctypes.byref(GatedBranch(int(k), s.data_ptr(), rowscale.data_ptr()))
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("MRG_RAW_STREAM", "1") == "1" else None

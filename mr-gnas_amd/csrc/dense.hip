@@ -90,8 +90,9 @@ extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in
   const int K = s_in ? 2 * D : D;
   if (!dense3_shape_ok(D, K)) return MRG_E_SHAPE;
   if (M == 0) return MRG_OK;
-  if (!s || !out || !W_host) return MRG_E_NULLPTR;
+  if (!s || !W_host) return MRG_E_NULLPTR;
   if (kind == 0 && !gate) return MRG_E_NULLPTR;
+  if (!out && kind != 0) return MRG_E_NULLPTR;     // kind 0, out == NULL: gate only (the consumer recomputes gate * s * c, mrg_gated_branch)
   if (!ws) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t lo[3] = {0, b0, b1}, hi[3] = {b0, b1, M};

@@ -258,6 +258,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
   float* xrow[16];
   float cs[16];
   bool rok[16];
+  // EPI_GATE with C == NULL: only the gate (aux) is stored -- the gated output is recomputed from gate, S and the row scale
+  // by its consumer (the MixedOp epilogue's "virtual" candidate, mixedop.hip) instead of being written and re-read four times
+  const bool cstore = EPI != EPI_GATE || a.C != nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -298,13 +301,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     }
     if (full) {
       if (cok) {
+        if (cstore) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 16; ++r) {
 #if MRG_C_NT
-          __builtin_nontemporal_store(v[r], crow[r] + n * 32);           // lab: C is written once and re-read by a later kernel
+            __builtin_nontemporal_store(v[r], crow[r] + n * 32);         // lab: C is written once and re-read by a later kernel
 #else
-          crow[r][n * 32] = v[r];
+            crow[r][n * 32] = v[r];
 #endif
+          }
         }
         if (EPI == EPI_GATE && a.aux) {
 #pragma unroll
@@ -315,7 +320,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (cok && rok[r]) {
-          crow[r][n * 32] = v[r];
+          if (cstore) crow[r][n * 32] = v[r];
           if (EPI == EPI_GATE && a.aux) xrow[r][n * 32] = g[r];
         }
       }
@@ -423,7 +428,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& a, f32x16 (&ac
 template <int EPI>
 inline bool gemm_epilogue_lds_ok(const GemmArgs& a) {
   if (EPI != EPI_BIAS_ACT && EPI != EPI_GATE && EPI != EPI_SCALE && EPI != EPI_ACCUM) return false;
-  if (a.N % 4 != 0 || a.ldc % 4 != 0 || !aligned16(a.C)) return false;
+  if (a.N % 4 != 0 || a.ldc % 4 != 0 || !a.C || !aligned16(a.C)) return false;
   if (EPI == EPI_GATE && (a.ld_s % 4 != 0 || !aligned16(a.S) || (a.aux && !aligned16(a.aux)))) return false;
   if (EPI == EPI_ACCUM && (a.ld_cin % 4 != 0 || !aligned16(a.Cin))) return false;
   return true;

@@ -25,24 +25,120 @@ struct MutPack { float* p[MRG_MIX_MAXK]; };
 struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK];
                       const float* s[MRG_MIX_MAXK]; const float* gate[MRG_MIX_MAXK]; float* gs_out[MRG_MIX_MAXK]; int add_from[MRG_MIX_MAXK]; };
 
+// A gated candidate that is never stored (f_dense_comp, reference models/operations_lp.py:356-390): ys.p[k] holds its GATE
+// sigmoid(W [s ; s_in] + b) and the candidate's value is recomputed here as  gate * s * c_r  -- the expression, and its order, of
+// the row GEMM's gate epilogue (gemm.hpp EPI_GATE: g * in * cs), so every statistic, the output and every gradient are the
+// stored form's bit for bit.  The gate is needed by the candidate's backward anyway; its [rows, D] output is one write (GEMM) and
+// four reads (statistics, combine, backward reduction, backward apply) that do not happen; s is the MixedOp's input state, which
+// the f_identity candidate of the same MixedOp reads at the same place (one L2 / L1 hit more, no HBM pass).   k < 0: none.
+struct GatedPack { int k; const float* s; const float* c;
+                   int pair_k; };   // pair_k: the candidate whose stored output is s itself (f_identity), -1 = none  (statistics kernel)
+
+// c: the candidate's per-row multiplier for ALL rows (the caller expands scale_edge * norm on edge rows, scale_self on self rows,
+// once per graph): an unconditional load.  A conditional one (edge rows only) was compiled into an exec-masked block that waited for
+// it -- s_waitcnt vmcnt(0) -- before the candidates' loads were issued: two dependent memory latencies per trip.
+__device__ __forceinline__ float gated_rowscale(const GatedPack& gp, int64_t r) { return gp.c[r]; }
+
 // ---- column statistics: sums[k][0][c] = sum_r y_k[r][c], sums[k][1][c] = sum_r y_k[r][c]^2 (float64)
+// block reduction of one candidate's per-lane column sums into its per-block partial [2][D] (every thread of the block calls it)
 template <int VEC, int LPR, int KMAX>
-__global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, int64_t rows, int D, double* __restrict__ ws) {
+__device__ __forceinline__ void colstats_flush(const double (&s1)[KMAX][VEC], const double (&s2)[KMAX][VEC], double* red, double* __restrict__ dst,
+                                               int D, int sl, int rw) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) {
+    int c = sl + q * LPR;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[(rw * 2 + 0) * WIDTH + c * VEC + j] = s1[q][j];
+      red[(rw * 2 + 1) * WIDTH + c * VEC + j] = s2[q][j];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * D; t += MRG_BLOCK) {
+    int which = t / D, c = t - which * D;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPB; ++q) acc += red[(q * 2 + which) * WIDTH + c];
+    dst[t] = acc;
+  }
+}
+
+// GATED: candidate gp.k is recomputed from its gate (GatedPack).  When gp.pair_k >= 0 -- f_identity of the same MixedOp, whose
+// output IS the multiplicand s -- the two candidates share ONE sweep (s is read once for both; a sweep per candidate would read
+// it from HBM twice, the tensors being far larger than the caches).
+template <int VEC, int LPR, int KMAX, bool GATED>
+__global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, int64_t rows, int D, double* __restrict__ ws, GatedPack gp) {
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ double red[RPB * 2 * WIDTH];
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
+  const int64_t step = (int64_t)gridDim.x * RPB;
   for (int k = 0; k < K; ++k) {
     const float* __restrict__ y = ys.p[k];
+    if (GATED && k == gp.k && gp.pair_k >= 0) continue;     // swept together with candidate pair_k
     double s1[KMAX][VEC], s2[KMAX][VEC];
 #pragma unroll
     for (int q = 0; q < KMAX; ++q)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s1[q][j] = 0.0; s2[q][j] = 0.0; }
+    if (GATED && (k == gp.k || k == gp.pair_k)) {
+      // t1 / t2: the recomputed candidate gate * s * c_r; s1 / s2: s itself (only stored when it is candidate pair_k)
+      const float* __restrict__ gate = ys.p[gp.k];
+      double t1[KMAX][VEC], t2[KMAX][VEC];
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { t1[q][j] = 0.0; t2[q][j] = 0.0; }
+      int64_t r = (int64_t)blockIdx.x * RPB + rw;
+      for (; r + 3 * step < rows; r += 4 * step) {          // four rows per trip: eight independent 16-byte loads in flight per lane
+        float ck[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ck[u] = gated_rowscale(gp, r + u * step);
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q) {
+          int c = sl + q * LPR;
+          if (c < dv) {
+            Vec<VEC> sv[4], ga[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sv[u] = Vec<VEC>::load(gp.s + (r + u * step) * D + c * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ga[u] = Vec<VEC>::load(gate + (r + u * step) * D + c * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) { double d = (double)sv[u][j]; s1[q][j] += d; s2[q][j] += d * d; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) { double d = (double)(ga[u][j] * sv[u][j] * ck[u]); t1[q][j] += d; t2[q][j] += d * d; }
+          }
+        }
+      }
+      for (; r < rows; r += step) {
+        const float ck = gated_rowscale(gp, r);
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q) {
+          int c = sl + q * LPR;
+          if (c < dv) {
+            const Vec<VEC> sv = Vec<VEC>::load(gp.s + r * D + c * VEC), ga = Vec<VEC>::load(gate + r * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              double d = (double)sv[j]; s1[q][j] += d; s2[q][j] += d * d;
+              d = (double)(ga[j] * sv[j] * ck); t1[q][j] += d; t2[q][j] += d * d;
+            }
+          }
+        }
+      }
+      colstats_flush<VEC, LPR, KMAX>(t1, t2, red, ws + ((int64_t)blockIdx.x * K + gp.k) * 2 * D, D, sl, rw);
+      if (k == gp.pair_k) colstats_flush<VEC, LPR, KMAX>(s1, s2, red, ws + ((int64_t)blockIdx.x * K + k) * 2 * D, D, sl, rw);
+      continue;
+    }
     if (y != nullptr) {
       // four rows per trip: four independent loads in flight per lane (one load per trip left HBM latency exposed)
-      const int64_t step = (int64_t)gridDim.x * RPB;
       int64_t r = (int64_t)blockIdx.x * RPB + rw;
       for (; r + 3 * step < rows; r += 4 * step) {
 #pragma unroll
@@ -71,25 +167,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, i
         }
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < KMAX; ++q) {
-      int c = sl + q * LPR;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        red[(rw * 2 + 0) * WIDTH + c * VEC + j] = s1[q][j];
-        red[(rw * 2 + 1) * WIDTH + c * VEC + j] = s2[q][j];
-      }
-    }
-    __syncthreads();
-    double* dst = ws + ((int64_t)blockIdx.x * K + k) * 2 * D;
-    for (int t = threadIdx.x; t < 2 * D; t += MRG_BLOCK) {
-      int which = t / D, c = t - which * D;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < RPB; ++q) acc += red[(q * 2 + which) * WIDTH + c];
-      dst[t] = acc;
-    }
+    colstats_flush<VEC, LPR, KMAX>(s1, s2, red, ws + ((int64_t)blockIdx.x * K + k) * 2 * D, D, sl, rw);
   }
 }
 
@@ -166,10 +244,10 @@ __global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb,
 }
 
 // ---- forward combine
-template <int VEC, int LPR, int KMAX>
+template <int VEC, int LPR, int KMAX, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
                                                        float* __restrict__ out, int64_t rows, int D,
-                                                       const float* __restrict__ addend) {
+                                                       const float* __restrict__ addend, GatedPack gp) {
   extern __shared__ float lds[];                 // [K][2][D] scale, shift
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
@@ -190,6 +268,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
         // `addend`: the output of the MixedOp this one is summed with (reference models/cell_lp.py:104-113: sum of the
         // MixedOps feeding a state) -- added here instead of by a separate full-size kernel
         Vec<VEC> acc = addend ? Vec<VEC>::load(addend + r * D + c * VEC) : Vec<VEC>::fill(0.f);
+        // the recomputed candidate's row scale and multiplicand: issued FIRST (loads return in order: the candidates before
+        // it can be consumed while the later loads are in flight); s comes from candidate pair_k's registers when it is one
+        float gck = 1.f;
+        Vec<VEC> gsv = Vec<VEC>::fill(0.f);
+        if constexpr (GATED) {
+          gck = gated_rowscale(gp, r);
+          gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
+        }
         // phase 1: every branch's load is issued before any is used (a load consumed inside its own `if (k < K)`
         // block leaves one 16-byte load in flight per lane)
         Vec<VEC> vin[MRG_MIX_MAXK];
@@ -201,7 +287,13 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           if (k < K) {
-            const Vec<VEC> v = vin[k];
+            Vec<VEC> v = vin[k];
+            if constexpr (GATED) {                         // the recomputed candidate: gate -> gate * s * c_r; the others * 1 * 1
+              const bool isg = k == gp.k;                  // (selects, not a branch: the loads above stay in flight together)
+              const float cm = isg ? gck : 1.0f;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
+            }
             Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -218,10 +310,10 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
 
 // ---- backward reduce: per branch  red[k][0] = sum gr, [1] = sum gr*xhat, [2] = sum g*relu(z)  (gr = w g [z>0])
 // rows outermost: g is read once, every y_k once; per-branch column accumulators live in registers.
-template <int VEC, int LPR, int KMAX, int KB>
+template <int VEC, int LPR, int KMAX, int KB, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __restrict__ g, PtrPack ys, int K,
                                                               const float* __restrict__ coef, const float* __restrict__ w,
-                                                              float* __restrict__ ws, int64_t rows, int D) {
+                                                              float* __restrict__ ws, int64_t rows, int D, GatedPack gp) {
   extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
@@ -243,6 +335,12 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
       if (c < dv) {
+        float gck = 1.f;                                   // the recomputed candidate's row scale and multiplicand (see mix_fwd_k)
+        Vec<VEC> gsv = Vec<VEC>::fill(0.f);
+        if constexpr (GATED) {
+          gck = gated_rowscale(gp, r);
+          gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
+        }
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
         Vec<VEC> vin[KB];                                  // all loads first (see mix_fwd_k)
 #pragma unroll
@@ -253,7 +351,13 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
           if (k < K) {
-            const Vec<VEC> v = vin[k];
+            Vec<VEC> v = vin[k];
+            if constexpr (GATED) {                         // the recomputed candidate: gate -> gate * s * c_r; the others * 1 * 1
+              const bool isg = k == gp.k;
+              const float cm = isg ? gck : 1.0f;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
+            }
             const float* cf = lds + k * 4 * D + c * VEC;
             const Vec<VEC> c0 = Vec<VEC>::load(cf), c1 = Vec<VEC>::load(cf + D), c2 = Vec<VEC>::load(cf + 2 * D), c3 = Vec<VEC>::load(cf + 3 * D);
 #pragma unroll
@@ -323,10 +427,11 @@ __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double 
 }
 
 // ---- backward apply: gy_k = (gr - c1 - xhat*c2) * scale      (skipped where gy_k is NULL)
-template <int VEC, int LPR, int KMAX>
+template <int VEC, int LPR, int KMAX, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
-                                                             const float* __restrict__ w, int64_t rows, int D, RowScalePack rsp) {
+                                                             const float* __restrict__ w, int64_t rows, int D, RowScalePack rsp,
+                                                             GatedPack gp) {
   extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
   constexpr int RPB = MRG_BLOCK / LPR;
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
@@ -354,12 +459,27 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
       if (c < dv) {
+        float gck = 1.f;                                   // the recomputed candidate's row scale and multiplicand (see mix_fwd_k)
+        Vec<VEC> gsv = Vec<VEC>::fill(0.f), gga = Vec<VEC>::fill(0.f);
+        if constexpr (GATED) {
+          gck = gated_rowscale(gp, r);
+          gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
+        }
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
         Vec<VEC> vin[MRG_MIX_MAXK];                        // all loads first (see mix_fwd_k)
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           vin[k] = Vec<VEC>::fill(0.f);
           if (k < K && need[k] && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+        }
+        if constexpr (GATED) {
+#pragma unroll
+          for (int k = 0; k < MRG_MIX_MAXK; ++k)
+            if (k == gp.k) {
+              gga = vin[k];
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) vin[k][j] = vin[k][j] * gsv[j] * gck;
+            }
         }
         Vec<VEC> ov[MRG_MIX_MAXK];                         // every wanted gy_k first: a gated candidate may add another one's
 #pragma unroll
@@ -386,7 +506,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
             if (rsp.on[k]) {                               // the consumer's first backward pass (mrg_dense_filter_dz) folded into this store
               const float ck = r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k];
               if (rsp.on[k] == 2) {                        // f_dense_comp: same expressions, same order as dense_dz_k<.., 0>
-                const Vec<VEC> sv = Vec<VEC>::load(rsp.s[k] + r * D + c * VEC), ga = Vec<VEC>::load(rsp.gate[k] + r * D + c * VEC);
+                // (the recomputed candidate holds both already: the host checks rsp.s[k] == gp.s and rsp.gate[k] == ys.p[k])
+                const Vec<VEC> sv = (GATED && k == gp.k) ? gsv : Vec<VEC>::load(rsp.s[k] + r * D + c * VEC);
+                const Vec<VEC> ga = (GATED && k == gp.k) ? gga : Vec<VEC>::load(rsp.gate[k] + r * D + c * VEC);
                 Vec<VEC> o2;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -711,6 +833,20 @@ static int mix_grid(int64_t rows, int lpr) {
 
 static bool pack_ok(const void* const* host, int K) { return host != nullptr && K >= 1 && K <= MRG_MIX_MAXK; }
 
+// host descriptor (include/mrgnas.h: mrg_gated_branch) -> kernel argument; *al: every pointer it adds is 16-byte aligned
+static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, int K, GatedPack* gp, bool* al) {
+  *gp = GatedPack{};
+  gp->k = -1; gp->pair_k = -1;
+  if (!gb || gb->k < 0) return MRG_OK;
+  if (gb->k >= K) return MRG_E_SHAPE;
+  if (!gb->s || !gb->rowscale || !y_host[gb->k]) return MRG_E_NULLPTR;       // the gate stands where the candidate's output would
+  gp->k = gb->k; gp->s = gb->s; gp->c = gb->rowscale;
+  for (int q = 0; q < K; ++q)
+    if (q != gb->k && y_host[q] == gb->s) { gp->pair_k = q; break; }
+  *al = *al && aligned16(gb->s);
+  return MRG_OK;
+}
+
 }  // namespace mrg
 
 using namespace mrg;
@@ -721,18 +857,19 @@ extern "C" int64_t mrg_mix_workspace_bytes(int K, int D) {
 }
 
 // sums [K][2][D] float64
-static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out);
+static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out,
+                               const mrg_gated_branch* gated);
 
 // mrg_mix_colstats + mrg_mix_finalize_fwd in two launches instead of three (statistics kernel, then reduction and finalize fused):
 // for callers without a collective between the two (the single-GPU step).  Same results bit for bit.
 extern "C" int mrg_mix_stats_coef(const float* const* y_host, const float* const* gamma_host, const float* const* beta_host,
                                   float* const* rmean_host, float* const* rvar_host, int K, int64_t rows, double total_rows, int D, float eps,
-                                  float momentum, float* coef, void* ws, void* stream) {
+                                  float momentum, float* coef, void* ws, const mrg_gated_branch* gated, void* stream) {
   if (K < 1 || K > MRG_MIX_MAXK || D <= 0 || total_rows < 0) return MRG_E_SHAPE;
   if (!coef || !gamma_host || !beta_host) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
   int grid = 1;
-  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid);
+  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid, gated);
   if (rc != MRG_OK) return rc;
   PtrPack ga{}, be{};
   MutPack rm{}, rv{};
@@ -748,11 +885,12 @@ extern "C" int mrg_mix_stats_coef(const float* const* y_host, const float* const
   return MRG_OK;
 }
 
-extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows, int D, double* sums, void* ws, void* stream) {
+extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows, int D, double* sums, void* ws,
+                                const mrg_gated_branch* gated, void* stream) {
   if (!sums) return MRG_E_NULLPTR;
   hipStream_t st = (hipStream_t)stream;
   int grid = 1;
-  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid);
+  const int rc = mix_colstats_blocks(y_host, K, rows, D, ws, st, &grid, gated);
   if (rc != MRG_OK) return rc;
   int len = K * 2 * D;
   launch_ordered_reduce<double>((const double*)ws, sums, 0, grid, len, len, st);
@@ -761,20 +899,25 @@ extern "C" int mrg_mix_colstats(const float* const* y_host, int K, int64_t rows,
 }
 
 // the statistics kernel: per-block partial sums [grid][K][2][D] in ws
-static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out) {
+static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, int D, void* ws, hipStream_t st, int* grid_out,
+                               const mrg_gated_branch* gated) {
   if (!pack_ok((const void* const*)y_host, K)) return MRG_E_SHAPE;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (!ws) return MRG_E_WORKSPACE;
   PtrPack ys{};
   bool al = true;
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  GatedPack gp;
+  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  if (grc != MRG_OK) return grc;
   RowGeom g = row_geom(D, al);
   if (!g.ok) return MRG_E_SHAPE;
   int grid = 1;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
     grid = mix_grid(rows, L);                                                                             \
-    hipLaunchKernelGGL((mix_colstats_k<V, L, KM>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws); \
+    if (gp.k >= 0) hipLaunchKernelGGL((mix_colstats_k<V, L, KM, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws, gp); \
+    else hipLaunchKernelGGL((mix_colstats_k<V, L, KM, false>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws, gp); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
@@ -804,7 +947,7 @@ extern "C" int mrg_mix_finalize_fwd(const double* sums, const float* const* gamm
 }
 
 extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef, const float* w, const float* addend, float* out,
-                           int64_t rows, int D, void* stream) {
+                           int64_t rows, int D, const mrg_gated_branch* gated, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!coef || !w || !out) return MRG_E_NULLPTR;
@@ -812,12 +955,18 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   PtrPack ys{};
   bool al = aligned16(out) && aligned16(addend);
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  GatedPack gp;
+  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  if (grc != MRG_OK) return grc;
   RowGeom g = row_geom(D, al);
   if (!g.ok) return MRG_E_SHAPE;
   size_t lds = (size_t)K * 2 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
-  hipLaunchKernelGGL((mix_fwd_k<V, L, KM>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend)
+  do {                                                                                                    \
+    if (gp.k >= 0) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+  } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();
@@ -826,7 +975,7 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
 
 // red [K][3][D] float32
 extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, int K, const float* coef, const float* w, float* red,
-                                  void* ws, int64_t rows, int D, void* stream) {
+                                  void* ws, int64_t rows, int D, const mrg_gated_branch* gated, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (!coef || !w || !red || (rows > 0 && !g)) return MRG_E_NULLPTR;
   if (!ws) return MRG_E_WORKSPACE;
@@ -834,6 +983,9 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
   PtrPack ys{};
   bool al = aligned16(g);
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
+  GatedPack gp;
+  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  if (grc != MRG_OK) return grc;
   RowGeom gm = row_geom(D, al);
   if (!gm.ok) return MRG_E_SHAPE;
   int grid = 1;
@@ -842,8 +994,9 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
     grid = mix_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
-    if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D); \
-    else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D); \
+    if (gp.k >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    else if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
   } while (0)
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
@@ -874,7 +1027,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
                                  const float* coef2, const float* w, const float* const* rs_host, const float* rs_scale_host,
                                  const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host,
                                  const float* const* fold_s_host, const float* const* fold_gate_host, float* const* fold_gs_host,
-                                 const int* fold_add_from_host, int64_t rows, int D, void* stream) {
+                                 const int* fold_add_from_host, int64_t rows, int D, const mrg_gated_branch* gated, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
   if (rows == 0) return MRG_OK;
   if (!g || !coef || !coef2 || !w) return MRG_E_NULLPTR;
@@ -912,12 +1065,20 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
       }
     }
   }
+  GatedPack gp;
+  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  if (grc != MRG_OK) return grc;
+  // the recomputed candidate's folded gradient store reads s and the gate it already holds: they must be the same tensors
+  if (gp.k >= 0 && rsp.on[gp.k] == 2 && (rsp.s[gp.k] != gp.s || rsp.gate[gp.k] != y_host[gp.k])) return MRG_E_SHAPE;
   RowGeom gm = row_geom(D, al);
   if (!gm.ok) return MRG_E_SHAPE;
   size_t lds = (size_t)K * 6 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
-  hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp)
+  do {                                                                                                    \
+    if (gp.k >= 0) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+  } while (0)
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
   MRG_LAUNCH_CHECK();

@@ -881,8 +881,11 @@ class _MixCfg:
     """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
     updated in place like torch does), which branches are all-zero, sharding info."""
 
-    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None, identity=None):
+    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None, identity=None, gated=None):
         self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
+        # (k, s, c [rows]): candidate k arrives as its GATE and is recomputed as gate * s * c[r] wherever the kernels read it
+        # (include/mrgnas.h: mrg_gated_branch), or None
+        self.gated = gated
         self.identity = identity       # index of the candidate that returns its input unchanged (f_identity), or None
         self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self, gated node | None, node): folded into its gradient
 
@@ -908,6 +911,9 @@ class _MixedEpilogue(torch.autograd.Function):
         total = float(cfg.total_rows if cfg.total_rows is not None else rows)
         coef = torch.empty(K_, 4, D, dtype=torch.float32, device=dev)
         ypa = ptr_array(ys)
+        gb = _lib.gated_branch(cfg.gated)
+        # the recomputed candidate reads its gate where the stored one read its output, and s -- which f_identity of the same MixedOp reads anyway
+        nz_rd = nz + (1 if (cfg.gated is not None and (cfg.identity is None or not cfg.present[cfg.identity])) else 0)
         bn0 = cfg.bns[0]
         training = bn0.training or not bn0.track_running_stats
         if training:
@@ -917,12 +923,12 @@ class _MixedEpilogue(torch.autograd.Function):
             rv = ptr_array([b.running_var if track else None for b in cfg.bns])
             mom = bn0.momentum if bn0.momentum is not None else 0.1
             if cfg.group is None:                          # no collective between statistics and coefficients: two launches, not three
-                call("mrg_mix_stats_coef", (ypa, ptr_array(gam), ptr_array(bet), rm, rv, K_, rows, total, D, bn0.eps, mom, ptr(coef), ptr(ws), st),
-                     nbytes=4 * D * rows * nz)
+                call("mrg_mix_stats_coef", (ypa, ptr_array(gam), ptr_array(bet), rm, rv, K_, rows, total, D, bn0.eps, mom, ptr(coef), ptr(ws), gb, st),
+                     nbytes=4 * D * rows * nz_rd)
             else:
                 import torch.distributed as dist
                 sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
-                call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), st), nbytes=4 * D * rows * nz)
+                call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), gb, st), nbytes=4 * D * rows * nz_rd)
                 dist.all_reduce(sums, group=cfg.group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:                                      # one multi-tensor launch instead of one per BatchNorm
@@ -935,8 +941,8 @@ class _MixedEpilogue(torch.autograd.Function):
                 coef[k, 2] = invstd
                 coef[k, 3] = b.running_mean * invstd
         out = torch.empty(rows, D, dtype=torch.float32, device=dev)
-        call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(addend), ptr(out), rows, D, st), nbytes=4 * D * rows * (nz + 1 + (addend is not None)))
-        ctx.cfg, ctx.training, ctx.total, ctx.nz = cfg, training, total, nz
+        call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(addend), ptr(out), rows, D, gb, st), nbytes=4 * D * rows * (nz_rd + 1 + (addend is not None)))
+        ctx.cfg, ctx.training, ctx.total, ctx.nz, ctx.nz_rd = cfg, training, total, nz, nz_rd
         ctx.save_for_backward(w, coef, *ys_nz)
         return out
 
@@ -953,7 +959,8 @@ class _MixedEpilogue(torch.autograd.Function):
         ypa = ptr_array(ys)
         ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
         red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
-        call("mrg_mix_bwd_reduce", (ptr(g), ypa, K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, st), nbytes=4 * D * rows * (nz + 1))
+        gb = _lib.gated_branch(cfg.gated)
+        call("mrg_mix_bwd_reduce", (ptr(g), ypa, K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, gb, st), nbytes=4 * D * rows * (ctx.nz_rd + 1))
         red_local = red
         if cfg.group is not None and ctx.training:
             import torch.distributed as dist
@@ -1010,8 +1017,8 @@ class _MixedEpilogue(torch.autograd.Function):
             on = rs_ptr = rs_edge = rs_scale = rs_self = f_s = f_gate = f_gs_p = f_add = None
             n_fold = 0
         call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
-                                   f_s, f_gate, f_gs_p, f_add, rows, D, st),
-             nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold))
+                                   f_s, f_gate, f_gs_p, f_add, rows, D, gb, st),
+             nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold - (2 if (cfg.gated is not None and n_fold) else 0) + (ctx.nz_rd - nz if not n_fold else 0)))
         if rs is not None:
             for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
                 if rs[k] is not None and gys[k] is not None:
@@ -1040,7 +1047,14 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
                 # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node; [6] which of its outputs y is
                 rowscale[k] = spec[:4] + (node if spec[4] else None, node, spec[5])
                 node.prescaled[spec[5]] = True
-    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale, identity)
+    gated = None
+    for k, y in enumerate(ys):
+        spec = getattr(y, "_mrg_gated", None) if y is not None else None
+        if spec is not None:
+            if gated is not None:
+                raise _lib.MrgnasError("mixed epilogue: one recomputed (gate-only) candidate at most")
+            gated = (k,) + tuple(spec)
+    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale, identity, gated)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)
 
@@ -1379,7 +1393,7 @@ class _DensePair(torch.autograd.Function):
     params: W_in, b_in, W_out, b_out, W_self, b_self of f_dense_comp, then W_in, W_out, W_self of f_comp (no biases)."""
 
     @staticmethod
-    def forward(ctx, s, s_in, norm, b0, b1, *params):
+    def forward(ctx, s, s_in, norm, b0, b1, gate_only, *params):
         s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
         params = tuple(f32c(p) for p in params)
         require_hip(s, s_in, norm, *params)
@@ -1387,11 +1401,15 @@ class _DensePair(torch.autograd.Function):
         st = stream_of(s)
         K_ = 2 * D if s_in is not None else D
         ws3 = int(_lib.load().mrg_dense_filter3_workspace_bytes(D, K_))
-        out_d, out_c, gate = torch.empty_like(s), torch.empty_like(s), torch.empty_like(s)
+        out_c, gate = torch.empty_like(s), torch.empty_like(s)
+        # gate_only: f_dense_comp's output is never stored -- the node returns the GATE and its consumer (the MixedOp epilogue)
+        # recomputes gate * s * c in every pass that reads the candidate
+        out_d = gate if gate_only else torch.empty_like(s)
         dW, dB, cW = [params[0], params[2], params[4]], [params[1], params[3], params[5]], list(params[6:9])
         work = dict(flops=2 * M * K_ * D)
-        call("mrg_dense_filter_fwd3", (0, ptr(s), ptr(s_in), ptr_array(dW), ptr_array(dB), ptr(norm), 1.0 / 3.0, 1.0 / 3.0, ptr(out_d), ptr(gate),
-                                       ptr(_ws(ws3, s)), b0, b1, M, D, st), nbytes=4 * M * (K_ + 2 * D), **work)
+        call("mrg_dense_filter_fwd3", (0, ptr(s), ptr(s_in), ptr_array(dW), ptr_array(dB), ptr(norm), 1.0 / 3.0, 1.0 / 3.0,
+                                       None if gate_only else ptr(out_d), ptr(gate), ptr(_ws(ws3, s)), b0, b1, M, D, st),
+             nbytes=4 * M * (K_ + (1 if gate_only else 2) * D), **work)
         call("mrg_dense_filter_fwd3", (1, ptr(s), ptr(s_in), ptr_array(cW), ptr_array([None, None, None]), ptr(norm), 1.0 / 3.0, 1.0, ptr(out_c), None,
                                        ptr(_ws(ws3, s)), b0, b1, M, D, st), nbytes=4 * M * (K_ + D), **work)
         ctx.cfg = (b0, b1)
@@ -1447,7 +1465,7 @@ class _DensePair(torch.autograd.Function):
         call("mrg_linear_bwd_weight3", (ptr(dz_c), ptr(s), ptr(s_in), ptr_array(g_cW), ptr_array([None, None, None]), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st),
              **wwork)
         grads_d = [t for pair in zip(g_dW, g_dB) for t in pair]
-        return (gs, gs_in, None, None, None, *grads_d, *g_cW)
+        return (gs, gs_in, None, None, None, None, *grads_d, *g_cW)
 
 
 def dense_pair_available(D, tied):
@@ -1460,9 +1478,39 @@ def dense_pair_available(D, tied):
             and int(lib.mrg_linear_bwd_weight3_workspace_bytes(1, 2, 3, D, K_ - D, D)) > 0)
 
 
-def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights):
+_GATED_C = {}
+
+
+def _gated_rowscale(norm, b1, M, scale_edge, scale_self, device):
+    """The gated filter's per-row multiplier for all M rows: scale_edge * norm[r] on the b1 edge rows, scale_self on the self rows
+    (float32 products, as the row GEMM's gate epilogue forms them).  Built once per edge-norm vector (a graph's norm_flat() is one
+    cached tensor) and kept while that tensor lives."""
+    base = None if norm is None else (norm._base if norm._base is not None else norm)      # norm_flat() hands out a fresh view per call
+    key = (None if norm is None else (norm.data_ptr(), norm._version), b1, M, scale_edge, scale_self, str(device))
+    hit = _GATED_C.get(key)
+    if hit is not None and (norm is None or hit[0]() is base):
+        return hit[1]
+    c = torch.empty(M, dtype=torch.float32, device=device)
+    if norm is None:
+        c[:b1] = scale_edge
+    else:
+        torch.mul(norm[:b1], scale_edge, out=c[:b1])
+    c[b1:] = scale_self
+    if len(_GATED_C) > 64:
+        _GATED_C.clear()
+    import weakref
+    _GATED_C[key] = (weakref.ref(base) if base is not None else None, c)
+    return c
+
+
+GATED_RECOMPUTE = os.environ.get("MRG_GATED_RECOMPUTE", "1") == "1"     # lab switch: 0 = f_dense_comp's output is stored for the epilogue
+
+
+def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights, gate_only=False):
     """(f_dense_comp(s, s_in), f_comp(s, s_in)) as one autograd node; dense_params = (W_in, b_in, W_out, b_out, W_self, b_self),
-    comp_weights = (W_in, W_out, W_self).  Operands that are the same rows use the folded [D, D] weights."""
+    comp_weights = (W_in, W_out, W_self).  Operands that are the same rows use the folded [D, D] weights.
+    gate_only: the first result is f_dense_comp's GATE, tagged `_mrg_gated` -- ONLY for mixed_epilogue, which recomputes the
+    candidate's value gate * s * c wherever it reads it (the [rows, D] output is never written or re-read)."""
     dW, dB = list(dense_params[0::2]), list(dense_params[1::2])
     cW = list(comp_weights)
     if s_in is not None and same_rows(s, s_in):
@@ -1472,7 +1520,11 @@ def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights):
     norm = f32c(norm)
     if norm is not None and norm.numel() < int(b1):
         raise _lib.MrgnasError(f"dense filter: edge norm has {norm.numel()} entries, the edge rows need {int(b1)}")
-    y_d, y_c = _DensePair.apply(s, s_in, norm, int(b0), int(b1), dW[0], dB[0], dW[1], dB[1], dW[2], dB[2], *cW)
+    s = f32c(s)
+    gate_only = bool(gate_only and s.is_cuda)
+    y_d, y_c = _DensePair.apply(s, s_in, norm, int(b0), int(b1), gate_only, dW[0], dB[0], dW[1], dB[1], dW[2], dB[2], *cW)
+    if gate_only:
+        y_d._mrg_gated = (s, _gated_rowscale(norm, int(b1), s.shape[0], 1.0 / 3.0, 1.0 / 3.0, s.device))
     if FOLD_ROW_SCALE and y_d.grad_fn is not None and y_d.is_cuda:
         node = y_d.grad_fn
         node.prescaled, node.prescaled_ptr = [False, False], [None, None]

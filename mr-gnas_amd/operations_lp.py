@@ -142,9 +142,11 @@ class f_comp_op(nn.Module):
                                    self.W_out.weight, None, self.W_self.weight, None, 1.0)
 
 
-def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in):
+def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=False):
     """(f_dense_comp(g, src_emb, src_emb_in), f_comp(g, src_emb, src_emb_in)) of one MixedOp as one autograd node when the
-    shapes allow (functional.dense_filter_pair), else the two operators on their own."""
+    shapes allow (functional.dense_filter_pair), else the two operators on their own.  for_epilogue: both results go to
+    functional.mixed_epilogue and nowhere else -- f_dense_comp's may then be its gate, tagged for the epilogue to recompute the
+    output from (functional.GATED_RECOMPUTE)."""
     D = src_emb.shape[1]
     tied = src_emb_in is not None and K.same_rows(src_emb, src_emb_in)
     if not (src_emb.is_cuda and K.dense_pair_available(D, tied)):
@@ -152,7 +154,7 @@ def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in):
     b0, b1 = _bounds(g)
     dp = (op_dense.W_in.weight, op_dense.W_in.bias, op_dense.W_out.weight, op_dense.W_out.bias, op_dense.W_self.weight, op_dense.W_self.bias)
     cw = (op_comp.W_in.weight, op_comp.W_out.weight, op_comp.W_self.weight)
-    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw)
+    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw, gate_only=for_epilogue and K.GATED_RECOMPUTE)
 
 
 class f_dense_op(nn.Module):

@@ -113,7 +113,7 @@ class MixedOp(nn.Module):
                     ys.append(None)
                 elif pair is not None and k in pair:
                     if not paired:
-                        paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take())
+                        paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take(), for_epilogue=True)
                     ys.append(paired[k])
                 else:
                     ys.append(op(g, fh.take(), fi.take()))
@@ -135,7 +135,7 @@ class MixedOp(nn.Module):
                 b.record_stream(side)                  # allocator must not recycle them before that stream is done
             with torch.cuda.stream(side):
                 if pair is not None and k in pair:
-                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b)
+                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b, for_epilogue=True)
                     y = paired[k]
                     paired[pair[0] + pair[1] - k].record_stream(fork.main)
                 else:

@@ -69,7 +69,7 @@ def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels
     ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
     loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
     loss.backward()
-    out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
+    out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss.detach()), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
                ga=[a.grad for a in al[:4]])
     del og, P, al, ent, rel, loss
     free()
@@ -96,7 +96,7 @@ def supernet_case(ds, D, negative):
     loss = model.get_loss(g, ent, rel, samples_t, labels_t)
     loss.backward()
     torch.cuda.synchronize()
-    hip = dict(ent=ent.detach().clone(), rel=rel.detach().clone(), loss=float(loss),
+    hip = dict(ent=ent.detach().clone(), rel=rel.detach().clone(), loss=float(loss.detach()),
                g={k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()},
                ga=[a.grad.clone() for a in model.arch_parameters()[:4]])
     del ent, rel, loss
@@ -197,7 +197,7 @@ def test_c4_sharded_step_world1_rccl_full_size(fb_case):
         loss.backward()
         MD.all_reduce_gradients(list(model.parameters()) + model.arch_parameters()[:4])
         torch.cuda.synchronize()
-        got = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss),
+        got = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss.detach()),
                    g={k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()},
                    ga=[a.grad for a in model.arch_parameters()[:4]])
         assert abs(got["loss"] - c["hip"]["loss"]) <= 1e-4 * max(1.0, abs(c["hip"]["loss"]))      # same loss as the plain step

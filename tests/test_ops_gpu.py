@@ -478,10 +478,10 @@ def test_fused_statistics_to_coefficients_is_bit_exact(rows, D, K_):
         st = stream_of(coef)
         if fused:
             call("mrg_mix_stats_coef", (ptr_array(ys), ptr_array(gam), ptr_array(bet), ptr_array(rm), ptr_array(rv), K_, rows, float(rows), D, 1e-5, 0.1,
-                                        ptr(coef), ptr(ws), st))
+                                        ptr(coef), ptr(ws), None, st))
         else:
             sums = torch.empty(K_, 2, D, dtype=torch.float64, device=DEV)
-            call("mrg_mix_colstats", (ptr_array(ys), K_, rows, D, ptr(sums), ptr(ws), st))
+            call("mrg_mix_colstats", (ptr_array(ys), K_, rows, D, ptr(sums), ptr(ws), None, st))
             call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), ptr_array(rm), ptr_array(rv), K_, float(rows), D, 1e-5, 0.1, ptr(coef), st))
         out[fused] = [coef] + rm + rv
     for a, b in zip(out[True], out[False]):
@@ -730,3 +730,61 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
         assert torch.equal(res[True][0], res[other][0])
         for i, (a, b) in enumerate(zip(res[True][1:], res[other][1:])):
             close(a, b.cpu(), f"dense pair gradient {i} vs {other}", rtol=3e-5, atol=3e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tied", [True, False])
+@pytest.mark.parametrize("N,E,R,D", [(2000, 150000, 9, 200), (300, 5000, 4, 64), (50, 700, 3, 100)])
+def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
+    """f_dense_comp's output never stored (the row GEMM writes only the gate, the MixedOp epilogue's four passes recompute
+    gate * s * c: mrg_gated_branch) against the stored candidate: output, running statistics and EVERY gradient bit-identical --
+    with the epilogue's gradient folds on and off, in training and in eval mode."""
+    from mr_gnas_amd import supernet as S
+    gen = torch.Generator().manual_seed(7 * N + E + D + int(tied))
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    et = torch.randint(0, 2 * R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    h0 = torch.randn(E + N, D, generator=gen)
+    hin0 = h0 if tied else torch.randn(E + N, D, generator=gen)
+    w0 = torch.softmax(torch.randn(len(O.FIRST_OPS), generator=gen), 0)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    add0 = torch.randn(E + N, D, generator=gen).to(DEV)
+    torch.manual_seed(5)
+    mixed = S.MixedOp(D, 0.0, O.FIRST_OPS).to(DEV)
+    S.xavier_init_(mixed)
+    state0 = {k: v.clone() for k, v in mixed.state_dict().items()}
+    calls = []
+    real_call = K.call
+
+    def spy(name, args, **kw):
+        calls.append((name, args))
+        return real_call(name, args, **kw)
+
+    try:
+        for folds in (True, False):
+            for training in (True, False):
+                res = {}
+                for gated in (True, False):
+                    K.GATED_RECOMPUTE, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = gated, folds, folds
+                    mixed.load_state_dict(state0)
+                    mixed.train(training)
+                    mixed.zero_grad(set_to_none=True)
+                    h = h0.clone().to(DEV).requires_grad_(True)
+                    hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
+                    w = w0.clone().to(DEV).requires_grad_(True)
+                    del calls[:]
+                    K.call = spy
+                    out = mixed(w, g, h, hin, addend=add0)
+                    K.call = real_call
+                    fwd3 = [a for n, a in calls if n == "mrg_dense_filter_fwd3" and a[0] == 0]
+                    assert len(fwd3) == 1 and (fwd3[0][8] is None) == gated, "the gated row GEMM stores its output exactly when the candidate is stored"
+                    out.backward(gout)
+                    torch.cuda.synchronize()
+                    res[gated] = ([out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
+                                  + [b.clone() for b in mixed.buffers()])
+                for i, (a, b) in enumerate(zip(res[True], res[False])):
+                    assert torch.equal(a, b), f"gate-only vs stored f_dense_comp: tensor {i} differs (folds {folds}, training {training})"
+    finally:
+        K.call = real_call
+        K.GATED_RECOMPUTE, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = True, True, True
