@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate), mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -133,6 +133,16 @@ int64_t mrg_gate_bwd_workspace_bytes(int64_t M, int D);
 int mrg_gate_bwd(const float *gout, const float *s, const float *s_in, const float *norm,
                  const float *uvc, float *gs, float *gs_in, float *d_uvc, void *ws,
                  int64_t b0, int64_t b1, int64_t M, int D, float scale, void *stream);
+/* f_sparse_op_comp as a row factor: the candidate y = s * fvec[r] is recomputed by the MixedOp epilogue (mrg_gated_branch.row_k)
+ * instead of being stored.  fvec[r] = sigmoid(u.s + v.s_in + c0) * t_r is mrg_gate_fwd's factor (same expression and dot order:
+ * s * fvec[r] equals its output bit for bit); hvec[r] = t_r * gate * (1 - gate).  fvec, hvec: [M]. */
+int mrg_gate_row_fwd(const float *s, const float *s_in, const float *norm, const float *uvc, float *fvec, float *hvec,
+                     int64_t b0, int64_t b1, int64_t M, int D, float scale, void *stream);
+/* q [M] (mrg_mix_bwd_apply's row_dq: the gradient w.r.t. fvec), dz_r = q_r * hvec[r] -> gs_in [M, D] = dz_r * v (s_in != NULL)
+ * and d_uvc [3][MRG_GATE_LD(D)] for mrg_gate_param_grad3; the gradient w.r.t. s was added by the epilogue.
+ * ws: mrg_gate_bwd_workspace_bytes(M, D). */
+int mrg_gate_row_bwd(const float *q, const float *hvec, const float *s, const float *s_in, const float *uvc, float *gs_in, float *d_uvc,
+                     void *ws, int64_t b0, int64_t b1, int64_t M, int D, void *stream);
 /* chain rule back to the nn.Linear parameters:  d_uvc [in_dim+1] ->
  * gW [D, in_dim] = a (x) d_uv,  gb [D] = a * d_c (NULL ok),  ga [D] = W d_uv + b d_c. */
 int mrg_gate_param_grad(const float *W, const float *b, const float *a, const float *d_uvc,
@@ -244,9 +254,25 @@ int64_t mrg_mix_workspace_bytes(int K, int D);
  * backward less; s is the MixedOp's input state.
  * In mrg_mix_bwd_apply, when rs_on[k] == 2 for this k, fold_s[k] must be `s` and fold_gate[k] must be y_host[k]. */
 typedef struct mrg_gated_branch {
-  int32_t k;
+  int32_t k;               /* the gated candidate, < 0: none */
   const float *s;          /* [rows, D] device */
   const float *rowscale;   /* [rows] device */
+  /* The ROW-SCALED candidate (f_sparse_op_comp, reference models/operations_lp.py:304-343: a scalar gate per row), never stored
+   * either: y_row_k[r][c] = s[r][c] * row_f[r] with row_f from mrg_gate_row_fwd (bit for bit mrg_gate_fwd's output);
+   * y_host[row_k] must be `s` itself.  row_k < 0: none. */
+  int32_t row_k;
+  const float *row_f;      /* [rows] device */
+  /* mrg_mix_bwd_apply only (the other entry points ignore them).  The candidate gets NO gradient tensor (gy_host[row_k] must be
+   * NULL): with gy its gradient w.r.t. y, the kernel writes row_dq[r] = sum_c gy * s -- the gradient w.r.t. row_f[r], which
+   * mrg_gate_row_bwd turns into the parameter and s_in gradients -- and, with dz_r = row_dq[r] * row_h[r], ADDS the gradient
+   * w.r.t. s, gy * row_f[r] + dz_r * u_seg[c], into fold_gs[k] of the gated candidate k (required: rs_on[k] == 2; both are
+   * gradients w.r.t. the rows s).
+   * row_uvc: mrg_gate_collapse3's [3][row_ld] vectors; rows [0, b0) use segment 0, [b0, b1) 1, [b1, rows) 2.  D <= 256. */
+  const float *row_h;      /* [rows] device */
+  const float *row_uvc;
+  int32_t row_ld;
+  int64_t b0, b1;
+  float *row_dq;           /* [rows] device, out */
 } mrg_gated_branch;
 int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, double *sums, void *ws,
                      const mrg_gated_branch *gated, void *stream);

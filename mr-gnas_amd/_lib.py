@@ -52,6 +52,8 @@ SIGNATURES = {
     "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_sum_buffers": (_I, [_P, _I, _P, _L, _I, _P]),
     "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "mrg_gate_row_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),
+    "mrg_gate_row_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P]),
     "mrg_mix_workspace_bytes": (_L, [_I, _I]),
     "mrg_mix_colstats": (_I, [_P, _I, _L, _I, _P, _P, _P, _P]),
     "mrg_mix_finalize_fwd": (_I, [_P, _P, _P, _P, _P, _I, ctypes.c_double, _I, _F, _F, _P, _P]),
@@ -232,16 +234,21 @@ def ptr_array(tensors):
 
 class GatedBranch(ctypes.Structure):
     """include/mrgnas.h: mrg_gated_branch."""
-    _fields_ = [("k", ctypes.c_int32), ("s", ctypes.c_void_p), ("rowscale", ctypes.c_void_p)]
+    _fields_ = [("k", ctypes.c_int32), ("s", ctypes.c_void_p), ("rowscale", ctypes.c_void_p),
+                ("row_k", ctypes.c_int32), ("row_f", ctypes.c_void_p), ("row_h", ctypes.c_void_p), ("row_uvc", ctypes.c_void_p),
+                ("row_ld", ctypes.c_int32), ("b0", ctypes.c_int64), ("b1", ctypes.c_int64), ("row_dq", ctypes.c_void_p)]
 
 
-def gated_branch(spec):
-    """HOST mrg_gated_branch for spec = (k, s, rowscale [rows]), or None.  Returns the by-reference argument (which keeps the
-    structure alive for the call)."""
+def gated_branch(spec, row_dq=None):
+    """HOST mrg_gated_branch for spec = dict(k, s, c) and / or dict(row_k, s, row_f, row_h, row_uvc, row_ld, b0, b1) merged, or None.
+    row_dq: the [rows] output of mrg_mix_bwd_apply.  Returns the by-reference argument (which keeps the structure alive for the call)."""
     if spec is None:
         return None
-    k, s, rowscale = spec
-    return ctypes.byref(GatedBranch(int(k), s.data_ptr(), rowscale.data_ptr()))
+    dp = lambda t: None if t is None else t.data_ptr()
+    g = GatedBranch(int(spec.get("k", -1)), dp(spec["s"]), dp(spec.get("c")), int(spec.get("row_k", -1)), dp(spec.get("row_f")),
+                    dp(spec.get("row_h")), dp(spec.get("row_uvc")), int(spec.get("row_ld", 0)), int(spec.get("b0", 0)), int(spec.get("b1", 0)),
+                    dp(row_dq))
+    return ctypes.byref(g)
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("MRG_RAW_STREAM", "1") == "1" else None

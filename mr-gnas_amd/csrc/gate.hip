@@ -186,6 +186,133 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
   }
 }
 
+// ---- the gate as a ROW FACTOR (the candidate y = s * f_r is never stored: the MixedOp epilogue recomputes it, mixedop.hip) ----
+// fvec[r] = sigmoid(u.s + v.s_in + c0) * t_r   (t_r = scale * norm_r on edge rows, scale on self rows: f of gate_fwd_k, same
+// expression, same dot order: y = s * fvec[r] is gate_fwd_k's output bit for bit);  hvec[r] = t_r * gate * (1 - gate), the factor
+// between the row dot q_r = sum_c gy * s and the pre-activation gradient dz_r of gate_bwd_k.
+template <int VEC, int LPR, int KMAX, bool HAS_IN>
+__global__ __launch_bounds__(MRG_BLOCK) void gate_row_fwd_k(const float* __restrict__ s, const float* __restrict__ sin_,
+                                                            const float* __restrict__ norm, const float* __restrict__ uvc,
+                                                            float* __restrict__ fvec, float* __restrict__ hvec, SegPlan p, int D, float scale) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int b = blockIdx.x;
+  if (b >= p.blk[3]) return;
+  const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
+  const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const float* u = uvc + (int64_t)seg * MRG_GATE_LD(D);
+  const float cc = u[HAS_IN ? 2 * D : D];
+  Vec<VEC> uk[KMAX], vk[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    uk[k] = c < dv ? Vec<VEC>::load(u + c * VEC) : Vec<VEC>::fill(0.f);
+    vk[k] = (HAS_IN && c < dv) ? Vec<VEC>::load(u + D + c * VEC) : Vec<VEC>::fill(0.f);
+  }
+  const bool use_norm = norm != nullptr && seg < 2;
+  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        const Vec<VEC> sk = Vec<VEC>::load(s + r * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dot += sk[j] * uk[k][j];
+        if (HAS_IN) {
+          Vec<VEC> x = Vec<VEC>::load(sin_ + r * D + c * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dot += x[j] * vk[k][j];
+        }
+      }
+    }
+    const float z = group_sum<LPR>(dot) + cc;
+    const float gt = sigmoidf_fast(z);
+    const float nv = use_norm ? norm[r] : 1.0f;
+    if (sl == 0) {
+      fvec[r] = gt * scale * nv;
+      const float t = scale * nv;
+      hvec[r] = t * gt * (1.0f - gt);
+    }
+  }
+}
+
+// q[r] (the gradient w.r.t. fvec[r], from the epilogue's backward), dz_r = q_r * hvec[r] -> gs_in = dz_r * v (HAS_IN), per-block
+// partials of du = sum_r dz_r s_r, dv = sum_r dz_r s_in_r, dc = sum_r dz_r  (the block reduction and its order are gate_bwd_k's).
+// The gradient w.r.t. s (gy * f_r + dz_r * u) was added to the epilogue's gs_out.
+template <int VEC, int LPR, int KMAX, bool HAS_IN>
+__global__ __launch_bounds__(MRG_BLOCK) void gate_row_bwd_k(const float* __restrict__ qv, const float* __restrict__ hv, const float* __restrict__ s,
+                                                            const float* __restrict__ sin_, const float* __restrict__ uvc,
+                                                            float* __restrict__ gsin, float* __restrict__ ws, SegPlan p, int D) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  constexpr int WIDTH = LPR * KMAX * VEC;                 // >= D
+  __shared__ float red[RPB * (2 * WIDTH + 1)];
+  const int b = blockIdx.x;
+  if (b >= p.blk[3]) return;
+  const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
+  const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int dv = D / VEC;
+  const int ld = MRG_GATE_LD(D);
+  const int cidx = HAS_IN ? 2 * D : D;
+  const float* u = uvc + (int64_t)seg * ld;
+  Vec<VEC> vk[KMAX], du[KMAX], dvv[KMAX];
+  float dc = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+    vk[k] = (HAS_IN && c < dv) ? Vec<VEC>::load(u + D + c * VEC) : Vec<VEC>::fill(0.f);
+    du[k] = Vec<VEC>::fill(0.f);
+    dvv[k] = Vec<VEC>::fill(0.f);
+  }
+  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
+    const float dz = qv[r] * hv[r];
+    dc += dz;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int c = sl + k * LPR;
+      if (c < dv) {
+        const Vec<VEC> sk = Vec<VEC>::load(s + r * D + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) du[k][j] += dz * sk[j];
+        if (HAS_IN) {
+          const Vec<VEC> xk = Vec<VEC>::load(sin_ + r * D + c * VEC);
+          Vec<VEC> o2;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            o2[j] = dz * vk[k][j];
+            dvv[k][j] += dz * xk[j];
+          }
+          o2.store(gsin + r * D + c * VEC);
+        }
+      }
+    }
+  }
+  float* mine = red + rw * (2 * WIDTH + 1);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int c = sl + k * LPR;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mine[c * VEC + j] = du[k][j];
+      mine[WIDTH + c * VEC + j] = dvv[k][j];
+    }
+  }
+  if (sl == 0) mine[2 * WIDTH] = dc;
+  __syncthreads();
+  float* dst = ws + (int64_t)b * ld;
+  for (int t = threadIdx.x; t < ld; t += MRG_BLOCK) {
+    int srcidx = t < D ? t : ((HAS_IN && t < 2 * D) ? WIDTH + (t - D) : (t == cidx ? 2 * WIDTH : -1));
+    float acc = 0.f;
+    if (srcidx >= 0) {
+#pragma unroll
+      for (int q = 0; q < RPB; ++q) acc += red[q * (2 * WIDTH + 1) + srcidx];
+    }
+    dst[t] = acc;
+  }
+}
+
 // d_uvc[s][t] = sum over the blocks of segment s, in block order
 __global__ void gate_reduce_k(const float* __restrict__ ws, float* __restrict__ d_uvc, SegPlan p, int ld) {
   int seg = blockIdx.y;
@@ -444,6 +571,61 @@ extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in
     if (M > 0) {                                                                                                        \
       if (s_in) hipLaunchKernelGGL((gate_bwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
       else hipLaunchKernelGGL((gate_bwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+    }                                                                                                                   \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  launch_ordered_reduce_ranges<float>((const float*)ws, d_uvc, p.blk, 3, ld, ld, ld, st);
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// f_sparse_op_comp as a row factor (see gate_row_fwd_k): fvec / hvec [M].
+extern "C" int mrg_gate_row_fwd(const float* s, const float* s_in, const float* norm, const float* uvc, float* fvec, float* hvec,
+                                int64_t b0, int64_t b1, int64_t M, int D, float scale, void* stream) {
+  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (M == 0) return MRG_OK;
+  if (!s || !uvc || !fvec || !hvec) return MRG_E_NULLPTR;
+  RowGeom g = row_geom(D, aligned16(s) && aligned16(s_in) && aligned16(uvc));
+  if (!g.ok) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V, L, K)                                                                                                   \
+  do {                                                                                                                  \
+    int grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                        \
+    if (grid < 3) grid = 3;                                                                                             \
+    SegPlan p = make_plan(b0, b1, M, grid);                                                                             \
+    if (s_in) hipLaunchKernelGGL((gate_row_fwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, fvec, hvec, p, D, scale); \
+    else hipLaunchKernelGGL((gate_row_fwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, fvec, hvec, p, D, scale); \
+  } while (0)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
+
+// q [M] (written by mrg_mix_bwd_apply, mrg_gated_branch.row_dq), hvec [M] (mrg_gate_row_fwd) -> gs_in [M, D] (s_in != NULL) and
+// d_uvc [3][MRG_GATE_LD(D)] (then mrg_gate_param_grad3).  ws: mrg_gate_bwd_workspace_bytes(M, D).
+extern "C" int mrg_gate_row_bwd(const float* q, const float* hvec, const float* s, const float* s_in, const float* uvc, float* gs_in, float* d_uvc,
+                                void* ws, int64_t b0, int64_t b1, int64_t M, int D, void* stream) {
+  if (D <= 0 || M < 0 || b0 < 0 || b1 < b0 || M < b1) return MRG_E_SHAPE;
+  if (!uvc || !d_uvc) return MRG_E_NULLPTR;
+  if (M > 0 && (!q || !hvec || !s)) return MRG_E_NULLPTR;
+  if (s_in && !gs_in) return MRG_E_NULLPTR;
+  if (!ws) return MRG_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = MRG_GATE_LD(D);
+  RowGeom g = row_geom(D, aligned16(s) && aligned16(s_in) && aligned16(gs_in) && aligned16(uvc));
+  if (!g.ok) return MRG_E_SHAPE;
+  SegPlan p{};
+#define CALL(V, L, K)                                                                                                   \
+  do {                                                                                                                  \
+    int grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                        \
+    if (grid < 3) grid = 3;                                                                                             \
+    p = make_plan(b0, b1, M, grid);                                                                                     \
+    if (M > 0) {                                                                                                        \
+      if (s_in) hipLaunchKernelGGL((gate_row_bwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, q, hvec, s, s_in, uvc, gs_in, (float*)ws, p, D); \
+      else hipLaunchKernelGGL((gate_row_bwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, q, hvec, s, s_in, uvc, gs_in, (float*)ws, p, D); \
     }                                                                                                                   \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);

@@ -32,7 +32,12 @@ struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; 
 // four reads (statistics, combine, backward reduction, backward apply) that do not happen; s is the MixedOp's input state, which
 // the f_identity candidate of the same MixedOp reads at the same place (one L2 / L1 hit more, no HBM pass).   k < 0: none.
 struct GatedPack { int k; const float* s; const float* c;
-                   int pair_k; };   // pair_k: the candidate whose stored output is s itself (f_identity), -1 = none  (statistics kernel)
+                   int pair_k;      // pair_k: the candidate whose stored output is s itself (f_identity), -1 = none  (statistics kernel)
+                   // the row-scaled candidate (f_sparse_op_comp, never stored either): y = s * rf[r]; ys.p[rk] == s.   rk < 0: none
+                   int rk; const float* rf;
+                   // ... its backward (mix_bwd_apply_k only): rh[r] = d pre-activation / d row dot, the collapsed gate vectors
+                   // uvc[seg][uld] of the three direction segments [0, b0) [b0, b1) [b1, rows), rdq[r] out (the gradient w.r.t. rf[r])
+                   const float* rh; const float* uvc; int uld; int64_t b0, b1; float* rdq; };
 
 // c: the candidate's per-row multiplier for ALL rows (the caller expands scale_edge * norm on edge rows, scale_self on self rows,
 // once per graph): an unconditional load.  A conditional one (edge rows only) was compiled into an exec-masked block that waited for
@@ -66,9 +71,10 @@ __device__ __forceinline__ void colstats_flush(const double (&s1)[KMAX][VEC], co
   }
 }
 
-// GATED: candidate gp.k is recomputed from its gate (GatedPack).  When gp.pair_k >= 0 -- f_identity of the same MixedOp, whose
-// output IS the multiplicand s -- the two candidates share ONE sweep (s is read once for both; a sweep per candidate would read
-// it from HBM twice, the tensors being far larger than the caches).
+// GATED: candidate gp.k is recomputed from its gate and candidate gp.rk from its row factor (GatedPack); with gp.pair_k >= 0 --
+// f_identity of the same MixedOp, whose output IS the multiplicand s -- up to three candidates are functions of the same rows s
+// and share ONE sweep (s is read once for all; a sweep per candidate would read it from HBM each time, the tensors being far
+// larger than the caches).  Each candidate's sums see the same values in the same order as a sweep of its own.
 template <int VEC, int LPR, int KMAX, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, int64_t rows, int D, double* __restrict__ ws, GatedPack gp) {
   constexpr int RPB = MRG_BLOCK / LPR;
@@ -77,49 +83,53 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, i
   const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
   const int dv = D / VEC;
   const int64_t step = (int64_t)gridDim.x * RPB;
+  int first = MRG_MIX_MAXK;                                // the shared sweep runs at the first of its candidates
+  if (GATED) {
+    if (gp.k >= 0 && gp.k < first) first = gp.k;
+    if (gp.pair_k >= 0 && gp.pair_k < first) first = gp.pair_k;
+    if (gp.rk >= 0 && gp.rk < first) first = gp.rk;
+  }
   for (int k = 0; k < K; ++k) {
     const float* __restrict__ y = ys.p[k];
-    if (GATED && k == gp.k && gp.pair_k >= 0) continue;     // swept together with candidate pair_k
+    const bool shared = GATED && (k == gp.k || k == gp.pair_k || k == gp.rk);
+    if (shared && k != first) continue;
     double s1[KMAX][VEC], s2[KMAX][VEC];
 #pragma unroll
     for (int q = 0; q < KMAX; ++q)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s1[q][j] = 0.0; s2[q][j] = 0.0; }
-    if (GATED && (k == gp.k || k == gp.pair_k)) {
-      // t1 / t2: the recomputed candidate gate * s * c_r; s1 / s2: s itself (only stored when it is candidate pair_k)
-      const float* __restrict__ gate = ys.p[gp.k];
-      double t1[KMAX][VEC], t2[KMAX][VEC];
+    if (shared) {
+      // s1 / s2: s itself (candidate pair_k); t1 / t2: gate * s * c_r (candidate gp.k); u1 / u2: s * f_r (candidate gp.rk)
+      const float* __restrict__ gate = gp.k >= 0 ? ys.p[gp.k] : gp.s;
+      double t1[KMAX][VEC], t2[KMAX][VEC], u1[KMAX][VEC], u2[KMAX][VEC];
 #pragma unroll
       for (int q = 0; q < KMAX; ++q)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { t1[q][j] = 0.0; t2[q][j] = 0.0; }
+        for (int j = 0; j < VEC; ++j) { t1[q][j] = 0.0; t2[q][j] = 0.0; u1[q][j] = 0.0; u2[q][j] = 0.0; }
       int64_t r = (int64_t)blockIdx.x * RPB + rw;
-      for (; r + 3 * step < rows; r += 4 * step) {          // four rows per trip: eight independent 16-byte loads in flight per lane
-        float ck[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ck[u] = gated_rowscale(gp, r + u * step);
+      for (; r + step < rows; r += 2 * step) {              // two rows per trip: four independent 16-byte loads in flight per lane
+        const float ck0 = gated_rowscale(gp, r), ck1 = gated_rowscale(gp, r + step);
+        const float rf0 = gp.rf[r], rf1 = gp.rf[r + step];
 #pragma unroll
         for (int q = 0; q < KMAX; ++q) {
           int c = sl + q * LPR;
           if (c < dv) {
-            Vec<VEC> sv[4], ga[4];
+            const Vec<VEC> sv0 = Vec<VEC>::load(gp.s + r * D + c * VEC), sv1 = Vec<VEC>::load(gp.s + (r + step) * D + c * VEC);
+            const Vec<VEC> ga0 = Vec<VEC>::load(gate + r * D + c * VEC), ga1 = Vec<VEC>::load(gate + (r + step) * D + c * VEC);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sv[u] = Vec<VEC>::load(gp.s + (r + u * step) * D + c * VEC);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ga[u] = Vec<VEC>::load(gate + (r + u * step) * D + c * VEC);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int j = 0; j < VEC; ++j) { double d = (double)sv[u][j]; s1[q][j] += d; s2[q][j] += d * d; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int j = 0; j < VEC; ++j) { double d = (double)(ga[u][j] * sv[u][j] * ck[u]); t1[q][j] += d; t2[q][j] += d * d; }
+            for (int j = 0; j < VEC; ++j) {
+              double d = (double)sv0[j]; s1[q][j] += d; s2[q][j] += d * d;
+              d = (double)sv1[j]; s1[q][j] += d; s2[q][j] += d * d;
+              d = (double)(ga0[j] * sv0[j] * ck0); t1[q][j] += d; t2[q][j] += d * d;
+              d = (double)(ga1[j] * sv1[j] * ck1); t1[q][j] += d; t2[q][j] += d * d;
+              d = (double)(sv0[j] * rf0); u1[q][j] += d; u2[q][j] += d * d;
+              d = (double)(sv1[j] * rf1); u1[q][j] += d; u2[q][j] += d * d;
+            }
           }
         }
       }
       for (; r < rows; r += step) {
-        const float ck = gated_rowscale(gp, r);
+        const float ck = gated_rowscale(gp, r), rf = gp.rf[r];
 #pragma unroll
         for (int q = 0; q < KMAX; ++q) {
           int c = sl + q * LPR;
@@ -129,12 +139,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, i
             for (int j = 0; j < VEC; ++j) {
               double d = (double)sv[j]; s1[q][j] += d; s2[q][j] += d * d;
               d = (double)(ga[j] * sv[j] * ck); t1[q][j] += d; t2[q][j] += d * d;
+              d = (double)(sv[j] * rf); u1[q][j] += d; u2[q][j] += d * d;
             }
           }
         }
       }
-      colstats_flush<VEC, LPR, KMAX>(t1, t2, red, ws + ((int64_t)blockIdx.x * K + gp.k) * 2 * D, D, sl, rw);
-      if (k == gp.pair_k) colstats_flush<VEC, LPR, KMAX>(s1, s2, red, ws + ((int64_t)blockIdx.x * K + k) * 2 * D, D, sl, rw);
+      if (gp.k >= 0) colstats_flush<VEC, LPR, KMAX>(t1, t2, red, ws + ((int64_t)blockIdx.x * K + gp.k) * 2 * D, D, sl, rw);
+      if (gp.pair_k >= 0) colstats_flush<VEC, LPR, KMAX>(s1, s2, red, ws + ((int64_t)blockIdx.x * K + gp.pair_k) * 2 * D, D, sl, rw);
+      if (gp.rk >= 0) colstats_flush<VEC, LPR, KMAX>(u1, u2, red, ws + ((int64_t)blockIdx.x * K + gp.rk) * 2 * D, D, sl, rw);
       continue;
     }
     if (y != nullptr) {
@@ -269,11 +281,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
         // MixedOps feeding a state) -- added here instead of by a separate full-size kernel
         Vec<VEC> acc = addend ? Vec<VEC>::load(addend + r * D + c * VEC) : Vec<VEC>::fill(0.f);
         // the recomputed candidate's row scale and multiplicand: issued FIRST (loads return in order: the candidates before
-        // it can be consumed while the later loads are in flight); s comes from candidate pair_k's registers when it is one
-        float gck = 1.f;
+        // it can be consumed while the later loads are in flight).  The candidates that ARE s (f_identity, the row-scaled one) still
+        // load it themselves: the repeated addresses hit in L1, and taking them from gsv by a select was measured slower (lab: 413 vs
+        // 409 us, backward reduction 482 vs 425 us) and let the compiler re-associate the products (1-ulp differences)
+        float gck = 1.f, rfv = 1.f;
         Vec<VEC> gsv = Vec<VEC>::fill(0.f);
         if constexpr (GATED) {
           gck = gated_rowscale(gp, r);
+          rfv = gp.rf[r];
           gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
         }
         // phase 1: every branch's load is issued before any is used (a load consumed inside its own `if (k < K)`
@@ -288,9 +303,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           if (k < K) {
             Vec<VEC> v = vin[k];
-            if constexpr (GATED) {                         // the recomputed candidate: gate -> gate * s * c_r; the others * 1 * 1
+            if constexpr (GATED) {                         // the recomputed candidates: gate -> gate * s * c_r, s -> s * 1 * f_r; the others * 1 * 1
               const bool isg = k == gp.k;                  // (selects, not a branch: the loads above stay in flight together)
-              const float cm = isg ? gck : 1.0f;
+              const float cm = isg ? gck : (k == gp.rk ? rfv : 1.0f);
 #pragma unroll
               for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
             }
@@ -335,10 +350,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
       if (c < dv) {
-        float gck = 1.f;                                   // the recomputed candidate's row scale and multiplicand (see mix_fwd_k)
+        float gck = 1.f, rfv = 1.f;                        // the recomputed candidates' row multipliers and multiplicand (see mix_fwd_k)
         Vec<VEC> gsv = Vec<VEC>::fill(0.f);
         if constexpr (GATED) {
           gck = gated_rowscale(gp, r);
+          rfv = gp.rf[r];
           gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
         }
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
@@ -352,9 +368,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
         for (int k = 0; k < KB; ++k) {
           if (k < K) {
             Vec<VEC> v = vin[k];
-            if constexpr (GATED) {                         // the recomputed candidate: gate -> gate * s * c_r; the others * 1 * 1
+            if constexpr (GATED) {                         // the recomputed candidates: gate -> gate * s * c_r, s -> s * 1 * f_r; the others * 1 * 1
               const bool isg = k == gp.k;
-              const float cm = isg ? gck : 1.0f;
+              const float cm = isg ? gck : (k == gp.rk ? rfv : 1.0f);
 #pragma unroll
               for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
             }
@@ -427,6 +443,11 @@ __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double 
 }
 
 // ---- backward apply: gy_k = (gr - c1 - xhat*c2) * scale      (skipped where gy_k is NULL)
+// The row-scaled candidate gp.rk (GATED variant; f_sparse_op_comp, y = s * f_r with f_r = sigmoid(u.s + v.s_in + c0) * t_r) has no
+// gradient tensor of its own: with gy its gradient w.r.t. y, this kernel forms the row dot q_r = sum_c gy * s (the lanes of the
+// row, same order as gate_bwd_k) -> gp.rdq[r], the gradient w.r.t. f_r, from which mrg_gate_row_bwd derives the candidate's
+// parameter / s_in gradients; and with dz_r = q_r * h_r (h_r = t_r * gate * (1 - gate), saved by the forward) it ADDS the candidate's
+// whole gradient w.r.t. s, gy * f_r + dz_r * u[c], into the gated candidate's direct term gs_out (gradients w.r.t. the same rows s).
 template <int VEC, int LPR, int KMAX, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
 #pragma unroll
   for (int k = 0; k < MRG_MIX_MAXK; ++k) {
     wk[k] = k < K ? w[k] : 0.f;
-    need[k] = k < K && gys.p[k] != nullptr;
+    need[k] = k < K && (gys.p[k] != nullptr || (GATED && k == gp.rk));
   }
 #pragma unroll
   for (int k = 0; k < MRG_MIX_MAXK; ++k)
@@ -454,16 +475,25 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
 #pragma unroll
       for (int q = 0; q < MRG_MIX_MAXK; ++q) if (q == rsp.add_from[k]) need[q] = true;
     }
+  const bool hasr = GATED && gp.rk >= 0;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
-      int c = sl + q * LPR;
-      if (c < dv) {
-        float gck = 1.f;                                   // the recomputed candidate's row scale and multiplicand (see mix_fwd_k)
-        Vec<VEC> gsv = Vec<VEC>::fill(0.f), gga = Vec<VEC>::fill(0.f);
-        if constexpr (GATED) {
+      const int c = sl + q * LPR;
+      const bool act = c < dv;
+      float gck = 1.f, rfv = 1.f, rhv = 0.f;               // the recomputed candidates' row multipliers and s (see mix_fwd_k)
+      Vec<VEC> gsv = Vec<VEC>::fill(0.f), gga = Vec<VEC>::fill(0.f), guv = Vec<VEC>::fill(0.f);
+      Vec<VEC> ov[MRG_MIX_MAXK];                           // every wanted gy_k first: a gated candidate may add another one's
+      Vec<VEC> orv = Vec<VEC>::fill(0.f);                  // gy of the row-scaled candidate
+      float dq = 0.f;
+      if (act) {
+        if constexpr (GATED) {                             // (unconditional: the host hands safe pointers for what is absent)
           gck = gated_rowscale(gp, r);
+          rfv = gp.rf[r];
+          rhv = gp.rh[r];
           gsv = Vec<VEC>::load(gp.s + r * D + c * VEC);
+          const int seg = (r >= gp.b0) + (r >= gp.b1);
+          guv = Vec<VEC>::load(gp.uvc + (int64_t)seg * gp.uld + c * VEC);
         }
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
         Vec<VEC> vin[MRG_MIX_MAXK];                        // all loads first (see mix_fwd_k)
@@ -474,14 +504,18 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
         }
         if constexpr (GATED) {
 #pragma unroll
-          for (int k = 0; k < MRG_MIX_MAXK; ++k)
+          for (int k = 0; k < MRG_MIX_MAXK; ++k) {
             if (k == gp.k) {
               gga = vin[k];
 #pragma unroll
               for (int j = 0; j < VEC; ++j) vin[k][j] = vin[k][j] * gsv[j] * gck;
             }
+            if (k == gp.rk) {
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) vin[k][j] = vin[k][j] * rfv;
+            }
+          }
         }
-        Vec<VEC> ov[MRG_MIX_MAXK];                         // every wanted gy_k first: a gated candidate may add another one's
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           ov[k] = Vec<VEC>::fill(0.f);
@@ -499,6 +533,20 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
             }
           }
         }
+        if (hasr) {
+#pragma unroll
+          for (int k = 0; k < MRG_MIX_MAXK; ++k) if (k == gp.rk) orv = ov[k];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dq += orv[j] * gsv[j];
+        }
+      }
+      float dzr = 0.f;
+      if (hasr) {                                          // all lanes of the row (inactive ones carry 0): KMAX == 1 (host-checked)
+        const float qr = group_sum<LPR>(dq);
+        dzr = qr * rhv;                                    // (used by the active lanes only, which loaded rhv)
+        if (sl == 0) gp.rdq[r] = qr;
+      }
+      if (act) {
 #pragma unroll
         for (int k = 0; k < MRG_MIX_MAXK; ++k) {
           if (k < K && gys.p[k] != nullptr) {
@@ -519,11 +567,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
                 const int af = rsp.add_from[k];
                 if (af >= 0) {                             // + the gradient of the candidate whose output IS this one's operand s
 #pragma unroll
-                  for (int q = 0; q < MRG_MIX_MAXK; ++q)
-                    if (q == af) {
+                  for (int qq = 0; qq < MRG_MIX_MAXK; ++qq)
+                    if (qq == af) {
 #pragma unroll
-                      for (int j = 0; j < VEC; ++j) o2[j] += ov[q][j];
+                      for (int j = 0; j < VEC; ++j) o2[j] += ov[qq][j];
                     }
+                }
+                if (hasr && k == gp.k) {                   // + the row-scaled candidate's gradient w.r.t. s: gy * f_r + dz_r * u
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) o2[j] += orv[j] * rfv + dzr * guv[j];
                 }
                 o2.store(rsp.gs_out[k] + r * D + c * VEC);
               } else {                                     // f_comp: dz = g * c
@@ -833,16 +885,36 @@ static int mix_grid(int64_t rows, int lpr) {
 
 static bool pack_ok(const void* const* host, int K) { return host != nullptr && K >= 1 && K <= MRG_MIX_MAXK; }
 
-// host descriptor (include/mrgnas.h: mrg_gated_branch) -> kernel argument; *al: every pointer it adds is 16-byte aligned
-static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, int K, GatedPack* gp, bool* al) {
+// host descriptor (include/mrgnas.h: mrg_gated_branch) -> kernel argument; *al: every pointer it adds is 16-byte aligned.
+// Absent candidates keep their index < 0 and get SAFE pointers (valid [rows] / [rows, D] memory): the kernels load their row
+// factors unconditionally and discard them by a select.
+static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, int K, GatedPack* gp, bool* al, bool apply = false) {
   *gp = GatedPack{};
-  gp->k = -1; gp->pair_k = -1;
-  if (!gb || gb->k < 0) return MRG_OK;
-  if (gb->k >= K) return MRG_E_SHAPE;
-  if (!gb->s || !gb->rowscale || !y_host[gb->k]) return MRG_E_NULLPTR;       // the gate stands where the candidate's output would
-  gp->k = gb->k; gp->s = gb->s; gp->c = gb->rowscale;
+  gp->k = -1; gp->pair_k = -1; gp->rk = -1;
+  if (!gb || (gb->k < 0 && gb->row_k < 0)) return MRG_OK;
+  if (gb->k >= K || gb->row_k >= K || (gb->k >= 0 && gb->k == gb->row_k)) return MRG_E_SHAPE;
+  if (!gb->s) return MRG_E_NULLPTR;
+  gp->s = gb->s;
+  if (gb->k >= 0) {
+    if (!gb->rowscale || !y_host[gb->k]) return MRG_E_NULLPTR;       // the gate stands where the candidate's output would
+    gp->k = gb->k; gp->c = gb->rowscale;
+  }
+  if (gb->row_k >= 0) {
+    if (!gb->row_f) return MRG_E_NULLPTR;
+    if (y_host[gb->row_k] != gb->s) return MRG_E_SHAPE;               // the row-scaled candidate's slot holds s itself
+    gp->rk = gb->row_k; gp->rf = gb->row_f;
+    if (apply) {
+      if (!gb->row_h || !gb->row_uvc || !gb->row_dq) return MRG_E_NULLPTR;
+      if (gb->b0 < 0 || gb->b1 < gb->b0 || gb->row_ld <= 0) return MRG_E_SHAPE;
+      gp->rh = gb->row_h; gp->uvc = gb->row_uvc; gp->uld = gb->row_ld; gp->b0 = gb->b0; gp->b1 = gb->b1; gp->rdq = gb->row_dq;
+      *al = *al && aligned16(gb->row_uvc) && gb->row_ld % 4 == 0;
+    }
+  }
+  if (!gp->c) gp->c = gp->rf;
+  if (!gp->rf) gp->rf = gp->c;
+  if (!gp->rh) { gp->rh = gp->rf; gp->uvc = gp->s; gp->uld = 0; gp->b0 = gp->b1 = 0; }   // loaded, never used
   for (int q = 0; q < K; ++q)
-    if (q != gb->k && y_host[q] == gb->s) { gp->pair_k = q; break; }
+    if (q != gb->k && q != gb->row_k && y_host[q] == gb->s) { gp->pair_k = q; break; }
   *al = *al && aligned16(gb->s);
   return MRG_OK;
 }
@@ -916,7 +988,7 @@ static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, 
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
     grid = mix_grid(rows, L);                                                                             \
-    if (gp.k >= 0) hipLaunchKernelGGL((mix_colstats_k<V, L, KM, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws, gp); \
+    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_colstats_k<V, L, KM, true>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws, gp); \
     else hipLaunchKernelGGL((mix_colstats_k<V, L, KM, false>), dim3(grid), dim3(MRG_BLOCK), 0, st, ys, K, rows, D, (double*)ws, gp); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
@@ -964,7 +1036,7 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    if (gp.k >= 0) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
     else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
@@ -994,7 +1066,7 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
     grid = mix_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
-    if (gp.k >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
   } while (0)
@@ -1066,17 +1138,20 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
     }
   }
   GatedPack gp;
-  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  const int grc = gated_pack(gated, y_host, K, &gp, &al, true);
   if (grc != MRG_OK) return grc;
   // the recomputed candidate's folded gradient store reads s and the gate it already holds: they must be the same tensors
   if (gp.k >= 0 && rsp.on[gp.k] == 2 && (rsp.s[gp.k] != gp.s || rsp.gate[gp.k] != y_host[gp.k])) return MRG_E_SHAPE;
+  // the row-scaled candidate has no gradient tensor: its gradient w.r.t. s goes into the gated candidate's direct term
+  if (gp.rk >= 0 && (gp.k < 0 || rsp.on[gp.k] != 2 || gy_host[gp.rk] != nullptr)) return MRG_E_SHAPE;
   RowGeom gm = row_geom(D, al);
   if (!gm.ok) return MRG_E_SHAPE;
+  if (gp.rk >= 0 && gm.kmax != 1) return MRG_E_SHAPE;               // the row dot is one group_sum over the row's lanes
   size_t lds = (size_t)K * 6 * D * sizeof(float);
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    if (gp.k >= 0) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
     else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
   } while (0)
   MRG_DISPATCH_GEOM(gm, CALL);

@@ -191,6 +191,79 @@ def gate_last(s, W, b, a):
     return _Gate.apply(s, None, None, 0, 0, 1.0, None, None, None, None, None, None, W, b, a)
 
 
+ROW_FACTOR = os.environ.get("MRG_ROW_FACTOR", "1") == "1"     # lab switch: 0 = f_sparse_comp's output is stored for the epilogue
+
+
+class _GateRow(torch.autograd.Function):
+    """f_sparse_comp as a ROW FACTOR: returns fvec [M] with  f_sparse_comp(s, s_in) == s * fvec[:, None]  bit for bit (the gate is
+    one scalar per row: reference models/operations_lp.py:317-343).  Its consumer -- the MixedOp epilogue -- recomputes the
+    candidate from s in every pass instead of reading a stored [M, D] tensor, and in backward returns the true gradient
+    w.r.t. fvec (the row dots sum_c gy * s).  This node turns it into the parameter and s_in gradients; the part of the gradient
+    w.r.t. s that goes through the gate (dz_r * u) is added by the epilogue's gradient store when it says so
+    (`s_grad_folded_ptr`), and formed here otherwise.  Arguments as _Gate."""
+
+    @staticmethod
+    def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
+        tied = s_in is not None and same_rows(s, s_in)
+        s, s_in, norm = f32c(s), (None if tied else f32c(s_in)), f32c(norm)
+        params = tuple(f32c(p) for p in params)
+        require_hip(s, s_in, norm, *params)
+        M, D = s.shape
+        st = stream_of(s)
+        in_dim = 2 * D if (s_in is not None or tied) else D
+        Ws, bs, as_ = params[0::3], params[1::3], params[2::3]
+        uvc = torch.empty(3, gate_ld(D), dtype=torch.float32, device=s.device)
+        call("mrg_gate_collapse3", (ptr_array(Ws), ptr_array(bs), ptr_array(as_), ptr(uvc), D, in_dim, int(tied), st),
+             nbytes=4 * D * in_dim * sum(W is not None for W in Ws))
+        fvec = torch.empty(M, dtype=torch.float32, device=s.device)
+        hvec = torch.empty(M, dtype=torch.float32, device=s.device)
+        nb = 4 * D * M * (2 if s_in is not None else 1) + (4 * b1 if norm is not None else 0) + 8 * M
+        call("mrg_gate_row_fwd", (ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(fvec), ptr(hvec), b0, b1, M, D, scale, st), nbytes=nb)
+        ctx.save_for_backward(s, s_in, norm, uvc, hvec, *params)
+        ctx.cfg = (b0, b1, scale, in_dim, tied)
+        return fvec
+
+    @staticmethod
+    def backward(ctx, gq):
+        s, s_in, norm, uvc, hvec, *params = ctx.saved_tensors
+        b0, b1, scale, in_dim, tied = ctx.cfg
+        gq = f32c(gq)
+        M, D = s.shape
+        st = stream_of(s)
+        gs_in = torch.empty_like(s) if s_in is not None else None
+        d_uvc = torch.empty(3, gate_ld(D), dtype=torch.float32, device=s.device)
+        ws = _ws(_ws_bytes("mrg_gate_bwd_workspace_bytes", M, D), s)
+        nb = 4 * D * M * (3 if s_in is not None else 1) + 8 * M
+        call("mrg_gate_row_bwd", (ptr(gq), ptr(hvec), ptr(s), ptr(s_in), ptr(uvc), ptr(gs_in), ptr(d_uvc), ptr(ws), b0, b1, M, D, st), nbytes=nb)
+        Ws, bs, as_ = params[0::3], params[1::3], params[2::3]
+        gWs = [None if W is None else torch.empty_like(W) for W in Ws]
+        gbs = [None if b is None else torch.empty_like(b) for b in bs]
+        gas = [None if a is None else torch.empty_like(a) for a in as_]
+        call("mrg_gate_param_grad3", (ptr_array(Ws), ptr_array(bs), ptr_array(as_), ptr(d_uvc), ptr_array(gWs), ptr_array(gbs), ptr_array(gas),
+                                      D, in_dim, int(tied), st), nbytes=8 * D * in_dim * sum(W is not None for W in Ws))
+        gparams = []
+        for gW, gb, ga in zip(gWs, gbs, gas):
+            gparams += [gW, gb, ga]
+        gs = None
+        if getattr(ctx, "s_grad_folded_ptr", None) != gq.data_ptr():
+            # nobody added dz_r * u_seg to the gradient w.r.t. s (the factor was multiplied out by plain tensor arithmetic)
+            dz = gq * hvec
+            gs = torch.empty_like(s)
+            for seg, (lo, hi) in enumerate(((0, b0), (b0, b1), (b1, M))):
+                if hi > lo:
+                    torch.mul(dz[lo:hi, None], uvc[seg, :D][None, :], out=gs[lo:hi])
+        return (gs, gs_in, None, None, None, None, *gparams)
+
+
+def gate_comp_row_factor(s, s_in, norm, b0, b1, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self):
+    """f_sparse_comp as a row factor for mixed_epilogue: a [M] tensor tagged `_mrg_rowfactor`; the candidate is s * fvec[:, None]
+    (mixed_epilogue multiplies it out itself when it cannot recompute it in its kernels)."""
+    s = f32c(s)
+    fvec = _GateRow.apply(s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self)
+    fvec._mrg_rowfactor = (s, int(b0), int(b1))
+    return fvec
+
+
 # ---------------------------------------------------------------------------
 # a4 / a5 / a6: destination-segmented reducers
 # ---------------------------------------------------------------------------
@@ -890,6 +963,14 @@ class _MixCfg:
         self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self, gated node | None, node): folded into its gradient
 
 
+def _row_candidate_as_s(cfg, ys):
+    """ys with the row-factor candidate's [rows] factor replaced by the tensor the kernels read in its slot: s."""
+    if cfg.gated is not None and cfg.gated.get("row_k") is not None:
+        ys = list(ys)
+        ys[cfg.gated["row_k"]] = cfg.gated["s"]
+    return ys
+
+
 class _MixedEpilogue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, w, *tensors):
@@ -901,7 +982,8 @@ class _MixedEpilogue(torch.autograd.Function):
         addend = f32c(tensors[nz + 2 * K_]) if cfg.has_addend else None
         it = iter(ys_nz)
         ys = [next(it) if p else None for p in cfg.present]
-        ref = ys_nz[0] if ys_nz else None
+        ys = _row_candidate_as_s(cfg, ys)                  # the row-factor candidate's slot holds s; its [rows] factor travels in the descriptor
+        ref = next((y for y in ys if y is not None), None)
         if ref is None:
             raise _lib.MrgnasError("mixed epilogue needs at least one non-zero branch to know the row count")
         require_hip(w, addend, *ys_nz, *gam, *bet)
@@ -912,8 +994,8 @@ class _MixedEpilogue(torch.autograd.Function):
         coef = torch.empty(K_, 4, D, dtype=torch.float32, device=dev)
         ypa = ptr_array(ys)
         gb = _lib.gated_branch(cfg.gated)
-        # the recomputed candidate reads its gate where the stored one read its output, and s -- which f_identity of the same MixedOp reads anyway
-        nz_rd = nz + (1 if (cfg.gated is not None and (cfg.identity is None or not cfg.present[cfg.identity])) else 0)
+        # [rows, D] tensors a pass reads: the stored candidates, the gate of the recomputed one, and s once for every candidate that is a function of it
+        nz_rd = len({y.data_ptr() for y in ys if y is not None} | ({cfg.gated["s"].data_ptr()} if cfg.gated is not None else set()))
         bn0 = cfg.bns[0]
         training = bn0.training or not bn0.track_running_stats
         if training:
@@ -954,6 +1036,7 @@ class _MixedEpilogue(torch.autograd.Function):
         g = f32c(g)
         it = iter(ys_nz)
         ys = [next(it) if p else None for p in cfg.present]
+        ys = _row_candidate_as_s(cfg, ys)
         rows, D = g.shape
         dev, st = g.device, stream_of(g)
         ypa = ptr_array(ys)
@@ -990,7 +1073,17 @@ class _MixedEpilogue(torch.autograd.Function):
         gys_nz = [torch.empty_like(y) if nd else None for y, nd in zip(ys_nz, need_y)]
         it = iter(gys_nz)
         gys = [next(it) if p else None for p in cfg.present]
-        n_out = sum(t is not None for t in gys_nz)
+        row_k = cfg.gated.get("row_k") if cfg.gated is not None else None
+        row_dq = None
+        if row_k is not None:                              # the row-factor candidate: a [rows] gradient w.r.t. its factor, no [rows, D] one
+            row_dq = gys[row_k] if gys[row_k] is not None else torch.empty(rows, dtype=torch.float32, device=dev)
+            gys[row_k] = None
+            node = cfg.gated["row_node"]
+            if node is not None:
+                node.s_grad_folded_ptr = row_dq.data_ptr()
+                gb = _lib.gated_branch(dict(cfg.gated, row_h=node.saved_tensors[4], row_uvc=node.saved_tensors[3],
+                                            row_ld=node.saved_tensors[3].shape[1]), row_dq)
+        n_out = sum(t is not None and t.dim() == 2 for t in gys_nz)
         if rs is not None and any(r is not None for r in rs):
             import ctypes
             on = (ctypes.c_int * K_)(*[int(r is not None) for r in rs])
@@ -1018,7 +1111,7 @@ class _MixedEpilogue(torch.autograd.Function):
             n_fold = 0
         call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
                                    f_s, f_gate, f_gs_p, f_add, rows, D, gb, st),
-             nbytes=4 * D * rows * (1 + nz + n_out + 3 * n_fold - (2 if (cfg.gated is not None and n_fold) else 0) + (ctx.nz_rd - nz if not n_fold else 0)))
+             nbytes=4 * D * rows * (1 + ctx.nz_rd + n_out + n_fold))
         if rs is not None:
             for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
                 if rs[k] is not None and gys[k] is not None:
@@ -1053,7 +1146,26 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
         if spec is not None:
             if gated is not None:
                 raise _lib.MrgnasError("mixed epilogue: one recomputed (gate-only) candidate at most")
-            gated = (k,) + tuple(spec)
+            gated = dict(k=k, s=spec[0], c=spec[1])
+    # the row-factor candidate (f_sparse_comp as fvec [rows]): recomputed as s * fvec[r] by the kernels when the gated candidate of
+    # the same rows s is there to receive its gradient w.r.t. s; multiplied out by plain tensor arithmetic otherwise
+    ys = list(ys)
+    for k, y in enumerate(ys):
+        spec = getattr(y, "_mrg_rowfactor", None) if y is not None else None
+        if spec is None:
+            continue
+        s_r, rb0, rb1 = spec
+        D_ = s_r.shape[1]
+        wants_grad = torch.is_grad_enabled() and (y.requires_grad or s_r.requires_grad)
+        ok = (gated is not None and "row_k" not in gated and gated["s"].data_ptr() == s_r.data_ptr() and gated["s"].shape == s_r.shape
+              and ((D_ % 4 == 0 and D_ <= 256) or D_ <= 64))
+        if ok and wants_grad:                              # the gated candidate's folded gradient store is where the gradient w.r.t. s goes
+            rs_g = rowscale[gated["k"]]
+            ok = rs_g is not None and rs_g[4] is not None and y.grad_fn is not None
+        if ok:
+            gated.update(row_k=k, row_f=y, b0=rb0, b1=rb1, row_node=y.grad_fn)
+        else:
+            ys[k] = s_r * y.unsqueeze(1)
     cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale, identity, gated)
     tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
     return _MixedEpilogue.apply(cfg, w, *tensors)

@@ -78,12 +78,16 @@ class f_sparse_op_comp(nn.Module):
             setattr(self, "W_" + x, nn.Linear(2 * D, D, bias=True))
             setattr(self, "a_" + x, nn.Linear(D, 1, bias=False))
 
-    def forward(self, g, src_emb, src_emb_in):
+    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+        """for_epilogue: the result goes to functional.mixed_epilogue and nowhere else -- it may then be the gate as a ROW FACTOR
+        fvec [rows] (the candidate is src_emb * fvec[:, None], which the epilogue recomputes instead of reading it back)."""
         b0, b1 = _bounds(g)
         p = []
         for x in ("in", "out", "self"):
             W, a = getattr(self, "W_" + x), getattr(self, "a_" + x)
             p += [W.weight, W.bias, a.weight]
+        if for_epilogue and K.ROW_FACTOR and src_emb.is_cuda:
+            return K.gate_comp_row_factor(src_emb, src_emb_in, g.norm_flat(), b0, b1, *p)
         return K.gate_comp(src_emb, src_emb_in, g.norm_flat(), b0, b1, *p)
 
 

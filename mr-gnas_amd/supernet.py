@@ -100,6 +100,8 @@ class MixedOp(nn.Module):
         # f_dense_comp and f_comp read the same (h, h_in): one autograd node whose backward leaves ONE gradient per operand
         pair = self._dense_pair(fh.x)
         paired = {}
+        # f_sparse_comp as a row factor: only next to the gate-only f_dense_comp, whose folded gradient store receives its gradient
+        row_ok = pair is not None and K.GATED_RECOMPUTE and K.FOLD_ROW_SCALE
         # The candidates are independent: they run round-robin on a few HIP streams so that the tail of one
         # kernel (a GEMM workgroup owns a whole CU) is filled by another candidate's kernels.  Autograd replays
         # each candidate's backward on the stream its forward ran on.
@@ -115,6 +117,8 @@ class MixedOp(nn.Module):
                     if not paired:
                         paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take(), for_epilogue=True)
                     ys.append(paired[k])
+                elif row_ok and type(op) is OPS.f_sparse_op_comp:
+                    ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))
                 else:
                     ys.append(op(g, fh.take(), fi.take()))
             return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True,
@@ -138,6 +142,8 @@ class MixedOp(nn.Module):
                     paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b, for_epilogue=True)
                     y = paired[k]
                     paired[pair[0] + pair[1] - k].record_stream(fork.main)
+                elif row_ok and type(op) is OPS.f_sparse_op_comp:
+                    y = op(g, a, b, for_epilogue=True)
                 else:
                     y = op(g, a, b)
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream

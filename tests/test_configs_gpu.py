@@ -253,7 +253,7 @@ def test_c1_fb15k237_fixed_genotype_d64_matches_float64_oracle():
     loss = F.binary_cross_entropy(pred, label)
     loss.backward()
     torch.cuda.synchronize()
-    assert pred.shape == (B, N) and np.isfinite(float(loss))
+    assert pred.shape == (B, N) and np.isfinite(float(loss.detach()))
     # float64 oracle on the device
     src, dst, _ = g.edges(form="all")
     og = OGraph(N, src.cpu(), dst.cpu(), g.edata["e_type"].cpu(), g.edata["norm"].cpu()).to(DEV, torch.float64)
@@ -262,7 +262,7 @@ def test_c1_fb15k237_fixed_genotype_d64_matches_float64_oracle():
     loss64 = F.binary_cross_entropy(pred64, label.double())
     loss64.backward()
     assert float((pred.double() - pred64).abs().max()) <= 1e-4          # probabilities in [0, 1]
-    assert abs(float(loss) - float(loss64)) <= 1e-4 * max(1.0, float(loss64))
+    assert abs(float(loss.detach()) - float(loss64)) <= 1e-4 * max(1.0, float(loss64))
     for k, p in net.named_parameters():
         ref = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
         err, scale = grad_err(p.grad if p.grad is not None else torch.zeros_like(p), ref)

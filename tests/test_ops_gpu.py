@@ -733,12 +733,48 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [64, 200, 512])
+def test_row_factor_candidate_without_a_gated_partner_is_multiplied_out(D):
+    """f_sparse_comp as a row factor handed to an epilogue that cannot recompute it (no gate-only f_dense_comp of the same rows; D
+    beyond one lane group per row): mixed_epilogue multiplies s * fvec out itself -- same output bit for bit as the stored
+    operator, every gradient within float32 rounding (the node then forms dz (x) u for the gradient w.r.t. s itself)."""
+    N, E, R = 120, 2500, 4
+    gen = torch.Generator().manual_seed(D)
+    g = G.RelGraph(N, torch.randint(0, N, (E,), generator=gen).numpy(), torch.randint(0, N, (E,), generator=gen).numpy(),
+                   torch.randint(0, 2 * R, (E,), generator=gen).numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    op = O.MIXED_OPS["f_sparse_comp"]({"feature_dim": D}).to(DEV)
+    for p in op.parameters():
+        p.data.add_(0.05 * torch.randn(p.shape, generator=gen).to(DEV))
+    bn = torch.nn.BatchNorm1d(D).to(DEV)
+    x0, xin0 = torch.randn(E + N, D, generator=gen), torch.randn(E + N, D, generator=gen)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    res = {}
+    for row in (True, False):
+        op.zero_grad(set_to_none=True)
+        bn.zero_grad(set_to_none=True)
+        bn.reset_running_stats()
+        x, xin = x0.clone().to(DEV).requires_grad_(True), xin0.clone().to(DEV).requires_grad_(True)
+        w = torch.ones(1, device=DEV, requires_grad=True)
+        y = op(g, x, xin, for_epilogue=row)
+        assert (y.dim() == 1) == row
+        out = K.mixed_epilogue([y], [bn], w, fold_row_scales=True)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res[row] = [out.detach(), x.grad, xin.grad, w.grad, bn.weight.grad, bn.bias.grad] + [p.grad.clone() for p in op.parameters()]
+    assert torch.equal(res[True][0], res[False][0])
+    for i, (a, b) in enumerate(zip(res[True][1:], res[False][1:])):
+        close(a, b.cpu(), f"multiplied-out row factor: gradient {i}", rtol=2e-5, atol=2e-5 * max(1e-3, float(b.abs().max())))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tied", [True, False])
 @pytest.mark.parametrize("N,E,R,D", [(2000, 150000, 9, 200), (300, 5000, 4, 64), (50, 700, 3, 100)])
 def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
     """f_dense_comp's output never stored (the row GEMM writes only the gate, the MixedOp epilogue's four passes recompute
     gate * s * c: mrg_gated_branch) against the stored candidate: output, running statistics and EVERY gradient bit-identical --
-    with the epilogue's gradient folds on and off, in training and in eval mode."""
+    with the epilogue's gradient folds on and off, in training and in eval mode.  On top of it f_sparse_comp as a row factor
+    (y = s * fvec[r] recomputed, its gradient w.r.t. s added by the epilogue's gradient store: mrg_gated_branch.row_k): output and
+    running statistics bit-identical, gradients within float32 rounding of the stored form (the association of dz differs)."""
     from mr_gnas_amd import supernet as S
     gen = torch.Generator().manual_seed(7 * N + E + D + int(tied))
     src = torch.randint(0, N, (E,), generator=gen)
@@ -753,6 +789,9 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
     torch.manual_seed(5)
     mixed = S.MixedOp(D, 0.0, O.FIRST_OPS).to(DEV)
     S.xavier_init_(mixed)
+    for p in mixed.parameters():                          # biases and gate vectors away from their all-zero / symmetric start
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn(p.shape, generator=gen).to(DEV))
     state0 = {k: v.clone() for k, v in mixed.state_dict().items()}
     calls = []
     real_call = K.call
@@ -765,8 +804,9 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
         for folds in (True, False):
             for training in (True, False):
                 res = {}
-                for gated in (True, False):
-                    K.GATED_RECOMPUTE, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = gated, folds, folds
+                for mode in ("stored", "gate", "gate+row"):
+                    K.GATED_RECOMPUTE, K.ROW_FACTOR = mode != "stored", mode == "gate+row"
+                    K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = folds, folds
                     mixed.load_state_dict(state0)
                     mixed.train(training)
                     mixed.zero_grad(set_to_none=True)
@@ -776,15 +816,26 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
                     del calls[:]
                     K.call = spy
                     out = mixed(w, g, h, hin, addend=add0)
-                    K.call = real_call
-                    fwd3 = [a for n, a in calls if n == "mrg_dense_filter_fwd3" and a[0] == 0]
-                    assert len(fwd3) == 1 and (fwd3[0][8] is None) == gated, "the gated row GEMM stores its output exactly when the candidate is stored"
                     out.backward(gout)
+                    K.call = real_call
                     torch.cuda.synchronize()
-                    res[gated] = ([out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
-                                  + [b.clone() for b in mixed.buffers()])
-                for i, (a, b) in enumerate(zip(res[True], res[False])):
+                    fwd3 = [a for n, a in calls if n == "mrg_dense_filter_fwd3" and a[0] == 0]
+                    assert len(fwd3) == 1 and (fwd3[0][8] is None) == (mode != "stored"), "the gated row GEMM stores its output exactly when the candidate is stored"
+                    names = [n for n, _ in calls]
+                    rowed = mode == "gate+row" and folds          # the row factor needs the gated candidate's folded gradient store
+                    assert ("mrg_gate_row_fwd" in names) == rowed and ("mrg_gate_row_bwd" in names) == rowed
+                    assert ("mrg_gate_fwd" in names) == (not rowed)
+                    res[mode] = ([out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
+                                 + [b.clone() for b in mixed.buffers()])
+                for i, (a, b) in enumerate(zip(res["gate"], res["stored"])):
                     assert torch.equal(a, b), f"gate-only vs stored f_dense_comp: tensor {i} differs (folds {folds}, training {training})"
+                nb = len(list(mixed.buffers()))
+                assert torch.equal(res["gate+row"][0], res["stored"][0])
+                for a, b in zip(res["gate+row"][-nb:], res["stored"][-nb:]):
+                    assert torch.equal(a, b), "running statistics"
+                for i, (a, b) in enumerate(zip(res["gate+row"][1:-nb], res["stored"][1:-nb])):
+                    close(a, b.cpu(), f"row-factor f_sparse_comp: gradient {i} (folds {folds}, training {training})", rtol=2e-5,
+                          atol=2e-5 * max(1e-3, float(b.abs().max())))
     finally:
         K.call = real_call
-        K.GATED_RECOMPUTE, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = True, True, True
+        K.GATED_RECOMPUTE, K.ROW_FACTOR, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = True, True, True, True

@@ -27,7 +27,7 @@ lib = _lib.load()
 ws = torch.empty(int(lib.mrg_mix_workspace_bytes(K_, D)), dtype=torch.uint8, device=dev)
 st = stream_of(s)
 cvec = torch.cat([norm * (1.0 / 3.0), torch.full((rows - edge,), 1.0 / 3.0, device=dev)])
-spec = (2, s, cvec)
+spec = dict(k=2, s=s, c=cvec)
 res = {}
 for tag, ys, gspec in (("stored", [None, s, yd, y3, y4], None), ("gated", [None, s, gate, y3, y4], spec), ("gated-nopair", [None, y3.clone(), gate, y3, y4], spec)):
     ypa = ptr_array(ys)

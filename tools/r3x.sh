@@ -1,14 +1,20 @@
 #!/bin/bash
-# gate-only candidate: targeted tests, then the bench with the switch on / off
+# recomputed candidates (gate-only f_dense_comp, row-factor f_sparse_comp): targeted tests, then the bench with the row factor on / off
 set -o pipefail
 mkdir -p gpurun_out/r3x
-timeout -k 10 900 python3 -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "gate_only or dense_pair or mixed or epilogue" > gpurun_out/r3x/tests.txt 2>&1 || { tail -30 gpurun_out/r3x/tests.txt; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "gate_only or row_factor or dense_pair or mixed or epilogue" > gpurun_out/r3x/tests.txt 2>&1 || { tail -40 gpurun_out/r3x/tests.txt; exit 1; }
 tail -3 gpurun_out/r3x/tests.txt
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32-leg > gpurun_out/r3x/bench_on.json 2> gpurun_out/r3x/bench_on.err || { tail -20 gpurun_out/r3x/bench_on.err; exit 1; }
-MRG_GATED_RECOMPUTE=0 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32-leg > gpurun_out/r3x/bench_off.json 2> gpurun_out/r3x/bench_off.err || { tail -20 gpurun_out/r3x/bench_off.err; exit 1; }
+MRG_ROW_FACTOR=0 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32-leg > gpurun_out/r3x/bench_off.json 2> gpurun_out/r3x/bench_off.err || { tail -20 gpurun_out/r3x/bench_off.err; exit 1; }
 python3 - <<'PY'
 import json
+r = {}
 for t in ("on", "off"):
-    d = json.loads(open(f"gpurun_out/r3x/bench_{t}.json").read().strip().splitlines()[-1])
-    print(t, "ms/step", d["ms_per_step"], "value", d["value"], "loss", d.get("loss"), "mem", d.get("peak_mem_gb"))
+    d = r[t] = json.loads(open(f"gpurun_out/r3x/bench_{t}.json").read().strip().splitlines()[-1])
+    print(t, "ms/step", d["ms_per_step"], "value", d["value"], "loss", d.get("loss"))
+ko, kf = r["on"]["kernels"], r["off"]["kernels"]
+for n in sorted(set(ko) | set(kf)):
+    ta, tb = ko.get(n, {}).get("ms_total", 0.0), kf.get(n, {}).get("ms_total", 0.0)
+    if abs(ta - tb) > 0.02:
+        print(f"{n:36s} on {ta:7.3f} off {tb:7.3f}  d {ta - tb:+.3f}")
 PY
