@@ -256,7 +256,9 @@ __global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb,
 }
 
 // ---- forward combine
-template <int VEC, int LPR, int KMAX, bool GATED>
+// KB: the candidate slots the kernel is unrolled for (K <= KB): 5 covers every MixedOp of the search space (3, 4 or 5 candidates)
+// with 3/8 fewer registers than the general 8 -- one more wave per SIMD.
+template <int VEC, int LPR, int KMAX, bool GATED, int KB>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
                                                        float* __restrict__ out, int64_t rows, int D,
                                                        const float* __restrict__ addend, GatedPack gp) {
@@ -269,9 +271,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
     lds[t] = coef[(int64_t)k * 4 * D + rem];
   }
   __syncthreads();
-  float wk[MRG_MIX_MAXK];
+  float wk[KB];
 #pragma unroll
-  for (int k = 0; k < MRG_MIX_MAXK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (int k = 0; k < KB; ++k) wk[k] = k < K ? w[k] : 0.f;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
@@ -293,14 +295,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
         }
         // phase 1: every branch's load is issued before any is used (a load consumed inside its own `if (k < K)`
         // block leaves one 16-byte load in flight per lane)
-        Vec<VEC> vin[MRG_MIX_MAXK];
+        Vec<VEC> vin[KB];
 #pragma unroll
-        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+        for (int k = 0; k < KB; ++k) {
           vin[k] = Vec<VEC>::fill(0.f);
           if (k < K && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
         }
 #pragma unroll
-        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+        for (int k = 0; k < KB; ++k) {
           if (k < K) {
             Vec<VEC> v = vin[k];
             if constexpr (GATED) {                         // the recomputed candidates: gate -> gate * s * c_r, s -> s * 1 * f_r; the others * 1 * 1
@@ -448,7 +450,7 @@ __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double 
 // row, same order as gate_bwd_k) -> gp.rdq[r], the gradient w.r.t. f_r, from which mrg_gate_row_bwd derives the candidate's
 // parameter / s_in gradients; and with dz_r = q_r * h_r (h_r = t_r * gate * (1 - gate), saved by the forward) it ADDS the candidate's
 // whole gradient w.r.t. s, gy * f_r + dz_r * u[c], into the gated candidate's direct term gs_out (gradients w.r.t. the same rows s).
-template <int VEC, int LPR, int KMAX, bool GATED>
+template <int VEC, int LPR, int KMAX, bool GATED, int KB>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
                                                              const float* __restrict__ w, int64_t rows, int D, RowScalePack rsp,
@@ -462,18 +464,18 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
     lds[t] = rem < 4 * D ? coef[(int64_t)k * 4 * D + rem] : coef2[(int64_t)k * 2 * D + rem - 4 * D];
   }
   __syncthreads();
-  float wk[MRG_MIX_MAXK];
-  bool need[MRG_MIX_MAXK];                                 // gy_k is wanted: stored, or added into a gated candidate's gs_out
+  float wk[KB];
+  bool need[KB];                                 // gy_k is wanted: stored, or added into a gated candidate's gs_out
 #pragma unroll
-  for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+  for (int k = 0; k < KB; ++k) {
     wk[k] = k < K ? w[k] : 0.f;
     need[k] = k < K && (gys.p[k] != nullptr || (GATED && k == gp.rk));
   }
 #pragma unroll
-  for (int k = 0; k < MRG_MIX_MAXK; ++k)
+  for (int k = 0; k < KB; ++k)
     if (k < K && rsp.on[k] == 2 && rsp.add_from[k] >= 0) {
 #pragma unroll
-      for (int q = 0; q < MRG_MIX_MAXK; ++q) if (q == rsp.add_from[k]) need[q] = true;
+      for (int q = 0; q < KB; ++q) if (q == rsp.add_from[k]) need[q] = true;
     }
   const bool hasr = GATED && gp.rk >= 0;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       const bool act = c < dv;
       float gck = 1.f, rfv = 1.f, rhv = 0.f;               // the recomputed candidates' row multipliers and s (see mix_fwd_k)
       Vec<VEC> gsv = Vec<VEC>::fill(0.f), gga = Vec<VEC>::fill(0.f), guv = Vec<VEC>::fill(0.f);
-      Vec<VEC> ov[MRG_MIX_MAXK];                           // every wanted gy_k first: a gated candidate may add another one's
+      Vec<VEC> ov[KB];                           // every wanted gy_k first: a gated candidate may add another one's
       Vec<VEC> orv = Vec<VEC>::fill(0.f);                  // gy of the row-scaled candidate
       float dq = 0.f;
       if (act) {
@@ -496,15 +498,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
           guv = Vec<VEC>::load(gp.uvc + (int64_t)seg * gp.uld + c * VEC);
         }
         Vec<VEC> gv = Vec<VEC>::load(g + r * D + c * VEC);
-        Vec<VEC> vin[MRG_MIX_MAXK];                        // all loads first (see mix_fwd_k)
+        Vec<VEC> vin[KB];                        // all loads first (see mix_fwd_k)
 #pragma unroll
-        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+        for (int k = 0; k < KB; ++k) {
           vin[k] = Vec<VEC>::fill(0.f);
           if (k < K && need[k] && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
         }
         if constexpr (GATED) {
 #pragma unroll
-          for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+          for (int k = 0; k < KB; ++k) {
             if (k == gp.k) {
               gga = vin[k];
 #pragma unroll
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
           }
         }
 #pragma unroll
-        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+        for (int k = 0; k < KB; ++k) {
           ov[k] = Vec<VEC>::fill(0.f);
           if (k < K && need[k]) {
             const Vec<VEC> v = vin[k];
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
         }
         if (hasr) {
 #pragma unroll
-          for (int k = 0; k < MRG_MIX_MAXK; ++k) if (k == gp.rk) orv = ov[k];
+          for (int k = 0; k < KB; ++k) if (k == gp.rk) orv = ov[k];
 #pragma unroll
           for (int j = 0; j < VEC; ++j) dq += orv[j] * gsv[j];
         }
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       }
       if (act) {
 #pragma unroll
-        for (int k = 0; k < MRG_MIX_MAXK; ++k) {
+        for (int k = 0; k < KB; ++k) {
           if (k < K && gys.p[k] != nullptr) {
             Vec<VEC> o = ov[k];
             if (rsp.on[k]) {                               // the consumer's first backward pass (mrg_dense_filter_dz) folded into this store
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
                 const int af = rsp.add_from[k];
                 if (af >= 0) {                             // + the gradient of the candidate whose output IS this one's operand s
 #pragma unroll
-                  for (int qq = 0; qq < MRG_MIX_MAXK; ++qq)
+                  for (int qq = 0; qq < KB; ++qq)
                     if (qq == af) {
 #pragma unroll
                       for (int j = 0; j < VEC; ++j) o2[j] += ov[qq][j];
@@ -1036,8 +1038,14 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
-    else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false>), dim3(stream_grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    const dim3 grid_(stream_grid_for(rows, (MRG_BLOCK / L) * 4));                                          \
+    if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
+      if (K <= 5) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+      else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    } else {                                                                                              \
+      if (K <= 5) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false, 5>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+      else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    }                                                                                                     \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
@@ -1066,7 +1074,8 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
     grid = mix_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
-    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    if ((gp.k >= 0 || gp.rk >= 0) && K <= 5) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 5, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    else if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
   } while (0)
@@ -1151,8 +1160,14 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
-    else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    const dim3 grid_(grid_for(rows, (MRG_BLOCK / L) * 4));                                                 \
+    if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
+      if (K <= 5) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+      else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    } else {                                                                                              \
+      if (K <= 5) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false, 5>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+      else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    }                                                                                                     \
   } while (0)
   MRG_DISPATCH_GEOM(gm, CALL);
 #undef CALL
