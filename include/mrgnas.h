@@ -366,6 +366,10 @@ int mrg_gemm_set_mode(int mode);
  * measured slower for the plain epilogue and in the whole step, kept as a tested comparison point.
  * Process-wide. */
 int mrg_gemm_set_epilogue(int row_order);
+/* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
+ * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
+ * (wgrad_x3_k, rounds 1-2).  Same products in the same order: bit-identical gradients. */
+int mrg_wgrad_set_variant(int variant);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);
 /* a_max_op.forward as ONE GEMM (reference models/operations_lp.py:230-235; SURVEY section 2b K_lin_relu_segmax):

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mrg_gemm_workspace_bytes": (_L, [_I, _I]),
     "mrg_gemm_set_mode": (_I, [_I]),
     "mrg_gemm_set_epilogue": (_I, [_I]),
+    "mrg_wgrad_set_variant": (_I, [_I]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mrg_dense_filter3_workspace_bytes": (_L, [_I, _I]),
     "mrg_dense_filter_fwd3": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _L, _L, _I, _P]),
@@ -138,6 +139,8 @@ def load():
     if os.environ.get("MRG_STREAM_BLOCKS"):          # lab: grid bound of the streaming kernels (mrg_set_stream_blocks)
         if lib.mrg_set_stream_blocks(int(os.environ["MRG_STREAM_BLOCKS"])) != 0:
             raise MrgnasLibraryError("MRG_STREAM_BLOCKS must be 64..4096")
+    if os.environ.get("MRG_WGRAD_VARIANT"):          # lab: 0 = every wave splits the fragments it multiplies (mrg_wgrad_set_variant)
+        lib.mrg_wgrad_set_variant(int(os.environ["MRG_WGRAD_VARIANT"]))
     if os.environ.get("MRG_GEMM_EPILOGUE"):          # lab: 0 = accumulator-order stores of the row GEMM (mrg_gemm_set_epilogue)
         lib.mrg_gemm_set_epilogue(int(os.environ["MRG_GEMM_EPILOGUE"]))
     _lib = lib

@@ -468,6 +468,211 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
       }
 }
 
+// ---- the same weight gradient with every fragment split ONCE per workgroup ------------------------------------------------
+// wgrad_x3_k stages raw f32 tiles in LDS and every wave splits the fragments it multiplies: a gY fragment is split by the four
+// waves that share its row tiles, an X fragment by two -- 264 VALU instructions per wave and 16-row tile beside 48 MFMAs, and
+// eight ds_read_b32 per fragment.  Here fragment f of a tile is produced by ONE wave (f % 8): eight coalesced global_load_dword
+// straight into the MFMA operand layout (lane = column f*32 + lane%32, rows 8*(lane/32) .. +7 -- 128 contiguous bytes per row
+// and half wave), one split, three ds_write_b128 (bf16 planes, lane-contiguous: conflict free); the consumers read three
+// ds_read_b128 per fragment.  Per workgroup and tile: 15 splits instead of 48 (TM = 7, KT = 8).  Two LDS buffers, one barrier per
+// tile; the loads of tile t + 2 are issued before the barrier of tile t and consumed (split) during the MFMAs of tile t + 1.
+// Same products, same accumulation order per output element as wgrad_x3_k: bit-identical partial tiles.
+template <int NG>
+__global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
+  constexpr int KP = 8 / NG, KT = 2 * KP;
+  constexpr int ASLOTS = NG == 2 ? 8 : 4;                 // row-tile slots (TM <= 7 / <= 4)
+  constexpr int NFRAG = ASLOTS + KT;
+  constexpr int FPW = (NFRAG + 7) / 8;                    // fragments a wave produces per tile
+  extern __shared__ __align__(16) float smem[];
+    const int tn0 = (int)(((int64_t)blockIdx.y * a.TN) / gridDim.y);
+  const int tnb = (int)(((int64_t)(blockIdx.y + 1) * a.TN) / gridDim.y) - tn0;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wg = wave / KP, wp = wave % KP;
+  const int m0 = wg * 4;
+  const int an = a.TM - m0 < 4 ? (a.TM - m0 > 0 ? a.TM - m0 : 0) : 4;      // row tiles of this wave
+  const int kn = tnb - 2 * wp < 2 ? (tnb - 2 * wp > 0 ? tnb - 2 * wp : 0) : 2;   // column tiles of this wave
+  const int K = a.K1 + a.K2;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r_end = r_begin + a.rows_per_block;
+  if (r_end > a.rows) r_end = a.rows;
+  int64_t ws_off = 0;
+  if (a.ngrp > 0) {
+    const int z = blockIdx.z;
+#define MRG_PICKZ(F) (z == 0 ? a.F[0] : (z == 1 ? a.F[1] : a.F[2]))
+    if ((int)blockIdx.x >= MRG_PICKZ(g_G)) return;          // workgroup-uniform, before any barrier
+    const int64_t rpb = MRG_PICKZ(g_rpb), hi = MRG_PICKZ(g_hi);
+    r_begin = MRG_PICKZ(g_lo) + (int64_t)blockIdx.x * rpb;
+    r_end = r_begin + rpb < hi ? r_begin + rpb : hi;
+    ws_off = MRG_PICKZ(g_ws_off);
+#undef MRG_PICKZ
+  }
+
+  // the fragments this wave produces: per lane one column, eight rows; constants (the bias column of ones, padding, fragments
+  // that do not exist) come from a 4-float device array with row stride 0: the loads are the same straight-line code for every
+  // wave and tile (a conditional load would make the compiler wait for it before the loop's back edge)
+  const float* src[FPW]; int64_t ld[FPW]; bool live[FPW];
+#pragma unroll
+  for (int i = 0; i < FPW; ++i) {
+    const int f = wave + 8 * i;
+    live[i] = f < NFRAG && (f < ASLOTS ? f < a.TM : f - ASLOTS < tnb);
+    const float* base = mrg_zeros16; int64_t l = 0;
+    if (live[i]) {
+      if (f < ASLOTS) {
+        const int cg = f * 32 + li;
+        if (cg < a.Nout) { base = a.gY + (r_begin + 8 * lh) * a.ldg + cg; l = a.ldg; }
+      } else {
+        const int cg = (tn0 + f - ASLOTS) * 32 + li;
+        if (cg < K) {
+          const XSel sx = wgrad_sel_x(a, cg);
+          base = sx.base + (r_begin + 8 * lh) * sx.ld + sx.kk; l = sx.ld;
+        } else if (cg == K) {
+          base = mrg_ones16;
+        }
+      }
+    }
+    src[i] = base; ld[i] = l;
+  }
+  constexpr unsigned BUF_BYTES = FPW * 8 * 3 * 1024;
+
+  // Tiles of 16 rows; a ragged last tile is the 16 rows ENDING at r_end (the host guarantees r_end >= 16: in-bounds loads without
+  // a mask), the rows it shares with the tile before are zeroed when it is split.
+  const int64_t ntiles = (r_end - r_begin + WBR - 1) / WBR;
+  auto tile_start = [&](int64_t t) { return t + 1 < ntiles ? r_begin + t * WBR : (r_end - WBR < r_begin + (ntiles - 1) * WBR ? r_end - WBR : r_begin + (ntiles - 1) * WBR); };
+  float raw[FPW][8];
+  auto fetch = [&](int64_t t) {                            // t clamped by the caller: always a real tile
+    const int64_t toff = tile_start(t) - r_begin;
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      const float* p = src[i] + toff * ld[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[i][j] = p[j * ld[i]];
+    }
+  };
+  auto produce = [&](int buf, int64_t t) {
+    const int64_t ts = tile_start(t), vstart = r_begin + t * WBR;     // rows below vstart belong to the previous tile
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      if (live[i]) {                                        // wave-uniform
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = raw[i][j];
+        if (ts < vstart) {                                  // workgroup-uniform: the ragged last tile only
+          const int first = (int)(vstart - ts) - 8 * lh;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = j >= first ? x[j] : 0.f;
+        }
+        u32x4 H, M, L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h, m, l;
+          split_pair(x[2 * j], x[2 * j + 1], h, m, l);
+          H[j] = h; M[j] = m; L[j] = l;
+        }
+        const int f = wave + 8 * i;
+        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(smem) + buf * BUF_BYTES + f * 3072) + lane;
+        dst[0] = H; dst[64] = M; dst[128] = L;
+      }
+    }
+  };
+  auto rdfrag = [&](int buf, int f, bf16x8& H, bf16x8& M, bf16x8& L) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(smem) + buf * BUF_BYTES + f * 3072) + lane;
+    H = __builtin_bit_cast(bf16x8, p[0]); M = __builtin_bit_cast(bf16x8, p[64]); L = __builtin_bit_cast(bf16x8, p[128]);
+  };
+
+  if (ntiles > 0) {
+    fetch(0);
+    produce(0, 0);
+    fetch(ntiles > 1 ? 1 : 0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t = 0; t < ntiles; ++t) {
+      if (an > 0 && kn > 0) {
+        bf16x8 Bh0, Bm0, Bl0, Bh1, Bm1, Bl1;
+        rdfrag(cur, ASLOTS + 2 * wp, Bh0, Bm0, Bl0);
+        if (kn > 1) rdfrag(cur, ASLOTS + 2 * wp + 1, Bh1, Bm1, Bl1);
+        else { Bh1 = Bh0; Bm1 = Bm0; Bl1 = Bl0; }
+        bf16x8 An[3];                                      // the NEXT row tile's planes: read while this one's MFMAs run
+        rdfrag(cur, m0, An[0], An[1], An[2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < an) {
+            const bf16x8 Ah = An[0], Am = An[1], Al = An[2];
+            if (i + 1 < an) rdfrag(cur, m0 + i + 1, An[0], An[1], An[2]);
+            if (kn > 1) {                                  // two accumulators interleaved: no back-to-back dependent MFMAs
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[i][1], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[i][1], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[i][1], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[i][1], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[i][1], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[i][1], 0, 0, 0);
+            } else {
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // tile t + 1 (its loads were issued one tile ago) is split under this tile's MFMAs; then the loads of tile t + 2 (clamped:
+      // past the end the last tile is simply loaded again and never used)
+      if (t + 1 < ntiles) produce(cur ^ 1, t + 1);
+      fetch(t + 2 < ntiles ? t + 2 : ntiles - 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  const int ldw = a.TN * 32;
+  float* out = a.ws + ws_off + (int64_t)blockIdx.x * (a.TM * 32) * ldw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (i < an && j < kn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (m0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          out[(int64_t)row * ldw + (tn0 + 2 * wp + j) * 32 + li] = acc[i][j][r];
+        }
+      }
+}
+
+static int g_wgrad_variant = 1;           // 1: fragments split once per workgroup (wgrad_x3v_k), 0: per consuming wave (wgrad_x3_k)
+inline int wgrad_variant() { return g_wgrad_variant; }
+
+template <int NG>
+static void launch_wgrad_x3(dim3 grid, const WgradArgs& a, hipStream_t st) {
+  const int kt = 16 / NG;
+  bool v1 = wgrad_variant() == 1 && a.rows >= WBR;         // (its ragged last tile is the 16 rows ENDING at the range's end)
+  for (int i = 0; i < a.ngrp; ++i) v1 = v1 && !(a.g_hi[i] > a.g_lo[i] && a.g_hi[i] < WBR);
+  if (v1) {
+    const size_t lds = (size_t)2 * ((((NG == 2 ? 8 : 4) + kt) + 7) / 8 * 8) * 3 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3v_k<NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((wgrad_x3v_k<NG>), grid, dim3(WX_THREADS), lds, st, a);
+  } else {
+    const size_t ldsx = (size_t)(NG == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+    hipLaunchKernelGGL((wgrad_x3_k<NG>), grid, dim3(WX_THREADS), ldsx, st, a);
+  }
+}
+
 // gW[n][c] = sum_g ws[g][n][c] (c < K);  gbias[n] = sum_g ws[g][n][K]   -- fixed order:
 // thread row ty sums the partial tiles g = ty, ty+16, ..., the 16 row sums are added in order.
 // Up to three row ranges in one launch (blockIdx.z).
@@ -590,14 +795,8 @@ static int launch_wgrad_one(const float* gY, int ldg, const float* X1, const flo
   if (vec && gemm_mode() != 1 && p.TM <= 7) {        // split-bf16 core
     const int ng = p.TM <= 4 ? 1 : 2, kt = 16 / ng;
     dim3 gridx(p.G, (p.TN + kt - 1) / kt);
-    const size_t ldsx = (size_t)(ng == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
-    if (ng == 1) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      hipLaunchKernelGGL((wgrad_x3_k<1>), gridx, dim3(WX_THREADS), ldsx, st, a);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      hipLaunchKernelGGL((wgrad_x3_k<2>), gridx, dim3(WX_THREADS), ldsx, st, a);
-    }
+    if (ng == 1) launch_wgrad_x3<1>(gridx, a, st);
+    else launch_wgrad_x3<2>(gridx, a, st);
     MRG_LAUNCH_CHECK();
     WgradReduce3 red{};
     red.ws[0] = (const float*)ws; red.gW[0] = gW; red.gbias[0] = gbias; red.G[0] = p.G;
@@ -722,6 +921,12 @@ extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
 extern "C" int mrg_gemm_set_mode(int mode) {
   if (mode < 0 || mode > 4) return MRG_E_ENUM;
   gemm_mode() = mode;
+  return MRG_OK;
+}
+
+extern "C" int mrg_wgrad_set_variant(int variant) {
+  if (variant != 0 && variant != 1) return MRG_E_ENUM;
+  g_wgrad_variant = variant;
   return MRG_OK;
 }
 
@@ -894,14 +1099,8 @@ extern "C" int mrg_linear_bwd_weight3(const float* gY, const float* X1, const fl
   if (maxG == 0) return MRG_OK;
   const int ng = a.TM <= 4 ? 1 : 2, kt = 16 / ng;
   dim3 gridx(maxG, (a.TN + kt - 1) / kt, 3);
-  const size_t ldsx = (size_t)(ng == 2 ? 4 : 3) * WBR * (57 + kt * 8 + 1) * 16;
-  if (ng == 1) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-    hipLaunchKernelGGL((wgrad_x3_k<1>), gridx, dim3(WX_THREADS), ldsx, st, a);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-    hipLaunchKernelGGL((wgrad_x3_k<2>), gridx, dim3(WX_THREADS), ldsx, st, a);
-  }
+  if (ng == 1) launch_wgrad_x3<1>(gridx, a, st);
+  else launch_wgrad_x3<2>(gridx, a, st);
   MRG_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce3_k, dim3((K + 1 + 63) / 64, Nout, 3), dim3(1024), 0, st, red, K, Nout, a.TM * 32, a.TN * 32);
   MRG_LAUNCH_CHECK();

@@ -314,6 +314,55 @@ def test_split_core_weight_gradient(rows, K1, K2, Nout):
         assert errs[0][i] <= 2e-5 * scale
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 200, 200), (40000, 200, 0, 200), (3000, 100, 100, 100), (517, 64, 0, 40),
+                                             (31, 200, 200, 200), (16, 64, 64, 64), (5000, 256, 0, 256), (3001, 128, 128, 300), (33, 52, 0, 128),
+                                             (4800, 200, 200, 200), (9600, 200, 0, 200)])
+def test_weight_gradient_split_once_is_bit_exact_with_split_per_wave(rows, K1, K2, Nout):
+    """wgrad_x3v_k (every operand fragment split into its bf16 planes once per workgroup, shared through LDS) against
+    wgrad_x3_k (split by every wave that multiplies it): same products, same order -- gW and gb bit-identical when every row range
+    is whole 16-row tiles, for the single row range (mrg_linear_bwd_weight) and the three direction segments in one launch
+    (mrg_linear_bwd_weight3).  A ragged last tile is the 16 rows ENDING at the range's end in the new kernel (in-bounds loads
+    without a mask) and the rows from the last tile boundary on in the old one: the same products enter the matrix instruction in
+    other k positions, so its internal summation order differs -- float32 rounding only (<= 2e-6 of the largest entry)."""
+    from mr_gnas_amd._lib import call, ptr, ptr_array, stream_of
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + Nout + K2 + 1)
+    gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+    x1 = (torch.randn(rows, K1, generator=gen) * 2).to(DEV)
+    x2 = torch.randn(rows, K2, generator=gen).to(DEV) if K2 else None
+    b0, b1 = rows // 3, rows - rows // 4
+    res = {}
+    try:
+        for variant in (1, 0):
+            assert lib.mrg_wgrad_set_variant(variant) == 0
+            gW, gb = torch.full((Nout, K1 + K2), 7.0, device=DEV), torch.full((Nout,), 7.0, device=DEV)
+            ws = torch.empty(max(16, int(lib.mrg_linear_bwd_weight_workspace_bytes(rows, K1 + K2, Nout))), dtype=torch.uint8, device=DEV)
+            call("mrg_linear_bwd_weight", (ptr(gy), ptr(x1), ptr(x2), ptr(gW), ptr(gb), ptr(ws), rows, K1, K2, Nout, stream_of(gW)))
+            out = [gW, gb]
+            ws3 = int(lib.mrg_linear_bwd_weight3_workspace_bytes(b0, b1, rows, K1, K2, Nout))
+            if ws3 > 0:
+                gWs = [torch.full((Nout, K1 + K2), 7.0, device=DEV) for _ in range(3)]
+                gbs = [torch.full((Nout,), 7.0, device=DEV) for _ in range(3)]
+                w3 = torch.empty(ws3, dtype=torch.uint8, device=DEV)
+                call("mrg_linear_bwd_weight3", (ptr(gy), ptr(x1), ptr(x2), ptr_array(gWs), ptr_array(gbs), ptr(w3), b0, b1, rows, K1, K2, Nout, stream_of(gW)))
+                out += gWs + gbs
+            torch.cuda.synchronize()
+            res[variant] = out
+    finally:
+        lib.mrg_wgrad_set_variant(1)
+    assert len(res[0]) == len(res[1])
+    whole = all(n % 16 == 0 for n in (rows, b0, b1 - b0, rows - b1))
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        if whole:
+            assert torch.equal(a, b), f"output {i}: max diff {float((a - b).abs().max())}"
+        else:
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), f"output {i}: max diff {float((a - b).abs().max())}"
+    x = x1 if x2 is None else torch.cat((x1, x2), 1)
+    ref = gy.double().t() @ x.double()
+    assert float((res[1][0].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_compose_broadcast_relation_row():
     """Advisor r1: the reference's pre-ops broadcast (`src_emb - hr` with hr [1, D]); the gradient of a
     broadcast hr must come back in hr's own shape."""
