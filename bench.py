@@ -50,12 +50,13 @@ HBM_ACHIEVABLE_GBS = 6290.0   # the guide's measured float4 copy rate: what an H
 KERNEL_FAMILIES = {
     "row_gemm [rowgemm_x3s_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
                                  "mrg_dense_filter_fwd3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd"],
-    "weight_gradient [wgrad_x3_k]": ["mrg_linear_bwd_weight", "mrg_linear_bwd_weight3"],
+    "weight_gradient [wgrad_x3v_k]": ["mrg_linear_bwd_weight", "mrg_linear_bwd_weight3"],
     "mixedop_epilogue [mix_colstats_k mix_fwd_k mix_bwd_reduce_k mix_bwd_apply_k]": [
         "mrg_mix_stats_coef", "mrg_mix_colstats", "mrg_mix_finalize_fwd", "mrg_mix_fwd", "mrg_mix_bwd_reduce", "mrg_mix_finalize_bwd",
         "mrg_mix_bwd_apply"],
     "span_sums [span_gcs_k]": ["mrg_span_gcs", "mrg_fused_gcs"],
-    "scalar_gates [gate_fwd_k gate_bwd_k]": ["mrg_gate_collapse3", "mrg_gate_fwd", "mrg_gate_bwd", "mrg_gate_param_grad3"],
+    "scalar_gates [gate_row_fwd_k gate_row_bwd_k gate_fwd_k gate_bwd_k]": ["mrg_gate_collapse3", "mrg_gate_row_fwd", "mrg_gate_row_bwd", "mrg_gate_fwd", "mrg_gate_bwd",
+                                                                           "mrg_gate_param_grad3"],
     "gradient_fan_in [sum_k]": ["mrg_sum_buffers"],
     "segment_reducers [seg_chunk_k seg_bwd_k]": ["mrg_seg_reduce_fwd", "mrg_seg_reduce_bwd", "mrg_seg_reduce_bwd_bits", "mrg_seg_reduce_heads_fwd"],
     "gathers [gather_compose_k distmult_k zero_colstats_k]": ["mrg_gather_compose_fwd", "mrg_distmult_score", "mrg_zero_stats_coef", "mrg_zero_colstats"],

@@ -58,6 +58,11 @@ ENTRY_KERNELS.update({
     "mrg_zero_bwd_apply": ["zero_bwd_apply_k"],
     "mrg_span_gcs": ["span_gcs_k<4, 64, 1, 2|span_gcs_k<4, 64, 1, 1|span_gcs_k<4, 64, 1, 3"],
     "mrg_seg_reduce_bwd_bits": ["seg_bwd_bits_k"],
+    # round 3, later: the weight gradient that splits every fragment once per workgroup; f_sparse_comp as a row factor
+    "mrg_linear_bwd_weight": ["wgrad_x3v_k", "wgrad_reduce3_k"],
+    "mrg_linear_bwd_weight3": ["wgrad_x3v_k@max", "wgrad_reduce3_k"],
+    "mrg_gate_row_fwd": ["gate_row_fwd_k"],
+    "mrg_gate_row_bwd": ["gate_row_bwd_k"],
 })
 NORTH_STAR = "span_gcs_k<4, 64, 1, 0,"            # MODE = SUB only runs in bench.py's north-star passes (last parameter: prefetch-depth override)
 
