@@ -302,9 +302,13 @@ int mrg_mix_finalize_bwd(const float *red, int K, double total_rows, int D, floa
  * device pointers, used for those k only). */
 int mrg_mix_bwd_apply(const float *g, const float *const *y_host, float *const *gy_host, int K,
                       const float *coef, const float *coef2, const float *w, const float *const *rs, const float *rs_scale,
-                      const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *fold_s,
+                      const float *rs_self, const int64_t *rs_edge_rows, const int *rs_on, const float *const *rs_full,
+                      const float *const *fold_s,
                       const float *const *fold_gate, float *const *fold_gs, const int *fold_add_from, int64_t rows, int D,
                       const mrg_gated_branch *gated, void *stream);
+/* rs_full (HOST array of K device pointers, NULL or NULL entries = none): candidate k's multiplier expanded over ALL rows
+ * (rs_scale[k] * rs[k][r] on the edge rows, rs_self[k] on the others), which the kernel then loads with the candidates' rows
+ * instead of deriving it from rs / rs_scale / rs_self / rs_edge_rows between the arithmetic and the stores. */
 /* fold_add_from (HOST array of K ints, NULL = none): for a gated candidate k (rs_on[k] == 2), the index q of the candidate
  * whose OUTPUT is k's operand s (f_identity of the same MixedOp: y_host[q] == fold_s[k]); its gradient gy_q is added to
  * fold_gs[k] and gy_host[q] may be NULL -- both are gradients w.r.t. the same rows. */

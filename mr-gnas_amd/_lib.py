@@ -67,7 +67,7 @@ SIGNATURES = {
     "mrg_mix_fwd": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P, _P]),
     "mrg_mix_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P]),
     "mrg_mix_finalize_bwd": (_I, [_P, _I, ctypes.c_double, _I, _P, _P, _P, _P, _P]),
-    "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "mrg_mix_bwd_apply": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "mrg_dense_filter_fwd": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
     "mrg_dense_filter_dz": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "mrg_gemm_workspace_bytes": (_L, [_I, _I]),

@@ -64,6 +64,22 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// Sum over the 64 lanes of a wave, in every lane, without the LDS crossbar: four DPP steps inside each 16-lane row (quad
+// permutes, half-row mirror, row mirror -- VALU latency, no ds_bpermute round trip), then the four row sums through scalar
+// registers.  group_sum<64> is a chain of six dependent ds_bpermute (~100 cycles each), which a kernel with two or three waves
+// per SIMD cannot hide.  Association differs from group_sum's butterfly (float32 rounding only).
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  float t = x;
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xF, 0xF, true));   // row_mirror
+  const int ti = __builtin_bit_cast(int, t);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ float sigmoidf_fast(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
 // ---- row-tile geometry ---------------------------------------------------------

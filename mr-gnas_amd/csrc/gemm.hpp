@@ -281,7 +281,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     const int off = cok ? n * 32 : 0;
     const float bv = a.bias ? a.bias[cok ? col : colw] : 0.f;
     float in[16], v[16], g[16];
-    if (EPI == EPI_GATE || EPI == EPI_ACCUM) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[r] = 0.f;
+    if ((EPI == EPI_GATE && cstore) || EPI == EPI_ACCUM) {     // (gate only: the multiplicand is not read at all)
 #pragma unroll
       for (int r = 0; r < 16; ++r) in[r] = srow[r][off];
     }

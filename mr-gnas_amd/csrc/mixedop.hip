@@ -22,7 +22,10 @@ struct MutPack { float* p[MRG_MIX_MAXK]; };
 // add_from[k] (gated candidates only, -1 = none): the index of ANOTHER candidate whose own gradient gy is ADDED to gs_out[k] instead
 // of being stored -- f_identity of the same MixedOp: its output IS the operand s of candidate k, so both are gradients w.r.t. the
 // same rows and the state's fan-in sum would add them anyway (one [rows, D] write here and one read there less).
+// full[k] (optional): the same multiplier expanded over ALL rows by the caller -- loaded with the candidates' rows at the top of the
+// trip instead of conditionally (edge rows only) between the arithmetic and the stores, where its latency was exposed.
 struct RowScalePack { const float* rs[MRG_MIX_MAXK]; float scale[MRG_MIX_MAXK]; float self_scale[MRG_MIX_MAXK]; int64_t edge_rows[MRG_MIX_MAXK]; int on[MRG_MIX_MAXK];
+                      const float* full[MRG_MIX_MAXK];
                       const float* s[MRG_MIX_MAXK]; const float* gate[MRG_MIX_MAXK]; float* gs_out[MRG_MIX_MAXK]; int add_from[MRG_MIX_MAXK]; };
 
 // A gated candidate that is never stored (f_dense_comp, reference models/operations_lp.py:356-390): ys.p[k] holds its GATE
@@ -488,6 +491,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       Vec<VEC> ov[KB];                           // every wanted gy_k first: a gated candidate may add another one's
       Vec<VEC> orv = Vec<VEC>::fill(0.f);                  // gy of the row-scaled candidate
       float dq = 0.f;
+      float ckv[KB];                                       // folded row multipliers (RowScalePack.full)
+#pragma unroll
+      for (int k = 0; k < KB; ++k) ckv[k] = 1.f;
       if (act) {
         if constexpr (GATED) {                             // (unconditional: the host hands safe pointers for what is absent)
           gck = gated_rowscale(gp, r);
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
         for (int k = 0; k < KB; ++k) {
           vin[k] = Vec<VEC>::fill(0.f);
           if (k < K && need[k] && ys.p[k]) vin[k] = Vec<VEC>::load(ys.p[k] + r * D + c * VEC);
+          if (k < K && rsp.on[k] && rsp.full[k]) ckv[k] = rsp.full[k][r];
         }
         if constexpr (GATED) {
 #pragma unroll
@@ -544,7 +551,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       }
       float dzr = 0.f;
       if (hasr) {                                          // all lanes of the row (inactive ones carry 0): KMAX == 1 (host-checked)
-        const float qr = group_sum<LPR>(dq);
+        float qr;
+        if constexpr (LPR == 64) qr = wave_sum_dpp(dq);     // one row per wave: no LDS round trips between the arithmetic and the stores
+        else qr = group_sum<LPR>(dq);
         dzr = qr * rhv;                                    // (used by the active lanes only, which loaded rhv)
         if (sl == 0) gp.rdq[r] = qr;
       }
@@ -554,7 +563,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
           if (k < K && gys.p[k] != nullptr) {
             Vec<VEC> o = ov[k];
             if (rsp.on[k]) {                               // the consumer's first backward pass (mrg_dense_filter_dz) folded into this store
-              const float ck = r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k];
+              const float ck = rsp.full[k] ? ckv[k]
+                                           : (r < rsp.edge_rows[k] ? rsp.scale[k] * (rsp.rs[k] ? rsp.rs[k][r] : 1.0f) : rsp.self_scale[k]);
               if (rsp.on[k] == 2) {                        // f_dense_comp: same expressions, same order as dense_dz_k<.., 0>
                 // (the recomputed candidate holds both already: the host checks rsp.s[k] == gp.s and rsp.gate[k] == ys.p[k])
                 const Vec<VEC> sv = (GATED && k == gp.k) ? gsv : Vec<VEC>::load(rsp.s[k] + r * D + c * VEC);
@@ -1107,6 +1117,7 @@ extern "C" int mrg_mix_finalize_bwd(const float* red, int K, double total_rows, 
 extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, float* const* gy_host, int K, const float* coef,
                                  const float* coef2, const float* w, const float* const* rs_host, const float* rs_scale_host,
                                  const float* rs_self_host, const int64_t* rs_edge_rows_host, const int* rs_on_host,
+                                 const float* const* rs_full_host,
                                  const float* const* fold_s_host, const float* const* fold_gate_host, float* const* fold_gs_host,
                                  const int* fold_add_from_host, int64_t rows, int D, const mrg_gated_branch* gated, void* stream) {
   if (!pack_ok((const void* const*)y_host, K) || !gy_host || rows < 0 || D <= 0) return MRG_E_SHAPE;
@@ -1130,6 +1141,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
     for (int k = 0; k < K; ++k) {
       rsp.on[k] = rs_on_host[k];
       rsp.rs[k] = rs_host ? rs_host[k] : nullptr;
+      rsp.full[k] = (rs_full_host && rsp.on[k]) ? rs_full_host[k] : nullptr;
       rsp.scale[k] = rs_scale_host[k]; rsp.self_scale[k] = rs_self_host[k]; rsp.edge_rows[k] = rs_edge_rows_host[k];
       if (rsp.on[k] == 2) {
         if (!fold_s_host || !fold_gate_host || !fold_gs_host || !fold_s_host[k] || !fold_gate_host[k] || !fold_gs_host[k]) return MRG_E_NULLPTR;

@@ -1091,6 +1091,9 @@ class _MixedEpilogue(torch.autograd.Function):
             rs_edge = (ctypes.c_int64 * K_)(*[int(r[1]) if r is not None else 0 for r in rs])
             rs_scale = (ctypes.c_float * K_)(*[float(r[2]) if r is not None else 1.0 for r in rs])
             rs_self = (ctypes.c_float * K_)(*[float(r[3]) if r is not None else 1.0 for r in rs])
+            # the same multipliers expanded over all rows (cached per graph): one unconditional load per row in the kernel
+            rs_full_t = [_gated_rowscale(r[0], int(r[1]), rows, float(r[2]), float(r[3]), dev) if r is not None else None for r in rs]
+            rs_full = ptr_array(rs_full_t)
             # gated consumers (f_dense_comp): their dz AND the direct term of their input gradient are written here; the buffer of
             # the direct term is handed to the consumer's backward node (which runs later, maybe on a side stream)
             gated = [r is not None and r[4] is not None for r in rs]
@@ -1107,9 +1110,9 @@ class _MixedEpilogue(torch.autograd.Function):
             n_fold = sum(gated)
             f_add = (ctypes.c_int * K_)(*[(add_from[1] if (add_from is not None and k == add_from[0]) else -1) for k in range(K_)])
         else:
-            on = rs_ptr = rs_edge = rs_scale = rs_self = f_s = f_gate = f_gs_p = f_add = None
+            on = rs_ptr = rs_edge = rs_scale = rs_self = rs_full = f_s = f_gate = f_gs_p = f_add = None
             n_fold = 0
-        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on,
+        call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), rs_ptr, rs_scale, rs_self, rs_edge, on, rs_full,
                                    f_s, f_gate, f_gs_p, f_add, rows, D, gb, st),
              nbytes=4 * D * rows * (1 + ctx.nz_rd + n_out + n_fold))
         if rs is not None:

@@ -261,7 +261,7 @@ def test_c1_fb15k237_fixed_genotype_d64_matches_float64_oracle():
     pred64 = ON.fixed_net_forward(og, P, README_GENOTYPE, subj, rel, 2 * R + 1, gamma=40.0)
     loss64 = F.binary_cross_entropy(pred64, label.double())
     loss64.backward()
-    assert float((pred.detach().double() - pred64).abs().max()) <= 1e-4          # probabilities in [0, 1]
+    assert float((pred.detach().double() - pred64.detach()).abs().max()) <= 1e-4          # probabilities in [0, 1]
     assert abs(float(loss.detach()) - float(loss64)) <= 1e-4 * max(1.0, float(loss64))
     for k, p in net.named_parameters():
         ref = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])

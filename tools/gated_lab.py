@@ -41,7 +41,7 @@ for tag, ys, gspec in (("stored", [None, s, yd, y3, y4], None), ("gated", [None,
         "stats": lambda: call("mrg_mix_stats_coef", (ypa, ptr_array(gam), ptr_array(bet), None, None, K_, rows, float(rows), D, 1e-5, 0.1, ptr(coef), ptr(ws), gb(), st)),
         "fwd": lambda: call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), None, ptr(out), rows, D, gb(), st)),
         "reduce": lambda: call("mrg_mix_bwd_reduce", (ptr(g), ypa, K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, gb(), st)),
-        "apply": lambda: call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), None, None, None, None, None, None, None, None, None,
+        "apply": lambda: call("mrg_mix_bwd_apply", (ptr(g), ypa, ptr_array(gys), K_, ptr(coef), ptr(coef2), ptr(w), None, None, None, None, None, None, None, None, None, None,
                                                     rows, D, gb(), st)),
     }
     for name, fn in steps.items():
