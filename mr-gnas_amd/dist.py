@@ -24,9 +24,12 @@ Exchange steps (the only collectives):
      node rows only -- half the bytes of an all-reduce.  Launched asynchronously as
      soon as the partials exist, so the exchange of MixedOp i overlaps the
      edge-parallel GEMMs of MixedOp i + 1.  Backward = the adjoint all-gather;
-  2. per BatchNorm: all-reduce of [2, D] (sum x, sum x^2) forward and of
-     (sum g, sum g*xhat) backward -- BN normalises over all M rows
-     (reference models/cell_lp.py:21), so shards must share statistics;
+  2. BatchNorm statistics: all-reduce of [K, 2, D] (sum x, sum x^2) forward and of
+     [K, 3, D] (sum g, sum g*xhat, ...) backward -- BN normalises over all M rows
+     (reference models/cell_lp.py:21), so shards must share statistics.  One
+     collective per MixedOp covers its K candidates; the MixedOps feeding ONE state
+     (reference :104-113) share one collective forward and one backward
+     (functional.StatChain): per cell 7 forward + 8 backward instead of 12 + 12;
   3. per layer: all_gather_into_tensor of the [N, D] node embeddings over the same
      equal chunks (next layer's gather and the scorer read rows of other ranks);
      backward = reduce-scatter (sum);
@@ -48,6 +51,10 @@ from . import functional as K
 from . import operations_lp as OPS
 from .supernet import _tsum
 from .graph import RelGraph, cached_on
+
+import os
+# one all-reduce for the BatchNorm statistics of the MixedOps feeding a state, forward and backward (functional.StatChain); 0 = one per MixedOp
+BATCH_STATS = os.environ.get("MRG_BATCH_STATS", "1") == "1"
 
 
 # ---------------------------------------------------------------------------
@@ -332,6 +339,22 @@ class ShardedSupernet:
             out = out + wk * act(sync_batch_norm(op(self.s, h, h_in).float(), bn, total_rows, self.group))
         return out
 
+    def _mixed_sum(self, ops, ws, hs, h_in, total_rows):
+        """sum_j MixedOp_j(hs[j], h_in) -- the MixedOps feeding one state (reference models/cell_lp.py:104-113).  On the GPU their
+        BatchNorm statistics travel in ONE all-reduce forward and ONE backward (functional.StatChain) instead of one each."""
+        first = hs[0].x if isinstance(hs[0], K.Fan) else hs[0]
+        if not (first.is_cuda and BATCH_STATS and len(ops) > 1):
+            sN = None
+            for op, w, h in zip(ops, ws, hs):
+                sN = self._mixed(op, w, h, h_in, total_rows, addend=sN)
+            return sN
+        preps = [op(w, self.s, h, h_in, group=self._stat_group(), total_rows=total_rows, prepare_only=True) for op, w, h in zip(ops, ws, hs)]
+        K.StatChain(preps, self._stat_group(), summed=True)
+        sN = None
+        for prep, w in zip(preps, ws):
+            sN = prep(w, sN)
+        return sN
+
     def _partials(self, mixed_op, take):
         """The rank-local halves of a middle MixedOp (reference models/operations_lp.py:223-264): per candidate the
         partial [N, D] over the LOCAL in-edges and the residual self rows; a_sum's and a_mean's partials are summed by
@@ -396,6 +419,16 @@ class ShardedSupernet:
             parts = self._partials(cell.cell_middle._ops[i], take)
             started.append((parts, self._exchange_start(parts)))
         outs = []
+        if started and started[0][0]["a_max"][0].is_cuda and BATCH_STATS and len(started) > 1:
+            # the two MixedOps' statistics in ONE forward all-reduce (their outputs are separate states: the backward reductions
+            # see different upstream gradients at different times and keep a collective each)
+            preps = []
+            for i, (parts, st) in enumerate(started):
+                mixed_op = cell.cell_middle._ops[i]
+                ys = self._exchange_finish(mixed_op, parts, st)
+                preps.append(K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in mixed_op._ops], self._stat_group(), total_nodes))
+            K.StatChain(preps, self._stat_group(), summed=False)
+            return [prep(wm[i]) for i, prep in enumerate(preps)]
         for i, (parts, st) in enumerate(started):
             mixed_op = cell.cell_middle._ops[i]
             ys = self._exchange_finish(mixed_op, parts, st)
@@ -415,18 +448,16 @@ class ShardedSupernet:
         h_in = fan(self._mixed(cell.cell_zero._ops[0], wz[0], x, hr, M))
         states, off = [h_in], 0
         for _ in range(cell.n_first):
-            sN = None
-            for j, h in enumerate(states):
-                sN = self._mixed(cell.cell_first._ops[off + j], wf[off + j], h, h_in, M, addend=sN)
-            off += len(states)
+            n = len(states)
+            sN = self._mixed_sum(cell.cell_first._ops[off:off + n], wf[off:off + n], states, h_in, M)
+            off += n
             states.append(fan(sN))
         states = [fan(y) for y in self._middle_stage(cell, wm, states[1:], N)]
         off = 0
         for _ in range(cell.n_last):
-            sN = None
-            for j, h in enumerate(states):
-                sN = self._mixed(cell.cell_last._ops[off + j], wl[off + j], h, h_in, N, addend=sN)
-            off += len(states)
+            n = len(states)
+            sN = self._mixed_sum(cell.cell_last._ops[off:off + n], wl[off:off + n], states, h_in, N)
+            off += n
             states.append(fan(sN))
         states = [t.take() if isinstance(t, K.Fan) else t for t in states]
         return cell.concat_weights(torch.cat(states, dim=1))

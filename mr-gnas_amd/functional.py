@@ -959,6 +959,7 @@ class _MixCfg:
         # (k, s, c [rows]): candidate k arrives as its GATE and is recomputed as gate * s * c[r] wherever the kernels read it
         # (include/mrgnas.h: mrg_gated_branch), or None
         self.gated = gated
+        self.chain = None              # (StatChain, index): the statistics collectives are shared with other epilogues
         self.identity = identity       # index of the candidate that returns its input unchanged (f_identity), or None
         self.rowscale = rowscale       # per candidate None or (norm [E] | None, edge_rows, scale_edge, scale_self, gated node | None, node): folded into its gradient
 
@@ -1009,9 +1010,12 @@ class _MixedEpilogue(torch.autograd.Function):
                      nbytes=4 * D * rows * nz_rd)
             else:
                 import torch.distributed as dist
-                sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
-                call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), gb, st), nbytes=4 * D * rows * nz_rd)
-                dist.all_reduce(sums, group=cfg.group)
+                if cfg.chain is not None and cfg.chain[0].sums is not None:
+                    sums = cfg.chain[0].sums[cfg.chain[1]]             # column sums of the whole graph, all-reduced with the other members'
+                else:
+                    sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
+                    call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), gb, st), nbytes=4 * D * rows * nz_rd)
+                    dist.all_reduce(sums, group=cfg.group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:                                      # one multi-tensor launch instead of one per BatchNorm
                 torch._foreach_add_([b.num_batches_tracked for b in cfg.bns], 1)
@@ -1026,7 +1030,22 @@ class _MixedEpilogue(torch.autograd.Function):
         call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(addend), ptr(out), rows, D, gb, st), nbytes=4 * D * rows * (nz_rd + 1 + (addend is not None)))
         ctx.cfg, ctx.training, ctx.total, ctx.nz, ctx.nz_rd = cfg, training, total, nz, nz_rd
         ctx.save_for_backward(w, coef, *ys_nz)
+        if cfg.chain is not None:
+            cfg.chain[0].ctx[cfg.chain[1]] = ctx
         return out
+
+    @staticmethod
+    def _launch_bwd_reduce(ctx, g, red):
+        """red[k][0..2] <- this rank's sums of member ctx for upstream gradient g."""
+        from ._lib import ptr_array
+        w, coef, *ys_nz = ctx.saved_tensors
+        cfg, K_ = ctx.cfg, len(ctx.cfg.bns)
+        it = iter(ys_nz)
+        ys = _row_candidate_as_s(cfg, [next(it) if p else None for p in cfg.present])
+        rows, D = g.shape
+        ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
+        call("mrg_mix_bwd_reduce", (ptr(g), ptr_array(ys), K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, _lib.gated_branch(cfg.gated), stream_of(g)),
+             nbytes=4 * D * rows * (ctx.nz_rd + 1))
 
     @staticmethod
     def backward(ctx, g):
@@ -1040,15 +1059,20 @@ class _MixedEpilogue(torch.autograd.Function):
         rows, D = g.shape
         dev, st = g.device, stream_of(g)
         ypa = ptr_array(ys)
-        ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
-        red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
         gb = _lib.gated_branch(cfg.gated)
-        call("mrg_mix_bwd_reduce", (ptr(g), ypa, K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, gb, st), nbytes=4 * D * rows * (ctx.nz_rd + 1))
-        red_local = red
-        if cfg.group is not None and ctx.training:
-            import torch.distributed as dist
-            red = red.clone()
-            dist.all_reduce(red, group=cfg.group)
+        shared = None
+        if cfg.group is not None and ctx.training and cfg.chain is not None:
+            shared = cfg.chain[0].reduced_gradient_sums(cfg.chain[1], g, _MixedEpilogue._launch_bwd_reduce)
+        if shared is not None:
+            red_local, red = shared
+        else:
+            red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
+            _MixedEpilogue._launch_bwd_reduce(ctx, g, red)
+            red_local = red
+            if cfg.group is not None and ctx.training:
+                import torch.distributed as dist
+                red = red.clone()
+                dist.all_reduce(red, group=cfg.group)
         coef2 = torch.empty(K_, 2, D, dtype=torch.float32, device=dev)
         dw = torch.empty(K_, dtype=torch.float32, device=dev)
         call("mrg_mix_finalize_bwd", (ptr(red), K_, ctx.total, D, ptr(coef2), None, None, ptr(dw), st))
@@ -1131,6 +1155,98 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
     """addend + sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
     all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine); addend: the output of the MixedOp this
     one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel."""
+    return mixed_epilogue_prepare(ys, bns, group, total_rows, fold_row_scales, identity)(w, addend)
+
+
+class PreparedEpilogue:
+    """A MixedOp epilogue whose candidates are known but which has not run: calling it with (w, addend) runs it.  Exists so that the
+    statistics collectives of several epilogues can be issued together (StatChain) before any of them combines."""
+
+    def __init__(self, cfg, cand, bns):
+        self.cfg, self.cand, self.bns = cfg, cand, bns
+
+    def __call__(self, w, addend=None):
+        self.cfg.has_addend = addend is not None
+        tensors = self.cand + [b.weight for b in self.bns] + [b.bias for b in self.bns] + ([addend] if addend is not None else [])
+        return _MixedEpilogue.apply(self.cfg, w, *tensors)
+
+
+class StatChain:
+    """ONE collective for the BatchNorm statistics of several MixedOp epilogues over row-sharded candidates (VERDICT r2 #4b).
+    Forward: the column sums of every member are computed first (they do not depend on one another: an `addend` only enters the
+    combine) into one stacked buffer, all-reduced once; each member's forward then finalizes from its slice.  Backward, when the
+    members' outputs are summed into one state (`summed=True`: every member receives the SAME upstream gradient): the member whose
+    backward runs first launches the gradient reductions of ALL members, all-reduces the stacked result once and leaves each
+    member's slice for its own backward.  Values are those of one collective per member (a sum over ranks of the same numbers)."""
+
+    def __init__(self, members, group, summed):
+        import torch.distributed as dist
+        self.members, self.group, self.summed = members, group, summed
+        self.ctx = [None] * len(members)
+        self.bwd = None                                    # (g data_ptr, [red_local_j], [red_global_j])
+        self.sums = None
+        cfgs = [m.cfg for m in members]
+        if not members or not all(self._trains(c) for c in cfgs):
+            return                                         # eval mode: fixed statistics, no collective at all
+        ks = [len(c.bns) for c in cfgs]
+        first = next(y for y in _row_candidate_as_s(cfgs[0], self._ys(members[0])) if y is not None)
+        D = first.shape[1]
+        sums = torch.empty(sum(ks), 2, D, dtype=torch.float64, device=first.device)
+        off = 0
+        for j, m in enumerate(members):
+            m.cfg.chain = (self, j)
+            ys = _row_candidate_as_s(m.cfg, self._ys(m))
+            y0 = next(y for y in ys if y is not None)
+            rows = y0.shape[0]
+            ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", ks[j], D), y0)
+            nz_rd = len({y.data_ptr() for y in ys if y is not None} | ({m.cfg.gated["s"].data_ptr()} if m.cfg.gated is not None else set()))
+            call("mrg_mix_colstats", (ptr_array(ys), ks[j], rows, D, ptr(sums[off:off + ks[j]]), ptr(ws), _lib.gated_branch(m.cfg.gated), stream_of(y0)),
+                 nbytes=4 * D * rows * nz_rd)
+            off += ks[j]
+        dist.all_reduce(sums, group=group)
+        self.sums, off = [], 0
+        for k_ in ks:
+            self.sums.append(sums[off:off + k_])
+            off += k_
+
+    @staticmethod
+    def _trains(cfg):
+        b = cfg.bns[0]
+        return b.training or not b.track_running_stats
+
+    @staticmethod
+    def _ys(m):
+        it = iter(f32c(t) for t in m.cand)
+        return [next(it) if p else None for p in m.cfg.present]
+
+    def reduced_gradient_sums(self, j, g, launch):
+        """(red_local, red_global) of member j for upstream gradient g; `launch(ctx, g, red_out)` runs one member's reduction."""
+        import torch.distributed as dist
+        if not self.summed:
+            return None
+        if self.bwd is None or self.bwd[0] != g.data_ptr():
+            if any(c is None for c in self.ctx):
+                return None
+            ks = [len(m.cfg.bns) for m in self.members]
+            D = g.shape[1]
+            red = torch.empty(sum(ks), 3, D, dtype=torch.float32, device=g.device)
+            off, loc = 0, []
+            for i, c in enumerate(self.ctx):
+                launch(c, g, red[off:off + ks[i]])
+                loc.append(red[off:off + ks[i]])
+                off += ks[i]
+            glob = red.clone()
+            dist.all_reduce(glob, group=self.group)
+            off, gl = 0, []
+            for k_ in ks:
+                gl.append(glob[off:off + k_])
+                off += k_
+            self.bwd = (g.data_ptr(), loc, gl, g)          # g kept alive: its address identifies the batch
+        return self.bwd[1][j], self.bwd[2][j]
+
+
+def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales=False, identity=None):
+    """mixed_epilogue without running it: returns a PreparedEpilogue."""
     present = [y is not None for y in ys]
     # a candidate whose backward starts with a row scale of its incoming gradient (f_comp: dz = g * c) and whose output feeds
     # ONLY this epilogue gets that scale folded into the epilogue's gradient store; its backward node is told to skip the pass
@@ -1169,9 +1285,8 @@ def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_ro
             gated.update(row_k=k, row_f=y, b0=rb0, b1=rb1, row_node=y.grad_fn)
         else:
             ys[k] = s_r * y.unsqueeze(1)
-    cfg = _MixCfg(list(bns), present, group, total_rows, addend is not None, rowscale, identity, gated)
-    tensors = [y for y in ys if y is not None] + [b.weight for b in bns] + [b.bias for b in bns] + ([addend] if addend is not None else [])
-    return _MixedEpilogue.apply(cfg, w, *tensors)
+    cfg = _MixCfg(list(bns), present, group, total_rows, False, rowscale, identity, gated)
+    return PreparedEpilogue(cfg, [y for y in ys if y is not None], list(bns))
 
 
 

@@ -73,7 +73,7 @@ class MixedOp(nn.Module):
         self._ops = nn.ModuleList(nn.ModuleList([registry[name](args), nn.BatchNorm1d(feature_dim), nn.ReLU()])
                                   for name in operations)
 
-    def forward(self, weights, g, h, h_in, group=None, total_rows=None, addend=None):
+    def forward(self, weights, g, h, h_in, group=None, total_rows=None, addend=None, prepare_only=False):
         """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
         BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
         materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
@@ -121,8 +121,9 @@ class MixedOp(nn.Module):
                     ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))
                 else:
                     ys.append(op(g, fh.take(), fi.take()))
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True,
-                                    identity=self._identity_index())
+            prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
+            # prepare_only (dist.py): the caller issues the statistics collective of several MixedOps at once (functional.StatChain)
+            return prep if prepare_only else prep(weights, addend)
         fork = K.Fork(dev, nstreams, tag="candidates")
         ys = []
         for k, (op, _, _) in enumerate(self._ops):
@@ -149,8 +150,8 @@ class MixedOp(nn.Module):
             y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
-        return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True,
-                                identity=self._identity_index())
+        prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
+        return prep if prepare_only else prep(weights, addend)
 
 
     def _identity_index(self):

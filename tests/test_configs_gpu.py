@@ -262,7 +262,7 @@ def test_c1_fb15k237_fixed_genotype_d64_matches_float64_oracle():
     loss64 = F.binary_cross_entropy(pred64, label.double())
     loss64.backward()
     assert float((pred.detach().double() - pred64.detach()).abs().max()) <= 1e-4          # probabilities in [0, 1]
-    assert abs(float(loss.detach()) - float(loss64)) <= 1e-4 * max(1.0, float(loss64))
+    assert abs(float(loss.detach()) - float(loss64.detach())) <= 1e-4 * max(1.0, float(loss64.detach()))
     for k, p in net.named_parameters():
         ref = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
         err, scale = grad_err(p.grad if p.grad is not None else torch.zeros_like(p), ref)
