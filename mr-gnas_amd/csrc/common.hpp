@@ -64,6 +64,16 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// Which of the block's row groups a thread belongs to.  With LPR == 64 a row group is a wave: the index is wave-uniform, and saying
+// so (readfirstlane) turns every `base + r * D` of the kernel into scalar arithmetic and every row access into the
+// SGPR-base + 32-bit lane offset form -- no 64-bit address registers and adds per tensor stream.
+template <int LPR>
+__device__ __forceinline__ int row_group_of_thread() {
+  const int rw = (int)threadIdx.x / LPR;
+  if constexpr (LPR == 64) return __builtin_amdgcn_readfirstlane(rw);
+  else return rw;
+}
+
 // Sum over the 64 lanes of a wave, in every lane, without the LDS crossbar: four DPP steps inside each 16-lane row (quad
 // permutes, half-row mirror, row mirror -- VALU latency, no ds_bpermute round trip), then the four row sums through scalar
 // registers.  group_sum<64> is a chain of six dependent ds_bpermute (~100 cycles each), which a kernel with two or three waves

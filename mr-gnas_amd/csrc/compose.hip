@@ -61,7 +61,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gather_compose_k(const float* __res
                                                               const int32_t* __restrict__ ei, const int32_t* __restrict__ ri,
                                                               float* __restrict__ out, int64_t rows, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
     const float* a = ent + (int64_t)ei[r] * D;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void dense_dz_k(const float* __restrict_
                                                         float scale, float* __restrict__ dz, float* __restrict__ gs,
                                                         int64_t rows, int D, int64_t edge_rows, float scale_self) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
     // rows [0, edge_rows): c = scale * rowscale[row]; rows behind them (the self rows of a three-segment call): scale_self

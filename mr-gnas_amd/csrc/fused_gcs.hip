@@ -29,7 +29,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_k(const float* __restrict__ X, 
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int U = 4;
   constexpr bool NY = NeedsY<MODE>::value;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ float lds[RPB * 2 * WIDTH];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   float* lx = lds + rw * 2 * WIDTH;
   float* ly = lx + WIDTH;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void span_gcs_k(const float* __restrict_
   // (91.7 us against 97.5 us): tools/ns_sweep.py
   constexpr int U = UOVR > 0 ? UOVR : SPAN_U<MODE>::value;
   constexpr bool NY = NeedsY<MODE>::value;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t sp = (int64_t)blockIdx.x * RPB + rw; sp < n_spans; sp += (int64_t)gridDim.x * RPB) {
     // spans cut at segment ends (mrg_span_plan_build's span_start): only segments longer than a span leave partial runs
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void distmult_k(const float* __restrict_
                                                         const int32_t* __restrict__ si, const int32_t* __restrict__ ri,
                                                         const int32_t* __restrict__ oi, float* __restrict__ score, int64_t T, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t t = (int64_t)blockIdx.x * RPB + rw; t < T; t += (int64_t)gridDim.x * RPB) {
     const float* a = ent + (int64_t)si[t] * D;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_fwd_k(const float* __restrict_
   if (b >= p.blk[3]) return;
   const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
   const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const float* u = uvc + (int64_t)seg * MRG_GATE_LD(D);
   const float cc = u[HAS_IN ? 2 * D : D];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
   if (b >= p.blk[3]) return;
   const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
   const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int ld = MRG_GATE_LD(D);
   const int cidx = HAS_IN ? 2 * D : D;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_row_fwd_k(const float* __restr
   if (b >= p.blk[3]) return;
   const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
   const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const float* u = uvc + (int64_t)seg * MRG_GATE_LD(D);
   const float cc = u[HAS_IN ? 2 * D : D];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_row_bwd_k(const float* __restr
   if (b >= p.blk[3]) return;
   const int seg = (b >= p.blk[1]) + (b >= p.blk[2]);
   const int jb = b - p.blk[seg], nb = p.blk[seg + 1] - p.blk[seg];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int ld = MRG_GATE_LD(D);
   const int cidx = HAS_IN ? 2 * D : D;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, i
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ double red[RPB * 2 * WIDTH];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int64_t step = (int64_t)gridDim.x * RPB;
   int first = MRG_MIX_MAXK;                                // the shared sweep runs at the first of its candidates
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
                                                        const float* __restrict__ addend, GatedPack gp) {
   extern __shared__ float lds[];                 // [K][2][D] scale, shift
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int t = threadIdx.x; t < K * 2 * D; t += MRG_BLOCK) {
     int k = t / (2 * D), rem = t - k * 2 * D;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
   extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   float* red = lds + K * 4 * D;                  // [RPB][3][WIDTH]
   for (int t = threadIdx.x; t < K * 4 * D; t += MRG_BLOCK) lds[t] = coef[t];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
                                                              GatedPack gp) {
   extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int t = threadIdx.x; t < K * 6 * D; t += MRG_BLOCK) {
     int k = t / (6 * D), rem = t - k * 6 * D;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_colstats_k(ZeroSrc z, int64_t 
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ double red[RPB * 2 * WIDTH];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int K = z.K;
   double s1[ZK][KMAX][VEC], s2[ZK][KMAX][VEC];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_fwd_k(ZeroSrc z, const float* 
                                                         float* __restrict__ out, int64_t rows, int D) {
   extern __shared__ float lds[];                 // [K][2][D] scale, shift
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int K = z.K;
   for (int t = threadIdx.x; t < K * 2 * D; t += MRG_BLOCK) {
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_reduce_k(const float* __re
   extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int K = z.K;
   float* red = lds + K * 4 * D;                  // [RPB][3][WIDTH]
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __res
                                                               float* __restrict__ ge_rows, float* __restrict__ gr_rows, int64_t rows, int D) {
   extern __shared__ float lds[];                 // [K][6][D]: scale, shift, invstd, mean*invstd, c1, c2
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   const int K = z.K;
   for (int t = threadIdx.x; t < K * 6 * D; t += MRG_BLOCK) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(THREADS) void seg_hub_k(const float* __restrict__ s
   constexpr int U = 8;
   __shared__ float sval[RPB * WIDTH];
   __shared__ int32_t sarg[IS_MAX ? RPB * WIDTH : 1];
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
     const int v = hub_node[h];

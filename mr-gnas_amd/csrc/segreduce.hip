@@ -31,7 +31,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_chunk_k(const float* __restrict
                                                          const int32_t* __restrict__ head_rowptr = nullptr) {
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int U = 4;                                      // rows in flight per lane group
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__
                                                        const float* __restrict__ relu_src, int64_t E, int64_t rows, int D,
                                                        const unsigned* __restrict__ relu_bits = nullptr) {
   constexpr int RPB = MRG_BLOCK / LPR;
-  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
     const bool edge = r < E;
