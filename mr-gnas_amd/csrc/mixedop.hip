@@ -890,9 +890,31 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __res
   }
 }
 
+static int lab_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// statistics: the flat kernels' bound (512 blocks measured best: profiles/r3_stream_grid.txt)
 static int mix_grid(int64_t rows, int lpr) {
   int g = stream_grid_for(rows, (MRG_BLOCK / lpr) * 8);
   return g > 1024 ? 1024 : g;                      // partial buffers are sized for 1024 blocks
+}
+// backward reduction / combine: since the row addressing became scalar these kernels hold 4 / 8 workgroups per CU and gain from
+// more blocks than the 512 of the flat kernels (lab: 3.0 -> 2.4 ms and 2.53 -> 2.42 ms per step at 1024)
+static int mix_reduce_grid(int64_t rows, int lpr) {
+  static const int cap = lab_env_int("MRG_MIX_REDUCE_BLOCKS", 1024);
+  int64_t b = (rows + (MRG_BLOCK / lpr) * 8 - 1) / ((MRG_BLOCK / lpr) * 8);
+  const int c = cap > 1024 ? 1024 : (cap < 1 ? 1 : cap);              // partial buffers are sized for 1024 blocks
+  return (int)(b < 1 ? 1 : (b > c ? c : b));
+}
+static int mix_apply_grid(int64_t rows, int lpr) {
+  static const int cap = lab_env_int("MRG_MIX_APPLY_BLOCKS", MRG_MAX_GRID);
+  int64_t b = (rows + (MRG_BLOCK / lpr) * 4 - 1) / ((MRG_BLOCK / lpr) * 4);
+  const int c = cap > 8192 ? 8192 : (cap < 1 ? 1 : cap);
+  return (int)(b < 1 ? 1 : (b > c ? c : b));
+}
+static int mix_fwd_grid(int64_t rows, int lpr) {
+  static const int cap = lab_env_int("MRG_MIX_FWD_BLOCKS", 1024);
+  int64_t b = (rows + (MRG_BLOCK / lpr) * 4 - 1) / ((MRG_BLOCK / lpr) * 4);
+  const int c = cap > MRG_MAX_GRID ? MRG_MAX_GRID : (cap < 1 ? 1 : cap);
+  return (int)(b < 1 ? 1 : (b > c ? c : b));
 }
 
 static bool pack_ok(const void* const* host, int K) { return host != nullptr && K >= 1 && K <= MRG_MIX_MAXK; }
@@ -1048,7 +1070,7 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    const dim3 grid_(stream_grid_for(rows, (MRG_BLOCK / L) * 4));                                          \
+    const dim3 grid_(mix_fwd_grid(rows, L));                                                               \
     if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
       if (K <= 5) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
       else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
@@ -1081,7 +1103,7 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
   int grid = 1;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    grid = mix_grid(rows, L);                                                                             \
+    grid = mix_reduce_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
     if ((gp.k >= 0 || gp.rk >= 0) && K <= 5) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 5, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
@@ -1172,7 +1194,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
   if (lds > 64 * 1024) return MRG_E_SHAPE;
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
-    const dim3 grid_(grid_for(rows, (MRG_BLOCK / L) * 4));                                                 \
+    const dim3 grid_(mix_apply_grid(rows, L));                                                             \
     if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
       if (K <= 5) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
       else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \

@@ -470,7 +470,7 @@ def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
     for lo in range(0, M, 1 << 21):
         z = (y64[lo:lo + (1 << 21)].double() - mean) / torch.sqrt(var + bns[k].eps) * bns[k].weight.double() + bns[k].bias.double()
         t = gup[lo:lo + (1 << 21)].double() * torch.relu(z)
-        dw += float(t.sum())
+        dw += float(t.detach().sum())
         dw_abs += float(t.abs().sum())
     assert abs(float(w.grad[k]) - dw) <= 1e-5 * dw_abs                 # a sum of 2.8e9 random-sign terms
     del out, gup, ys, xs
