@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Lab: randomized comparison of a first-stage MixedOp with its candidates recomputed (gate-only f_dense_comp, row-factor
+f_sparse_comp: functional.GATED_RECOMPUTE / ROW_FACTOR) against the stored form.  Random D (multiples of 4 from 52 to 320 -- above 256
+the row factor is multiplied out), edge counts, direction splits incl. empty segments, tied / distinct operands, training / eval.
+Output and running statistics must be bit-identical; gradients bit-identical for the gate-only form, within float32 rounding with the
+row factor.   usage: python tools/fuzz_mixed.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mr_gnas_amd import functional as K, graph as G, operations_lp as O, supernet as S  # noqa: E402
+
+DEV = "cuda"
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+class SplitGraph(G.RelGraph):
+    def bounds(self):
+        return self._b0, self.num_edges()
+
+
+bad = 0
+for case in range(cases):
+    D = int(rng.choice([52, 64, 100, 128, 200, 256, 260, 320]))
+    N = int(rng.integers(3, 400))
+    E = int(rng.choice([0, 1, 17, 300, 5000, 40000]))
+    b0 = int(rng.choice([0, E // 2, E, int(rng.integers(0, E + 1))]))
+    tied = bool(rng.integers(0, 2))
+    training = bool(rng.integers(0, 4) > 0)
+    gen = torch.Generator().manual_seed(case)
+    g = SplitGraph(N, torch.randint(0, N, (E,), generator=gen).numpy(), torch.randint(0, N, (E,), generator=gen).numpy(),
+                   torch.randint(0, 6, (E,), generator=gen).numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    g._b0 = b0
+    torch.manual_seed(case)
+    mixed = S.MixedOp(D, 0.0, O.FIRST_OPS).to(DEV)
+    S.xavier_init_(mixed)
+    for p in mixed.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn(p.shape, generator=gen).to(DEV))
+    state0 = {k: v.clone() for k, v in mixed.state_dict().items()}
+    h0 = torch.randn(E + N, D, generator=gen)
+    hin0 = h0 if tied else torch.randn(E + N, D, generator=gen)
+    w0 = torch.softmax(torch.randn(len(O.FIRST_OPS), generator=gen), 0)
+    gout = torch.randn(E + N, D, generator=gen).to(DEV)
+    res = {}
+    for mode in ("stored", "gate", "gate+row"):
+        K.GATED_RECOMPUTE, K.ROW_FACTOR = mode != "stored", mode == "gate+row"
+        mixed.load_state_dict(state0)
+        mixed.train(training)
+        mixed.zero_grad(set_to_none=True)
+        h = h0.clone().to(DEV).requires_grad_(True)
+        hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
+        w = w0.clone().to(DEV).requires_grad_(True)
+        out = mixed(w, g, h, hin)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res[mode] = ([out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in mixed.parameters()]
+                     + [b.clone() for b in mixed.buffers()])
+    nb = len(list(mixed.buffers()))
+    ok = all(torch.equal(a, b) for a, b in zip(res["gate"], res["stored"]))
+    ok = ok and torch.equal(res["gate+row"][0], res["stored"][0]) and all(torch.equal(a, b) for a, b in zip(res["gate+row"][-nb:], res["stored"][-nb:]))
+    worst = 0.0
+    for a, b in zip(res["gate+row"][1:-nb], res["stored"][1:-nb]):
+        scale = max(1e-3, float(b.abs().max())) if b.numel() else 1.0
+        worst = max(worst, float((a - b).abs().max()) / scale if b.numel() else 0.0)
+    ok = ok and worst <= 5e-5
+    print(f"case {case:3d} D={D:3d} N={N:3d} E={E:5d} b0={b0:5d} tied={int(tied)} train={int(training)}  {'ok' if ok else 'MISMATCH'}  row-factor gradient rel err {worst:.1e}", flush=True)
+    bad += not ok
+K.GATED_RECOMPUTE, K.ROW_FACTOR = True, True
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
