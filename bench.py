@@ -57,7 +57,7 @@ KERNEL_FAMILIES = {
     "span_sums [span_gcs_k]": ["mrg_span_gcs", "mrg_fused_gcs"],
     "scalar_gates [gate_row_fwd_k gate_row_bwd_k gate_fwd_k gate_bwd_k]": ["mrg_gate_collapse3", "mrg_gate_row_fwd", "mrg_gate_row_bwd", "mrg_gate_fwd", "mrg_gate_bwd",
                                                                            "mrg_gate_param_grad3"],
-    "gradient_fan_in [sum_k]": ["mrg_sum_buffers"],
+    "gradient_fan_in [sum_k sum_rows_gather_k]": ["mrg_sum_buffers", "mrg_sum_rows_gather"],
     "segment_reducers [seg_chunk_k seg_bwd_k]": ["mrg_seg_reduce_fwd", "mrg_seg_reduce_bwd", "mrg_seg_reduce_bwd_bits", "mrg_seg_reduce_heads_fwd"],
     "gathers [gather_compose_k distmult_k zero_colstats_k]": ["mrg_gather_compose_fwd", "mrg_distmult_score", "mrg_zero_stats_coef", "mrg_zero_colstats"],
     "cell_zero [zero_fwd_k zero_bwd_reduce_k zero_bwd_apply_k]": ["mrg_zero_fwd", "mrg_zero_bwd_reduce", "mrg_zero_bwd_apply"],

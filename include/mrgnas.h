@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -218,6 +218,12 @@ int mrg_span_gcs(int mode, const float *X, const float *Y, const void *meta, con
  *   out[i] = (accumulate ? out[i] : 0) + sum_k xs_host[k][i],  i < n,  1 <= K <= 8
  * xs_host: HOST array of K device pointers.  Order of summation k = 0..K-1. */
 int mrg_sum_buffers(const float *const *xs_host, int K, float *out, int64_t n, int accumulate, void *stream);
+/* out[r] = sum_k xs[k][r] + (r < E ? gather_edge[dst[r]] : gather_self[r - E]),  rows of D floats, 0 <= K <= 8.
+ * The fan-in of a state read by a_sum_op (reference models/operations_lp.py:252-264) among others: a_sum's gradient w.r.t. the
+ * [M, D] state is a gather of the [N, D] node gradient (edge rows: gather_edge = g * dropout mask, self rows: gather_self = g,
+ * NULL = zero), so it is read from that tensor instead of from a materialised [M, D] copy. */
+int mrg_sum_rows_gather(const float *const *xs_host, int K, const float *gather_edge, const float *gather_self,
+                        const int32_t *dst, int64_t E, int64_t rows, int D, float *out, void *stream);
 
 /* ---- DistMult scores (the step after the path) ---------------------------------------
  * Network.calc_score, reference models/model_search_lp.py:169-176:

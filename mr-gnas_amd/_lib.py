@@ -51,6 +51,7 @@ SIGNATURES = {
     "mrg_fused_gcs": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_span_gcs": (_I, [_I, _P, _P, _P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_sum_buffers": (_I, [_P, _I, _P, _L, _I, _P]),
+    "mrg_sum_rows_gather": (_I, [_P, _I, _P, _P, _P, _L, _L, _I, _P, _P]),
     "mrg_distmult_score": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "mrg_gate_row_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _P]),
     "mrg_gate_row_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P]),

@@ -50,9 +50,70 @@ static void launch_sum(const SumPack& xs, int K, float* out, int64_t n, bool vec
   }
 }
 
+// out[r] = sum_k xs[k][r] + (r < E ? gather_edge[dst[r]] : gather_self[r - E])      rows of D floats
+// The gradient fan-in of a state one of whose readers is a_sum (reference models/operations_lp.py:252-264: h = sum over the in-edges
+// of the message rows + the self row): that reader's gradient w.r.t. the [M, D] state is a GATHER of the [N, D] node gradient
+// (edge row e receives row dst[e], self row n receives row n), so it is read here from the cache-resident [N, D] tensor instead of
+// being written as an [M, D] tensor by a backward kernel and read back by the sum.
+template <int VEC, int LPR, int KMAX>
+__global__ __launch_bounds__(MRG_BLOCK) void sum_rows_gather_k(SumPack xs, int K, const float* __restrict__ gather_edge,
+                                                               const float* __restrict__ gather_self, const int32_t* __restrict__ dst,
+                                                               int64_t E, int64_t rows, int D, float* __restrict__ out) {
+  constexpr int RPB = MRG_BLOCK / LPR;
+  const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
+  const int dv = D / VEC;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const float* gb = r < E ? gather_edge + (int64_t)dst[r] * D : (gather_self ? gather_self + (r - E) * D : nullptr);
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+      const int c = sl + q * LPR;
+      if (c < dv) {
+        Vec<VEC> v[MRG_SUM_MAXK];
+#pragma unroll
+        for (int k = 0; k < MRG_SUM_MAXK; ++k) {
+          v[k] = Vec<VEC>::fill(0.f);
+          if (k < K) v[k] = Vec<VEC>::load(xs.p[k] + r * D + c * VEC);
+        }
+        Vec<VEC> a = gb ? Vec<VEC>::load(gb + c * VEC) : Vec<VEC>::fill(0.f);
+#pragma unroll
+        for (int k = 0; k < MRG_SUM_MAXK; ++k)
+          if (k < K) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += v[k][j];
+          }
+        a.store(out + r * D + c * VEC);
+      }
+    }
+  }
+}
+
 }  // namespace mrg
 
 using namespace mrg;
+
+extern "C" int mrg_sum_rows_gather(const float* const* xs_host, int K, const float* gather_edge, const float* gather_self, const int32_t* dst,
+                                   int64_t E, int64_t rows, int D, float* out, void* stream) {
+  if (K < 0 || K > MRG_SUM_MAXK || E < 0 || rows < E || D <= 0) return MRG_E_SHAPE;
+  if (rows == 0) return MRG_OK;
+  if (!out || (K > 0 && !xs_host) || (E > 0 && (!gather_edge || !dst))) return MRG_E_NULLPTR;
+  SumPack xs{};
+  bool al = aligned16(out) && aligned16(gather_edge) && aligned16(gather_self);
+  for (int k = 0; k < K; ++k) {
+    if (!xs_host[k]) return MRG_E_NULLPTR;
+    xs.p[k] = xs_host[k];
+    al = al && aligned16(xs_host[k]);
+  }
+  RowGeom g = row_geom(D, al);
+  if (!g.ok) return MRG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V, L, KM)                                                                                                  \
+  hipLaunchKernelGGL((sum_rows_gather_k<V, L, KM>), dim3(grid_for(rows, (MRG_BLOCK / L) * 4)), dim3(MRG_BLOCK), 0, st, xs, K, gather_edge, \
+                     gather_self, dst, E, rows, D, out)
+  MRG_DISPATCH_GEOM(g, CALL);
+#undef CALL
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
 
 // out[i] = (accumulate ? out[i] : 0) + sum_k xs_host[k][i],  i < n;  1 <= K <= 8 device buffers whose
 // pointers are given in a HOST array.  Summation order is k = 0..K-1 (deterministic).

@@ -351,6 +351,9 @@ class _AggRows(torch.autograd.Function):
         ctx.mode, ctx.graph, ctx.add_self = mode, graph, add_self
         ctx.save_for_backward(*[t for t in (arg, keep) if t is not None])
         ctx.has = (arg is not None, keep is not None)
+        # x is an alias handed out by a Fan: a_sum's gradient w.r.t. it is a gather of the [N, D] node gradient, which the fan-in
+        # sum can read itself (mrg_sum_rows_gather) instead of receiving an [M, D] copy
+        ctx.fan_node = getattr(x, "_mrg_fan_node", None) if (LAZY_ASUM and mode == 0 and x.is_cuda) else None
         return out
 
     @staticmethod
@@ -361,14 +364,21 @@ class _AggRows(torch.autograd.Function):
         arg = saved.pop(0) if ctx.has[0] else None
         keep = saved.pop(0) if ctx.has[1] else None
         E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
-        gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
         gh = g * keep if keep is not None else g
+        node = ctx.fan_node
+        if node is not None and ctx.mode == 0 and getattr(node, "gathered", None) is None:
+            node.gathered = (gh, g if ctx.add_self else None, graph)          # one gathered term per fan; further ones are materialised
+            return None, None, None, None, None
+        gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
         if ctx.add_self:
             gx[E:] = g
         else:
             gx[E:].zero_()
         _seg_bwd(ctx.mode, gh, graph, arg, gx, None)
         return None, gx, None, None, None
+
+
+LAZY_ASUM = os.environ.get("MRG_LAZY_ASUM", "1") == "1"     # lab switch: 0 = a_sum's [M, D] input gradient is materialised for the fan-in sum
 
 
 def aggregate_rows(kind, x, graph, add_self=True, keep=None):
@@ -1894,6 +1904,24 @@ class _Fanout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         gs = [g for g in grads if g is not None]
+        gathered = getattr(ctx, "gathered", None)
+        if gathered is not None:                            # a reader (a_sum) left its gradient as a gather of an [N, D] tensor
+            gh, gself, graph = gathered
+            ctx.gathered = None
+            E, N, D = graph.num_edges(), graph.number_of_nodes(), gh.shape[1]
+            if len(gs) <= 8 and all(g.is_cuda and g.shape == (E + N, D) for g in gs):
+                gs = [f32c(g) for g in gs]
+                out = torch.empty(E + N, D, dtype=torch.float32, device=gh.device)
+                call("mrg_sum_rows_gather", (ptr_array(gs), len(gs), ptr(f32c(gh)), ptr(f32c(gself)), ptr(graph.i32("dst")), E, E + N, D, ptr(out),
+                                             stream_of(out)), nbytes=4 * D * (E + N) * (len(gs) + 1))
+                return out, None
+            gx = torch.empty(E + N, D, dtype=torch.float32, device=gh.device)      # shapes the kernel does not take: materialise
+            if gself is not None:
+                gx[E:] = gself
+            else:
+                gx[E:].zero_()
+            _seg_bwd(0, gh, graph, None, gx, None)
+            gs.append(gx)
         if not gs:
             return None, None
         if len(gs) == 1:
@@ -1931,4 +1959,6 @@ class Fan:
             views = list(_Fanout.apply(self._root, self.BATCH))
             self._root = views.pop()                    # source of the next batch, if one is ever needed
             self._views = views
-        return self._views.pop()
+        v = self._views.pop()
+        v._mrg_fan_node = v.grad_fn                     # lets a reader leave its gradient with the fan-in sum (_AggRows.backward)
+        return v

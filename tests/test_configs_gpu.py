@@ -471,7 +471,7 @@ def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
         z = (y64[lo:lo + (1 << 21)].double() - mean) / torch.sqrt(var + bns[k].eps) * bns[k].weight.double() + bns[k].bias.double()
         t = gup[lo:lo + (1 << 21)].double() * torch.relu(z)
         dw += float(t.detach().sum())
-        dw_abs += float(t.abs().sum())
+        dw_abs += float(t.detach().abs().sum())
     assert abs(float(w.grad[k]) - dw) <= 1e-5 * dw_abs                 # a sum of 2.8e9 random-sign terms
     del out, gup, ys, xs
     free()

@@ -363,6 +363,43 @@ def test_weight_gradient_split_once_is_bit_exact_with_split_per_wave(rows, K1, K
     assert float((res[1][0].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,E,D,K_,self_rows", [(300, 5000, 200, 3, True), (50, 0, 64, 2, True), (1000, 70000, 100, 0, True), (200, 3000, 52, 8, False),
+                                              (77, 900, 260, 1, True)])
+def test_fan_in_sum_with_a_gathered_term(N, E, D, K_, self_rows):
+    """mrg_sum_rows_gather: sum of K [M, D] tensors plus a gather of [N, D] rows (edge row e <- dst[e], self row n <- n) against
+    torch; then a_sum's input gradient left to the fan-in sum (functional.LAZY_ASUM) against the materialised form through a Fan."""
+    from mr_gnas_amd._lib import call, ptr, ptr_array, stream_of
+    gen = torch.Generator().manual_seed(N + E + D + K_)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    xs = [torch.randn(E + N, D, generator=gen).to(DEV) for _ in range(K_)]
+    ge, gs_ = torch.randn(N, D, generator=gen).to(DEV), torch.randn(N, D, generator=gen).to(DEV)
+    out = torch.full((E + N, D), 7.0, device=DEV)
+    call("mrg_sum_rows_gather", (ptr_array(xs), K_, ptr(ge), ptr(gs_) if self_rows else None, ptr(dst.to(DEV).int()), E, E + N, D, ptr(out), stream_of(out)))
+    ref = torch.cat((ge[dst.to(DEV)], gs_ if self_rows else torch.zeros(N, D, device=DEV)))
+    for x in xs:
+        ref = ref + x
+    close(out, ref.cpu(), "sum with a gathered term", rtol=1e-6, atol=1e-6)
+    if E == 0 or D > 256:
+        return
+    g = G.RelGraph(N, torch.randint(0, N, (E,), generator=gen).numpy(), dst.numpy(), torch.randint(0, 4, (E,), generator=gen).numpy(),
+                   (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    x0 = torch.randn(E + N, D, generator=gen)
+    gout = torch.randn(N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for lazy in (True, False):
+            K.LAZY_ASUM = lazy
+            x = x0.clone().to(DEV).requires_grad_(True)
+            fan = K.Fan(x, 3)
+            y = K.aggregate_rows("sum", fan.take(), g) + K.aggregate_rows("mean", fan.take(), g)
+            (y * gout).sum().backward()
+            res[lazy] = x.grad.clone()
+    finally:
+        K.LAZY_ASUM = True
+    close(res[True], res[False].cpu(), "a_sum gradient through the fan-in gather", rtol=2e-6, atol=2e-6)
+
+
 def test_compose_broadcast_relation_row():
     """Advisor r1: the reference's pre-ops broadcast (`src_emb - hr` with hr [1, D]); the gradient of a
     broadcast hr must come back in hr's own shape."""

@@ -63,6 +63,7 @@ ENTRY_KERNELS.update({
     "mrg_linear_bwd_weight3": ["wgrad_x3v_k@max", "wgrad_reduce3_k"],
     "mrg_gate_row_fwd": ["gate_row_fwd_k"],
     "mrg_gate_row_bwd": ["gate_row_bwd_k"],
+    "mrg_sum_rows_gather": ["sum_rows_gather_k"],
 })
 NORTH_STAR = "span_gcs_k<4, 64, 1, 0,"            # MODE = SUB only runs in bench.py's north-star passes (last parameter: prefetch-depth override)
 
