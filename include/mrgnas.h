@@ -378,7 +378,7 @@ int mrg_gemm_set_mode(int mode);
 int mrg_gemm_set_epilogue(int row_order);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
- * (wgrad_x3_k, rounds 1-2).  Same products in the same order: bit-identical gradients. */
+ * (wgrad_x3_k, rounds 1-2).  Same operands and products in the same order: bit-identical gradients for any shape. */
 int mrg_wgrad_set_variant(int variant);
 int mrg_linear_fwd(const float *X, const float *W, const float *bias, float *Y, void *ws,
                    int64_t rows, int K, int Nout, int act, void *stream);

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
 // and half wave), one split, three ds_write_b128 (bf16 planes, lane-contiguous: conflict free); the consumers read three
 // ds_read_b128 per fragment.  Per workgroup and tile: 15 splits instead of 48 (TM = 7, KT = 8).  Two LDS buffers, one barrier per
 // tile; the loads of tile t + 2 are issued before the barrier of tile t and consumed (split) during the MFMAs of tile t + 1.
-// Same products, same accumulation order per output element as wgrad_x3_k: bit-identical partial tiles.
+// Same operands, same products, same accumulation order per output element as wgrad_x3_k: bit-identical partial tiles.
 template <int NG>
 __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
   constexpr int KP = 8 / NG, KT = 2 * KP;
@@ -543,13 +543,16 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
   }
   constexpr unsigned BUF_BYTES = FPW * 8 * 3 * 1024;
 
-  // Tiles of 16 rows; a ragged last tile is the 16 rows ENDING at r_end (the host guarantees r_end >= 16: in-bounds loads without
-  // a mask), the rows it shares with the tile before are zeroed when it is split.
-  const int64_t ntiles = (r_end - r_begin + WBR - 1) / WBR;
-  auto tile_start = [&](int64_t t) { return t + 1 < ntiles ? r_begin + t * WBR : (r_end - WBR < r_begin + (ntiles - 1) * WBR ? r_end - WBR : r_begin + (ntiles - 1) * WBR); };
+  // Full 16-row tiles run through the pipelined loop with plain loads; a ragged last tile (nv < 16 rows) is one extra, unpipelined
+  // trip: its k positions >= nv are loaded from the rows 16 ABOVE their own (inside the tensor: the host guarantees r_end >= 16) and
+  // zeroed at the split -- in-bounds loads without masks, and exactly the operand wgrad_x3_k builds (valid rows first, zeros after):
+  // bit-identical with it for any row count.
+  const int64_t nfull = (r_end - r_begin) / WBR;
+  const int nv_tail = (int)((r_end - r_begin) - nfull * WBR);
+  const int kbase = 8 * lh;
   float raw[FPW][8];
-  auto fetch = [&](int64_t t) {                            // t clamped by the caller: always a real tile
-    const int64_t toff = tile_start(t) - r_begin;
+  auto fetch = [&](int64_t t) {                            // a FULL tile (t clamped by the caller)
+    const int64_t toff = t * WBR;
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const float* p = src[i] + toff * ld[i];
@@ -557,19 +560,14 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
       for (int j = 0; j < 8; ++j) raw[i][j] = p[j * ld[i]];
     }
   };
-  auto produce = [&](int buf, int64_t t) {
-    const int64_t ts = tile_start(t), vstart = r_begin + t * WBR;     // rows below vstart belong to the previous tile
+  auto produce = [&](int buf, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       if (live[i]) {                                        // wave-uniform
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = raw[i][j];
-        if (ts < vstart) {                                  // workgroup-uniform: the ragged last tile only
-          const int first = (int)(vstart - ts) - 8 * lh;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = j >= first ? x[j] : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) x[j] = (!TAIL || kbase + j < nv_tail) ? raw[i][j] : 0.f;
         u32x4 H, M, L;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -587,57 +585,72 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
     const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(smem) + buf * BUF_BYTES + f * 3072) + lane;
     H = __builtin_bit_cast(bf16x8, p[0]); M = __builtin_bit_cast(bf16x8, p[64]); L = __builtin_bit_cast(bf16x8, p[128]);
   };
-
-  if (ntiles > 0) {
-    fetch(0);
-    produce(0, 0);
-    fetch(ntiles > 1 ? 1 : 0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t t = 0; t < ntiles; ++t) {
-      if (an > 0 && kn > 0) {
-        bf16x8 Bh0, Bm0, Bl0, Bh1, Bm1, Bl1;
-        rdfrag(cur, ASLOTS + 2 * wp, Bh0, Bm0, Bl0);
-        if (kn > 1) rdfrag(cur, ASLOTS + 2 * wp + 1, Bh1, Bm1, Bl1);
-        else { Bh1 = Bh0; Bm1 = Bm0; Bl1 = Bl0; }
-        bf16x8 An[3];                                      // the NEXT row tile's planes: read while this one's MFMAs run
-        rdfrag(cur, m0, An[0], An[1], An[2]);
+  auto consume = [&](int cur) {
+    if (an > 0 && kn > 0) {
+      bf16x8 Bh0, Bm0, Bl0, Bh1, Bm1, Bl1;
+      rdfrag(cur, ASLOTS + 2 * wp, Bh0, Bm0, Bl0);
+      if (kn > 1) rdfrag(cur, ASLOTS + 2 * wp + 1, Bh1, Bm1, Bl1);
+      else { Bh1 = Bh0; Bm1 = Bm0; Bl1 = Bl0; }
+      bf16x8 An[3];                                        // the NEXT row tile's planes: read while this one's MFMAs run
+      rdfrag(cur, m0, An[0], An[1], An[2]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < an) {
-            const bf16x8 Ah = An[0], Am = An[1], Al = An[2];
-            if (i + 1 < an) rdfrag(cur, m0 + i + 1, An[0], An[1], An[2]);
-            if (kn > 1) {                                  // two accumulators interleaved: no back-to-back dependent MFMAs
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[i][1], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[i][1], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[i][1], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[i][1], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[i][1], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[i][1], 0, 0, 0);
-            } else {
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
-              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
-            }
+      for (int i = 0; i < 4; ++i) {
+        if (i < an) {
+          const bf16x8 Ah = An[0], Am = An[1], Al = An[2];
+          if (i + 1 < an) rdfrag(cur, m0 + i + 1, An[0], An[1], An[2]);
+          if (kn > 1) {                                    // two accumulators interleaved: no back-to-back dependent MFMAs
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[i][1], 0, 0, 0);
+          } else {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[i][0], 0, 0, 0);
           }
         }
       }
+    }
+  };
+
+  if (nfull > 0) {
+    fetch(0);
+    produce(0, std::false_type{});
+    fetch(nfull > 1 ? 1 : 0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t = 0; t < nfull; ++t) {
+      consume(cur);
       // tile t + 1 (its loads were issued one tile ago) is split under this tile's MFMAs; then the loads of tile t + 2 (clamped:
-      // past the end the last tile is simply loaded again and never used)
-      if (t + 1 < ntiles) produce(cur ^ 1, t + 1);
-      fetch(t + 2 < ntiles ? t + 2 : ntiles - 1);
+      // past the end the last full tile is simply loaded again and never used)
+      if (t + 1 < nfull) produce(cur ^ 1, std::false_type{});
+      fetch(t + 2 < nfull ? t + 2 : nfull - 1);
       __syncthreads();
       cur ^= 1;
     }
+  }
+  if (nv_tail > 0) {                                       // every wave is past the loop's last barrier: both buffers are free
+    const int64_t toff = nfull * WBR;
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      const float* p = src[i] + toff * ld[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[i][j] = p[(int64_t)(kbase + j >= nv_tail ? j - WBR : j) * ld[i]];
+    }
+    produce(0, std::true_type{});
+    __syncthreads();
+    consume(0);
   }
   const int ldw = a.TN * 32;
   float* out = a.ws + ws_off + (int64_t)blockIdx.x * (a.TM * 32) * ldw;

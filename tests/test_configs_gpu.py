@@ -481,7 +481,7 @@ def test_c5_mixed_epilogue_sum_and_dense_filter(c5):
     o = K.dense_filter_single(s, s_in, W, b)
     cat = torch.cat((s.detach()[rows], s_in.detach()[rows]), 1).double()
     gate = torch.sigmoid(cat @ W.detach().double().t() + b.detach().double())
-    assert float((o[rows].double() - gate * s.detach()[rows].double()).abs().max()) <= 1e-4
+    assert float((o.detach()[rows].double() - gate.detach() * s.detach()[rows].double()).abs().max()) <= 1e-4
     go = rnd(M, D)
     o.backward(go)
     dz = go[rows].double() * s.detach()[rows].double() * gate * (1 - gate)
