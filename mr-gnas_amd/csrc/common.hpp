@@ -56,13 +56,6 @@ template <> struct IVec<1> {
   __device__ __forceinline__ int operator[](int) const { return v; }
 };
 
-// Sum over the LPR consecutive lanes that share one row (LPR = 16, 32 or 64).
-template <int LPR>
-__device__ __forceinline__ float group_sum(float x) {
-#pragma unroll
-  for (int off = LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, MRG_WAVE);
-  return x;
-}
 
 // Which of the block's row groups a thread belongs to.  With LPR == 64 a row group is a wave: the index is wave-uniform, and saying
 // so (readfirstlane) turns every `base + r * D` of the kernel into scalar arithmetic and every row access into the
@@ -76,8 +69,8 @@ __device__ __forceinline__ int row_group_of_thread() {
 
 // Sum over the 64 lanes of a wave, in every lane, without the LDS crossbar: four DPP steps inside each 16-lane row (quad
 // permutes, half-row mirror, row mirror -- VALU latency, no ds_bpermute round trip), then the four row sums through scalar
-// registers.  group_sum<64> is a chain of six dependent ds_bpermute (~100 cycles each), which a kernel with two or three waves
-// per SIMD cannot hide.  Association differs from group_sum's butterfly (float32 rounding only).
+// registers.  The xor butterfly over 64 lanes is a chain of six dependent ds_bpermute (~100 cycles each), which a kernel with two or
+// three waves per SIMD cannot hide.
 __device__ __forceinline__ float wave_sum_dpp(float x) {
   float t = x;
   t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
@@ -88,6 +81,19 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
   const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 16));
   const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 48));
   return (r0 + r1) + (r2 + r3);
+}
+
+// Sum over the LPR consecutive lanes that share one row (LPR = 16, 32 or 64), in every lane of the group.  A whole wave (LPR = 64)
+// takes the DPP form above; 16 / 32 lanes use the xor butterfly.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+  if constexpr (LPR == 64) {
+    return wave_sum_dpp(x);
+  } else {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, MRG_WAVE);
+    return x;
+  }
 }
 
 __device__ __forceinline__ float sigmoidf_fast(float z) { return 1.0f / (1.0f + __expf(-z)); }

@@ -551,9 +551,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       }
       float dzr = 0.f;
       if (hasr) {                                          // all lanes of the row (inactive ones carry 0): KMAX == 1 (host-checked)
-        float qr;
-        if constexpr (LPR == 64) qr = wave_sum_dpp(dq);     // one row per wave: no LDS round trips between the arithmetic and the stores
-        else qr = group_sum<LPR>(dq);
+        const float qr = group_sum<LPR>(dq);                // (one row per wave: DPP + scalar registers, no LDS round trips)
         dzr = qr * rhv;                                    // (used by the active lanes only, which loaded rhv)
         if (sl == 0) gp.rdq[r] = qr;
       }
