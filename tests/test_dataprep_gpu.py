@@ -206,7 +206,7 @@ def test_score_functions_full_size_against_float64():
         else:
             ref = torch.sigmoid(gamma - torch.cdist(s64 + r64, e64, p=1))
         ref.backward(gup.double())
-        assert float((out.detach().double() - ref).abs().max()) <= 1e-4, nm
+        assert float((out.detach().double() - ref.detach()).abs().max()) <= 1e-4, nm
         for got, want, what in ((e.grad, e64.grad, "ent"), (s.grad, s64.grad, "sub"), (r.grad, r64.grad, "rel")):
             err = float((got.double() - want).abs().max())
             assert err <= 2e-4 * max(1.0, float(want.abs().max())), f"{nm} grad {what}: {err:.3e}"
