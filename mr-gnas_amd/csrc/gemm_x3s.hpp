@@ -30,8 +30,24 @@
 #ifndef MRG_X3S_STAGGER
 #define MRG_X3S_STAGGER 0
 #endif
+// 1 (default): the weight fragments of a slab's FIRST column-tile pair are read during the previous slab's LAST pair -- the
+// barrier that publishes slab s + 1 stands in front of slab s's last pair instead of behind it -- so that the LDS round trip and
+// the barrier's skew no longer open every slab (round 4; 0 = round 3's schedule).  Needs an even number of tile pairs per slab.
+#ifndef MRG_X3S_PIPE
+#define MRG_X3S_PIPE 1
+#endif
 
 namespace mrg {
+
+// lab switch 16: per-wave phase stamps (shader clock, s_memtime) -> mrg_x3s_trace[wave slot * 24 + i]:
+// 0 start, 1 first slab, 2 + s = end of slab s (s < 16), 18 k-loop done, 19 stores issued, 20 stores landed, 21 HW_ID | XCC_ID << 32,
+// 22 / 23 the 100 MHz clock at the end / start
+#if MRG_X3S_DBG & 16
+__device__ unsigned long long* mrg_x3s_trace;
+#define MRG_X3S_STAMP(i) do { if (lane == 0) mrg_x3s_trace[trace_slot * 24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MRG_X3S_STAMP(i) do { } while (0)
+#endif
 
 template <int NT, int EPI, bool DUAL>
 __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
@@ -66,6 +82,11 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     for (int i = 0; i < MRG_X3S_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
+  [[maybe_unused]] const int64_t trace_slot = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+  MRG_X3S_STAMP(0);
+#if MRG_X3S_DBG & 16
+  if (lane == 0) mrg_x3s_trace[trace_slot * 24 + 23] = __builtin_amdgcn_s_memrealtime();
+#endif
   f32x16 acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -123,7 +144,26 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     H[q] = h; M[q] = m; L[q] = l;
   };
   auto nb_issued = [&](int j) { return (j >= -2 && j + 2 < nslab) ? NBW : 0; };   // B DMAs issued at the top of slab j (j < 0: prologue)
+  constexpr int NP = (NT + 1) / 2;                          // column-tile pairs per slab
+  constexpr bool PIPE = MRG_X3S_PIPE && (NP % 2 == 0);      // the pair buffers alternate across slabs: their parity must not depend on s
+  auto nbw = [&](int j) { return (j >= 1 && j < nslab) ? NBW : 0; };              // PIPE: DMAs of B(j) that stand BEHIND older A loads (B(0) leads)
 
+  if constexpr (PIPE) {
+    // issue order of a wave:  A(0) B(0) A(1) A(2) B(1) | A(3) B(2) | A(4) B(3) | ...   (slab s issues A(s+3) at its top and
+    // B(s+2) behind the barrier in front of its last pair)
+    load_a(0, xr[0]);
+    fetch_b(0, 0);
+    load_a(1, xr[1]);
+    load_a(2, xr[2]);
+    if (nslab > 1) fetch_b(1, 1);
+    wait_vmcnt(4 + nbw(1));                                  // A(0) and this wave's share of B(0) have landed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair_of(xr[0], q, ch, cm, cl);
+    __builtin_amdgcn_s_barrier();                            // everybody's share of B(0) is in LDS
+    read_b(0, 0, bq2[0][0]);                                 // slab 0's first pair
+    if (NT > 1) read_b(1, 0, bq2[0][1]);
+  } else {
   // ---- prologue, in the steady state's issue order: A(0) | B(0) A(1) | B(1) A(2)
   load_a(0, xr[0]);
   fetch_b(0, 0);
@@ -135,6 +175,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
 #pragma unroll
   for (int q = 0; q < 4; ++q) split_pair_of(xr[0], q, ch, cm, cl);
   __builtin_amdgcn_s_barrier();                              // everybody's share of B(0) is in LDS
+  }
+  MRG_X3S_STAMP(1);
 
   // One k-slab; R = s % 3 at compile time (ring positions of the raw fragments and of the B buffers).
   // In-order vector-memory history of a wave at the top of slab s:  ... A(s+1) | B(s+1) A(s+2)      (B(s) in LDS: barrier)
@@ -145,23 +187,44 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   auto slab = [&](auto r_c, int s) {
     constexpr int R = decltype(r_c)::value;
     const bool has_next = s + 1 < nslab;
-    if (s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
+    if (!PIPE && s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
     if (!(MRG_X3S_DBG & 2)) load_a(s + 3, xr[R]);
     // Column tiles in PAIRS: the twelve MFMAs of a pair alternate between its two accumulators (a dependent MFMA issued back to
     // back waits for its predecessor's result; with another accumulator's MFMA in between the pipe stays busy) and the VALU
     // instructions of the A split are spread between them (sched_group_barrier: 1 MFMA, then up to 3 VALU) instead of
     // standing in front of the MFMAs.  Each accumulator still receives its six terms in the same order: bit-identical results.
-    constexpr int NP = (NT + 1) / 2;
     constexpr int SPP = (4 + NP - 1) / NP;                    // split pairs handled in the shadow of one tile pair
+    if constexpr (PIPE) {
+      // A(s+1) is split during this slab; younger than it: B(s) [unless s == 0: B(0) leads the prologue] A(s+2) B(s+1) A(s+3)
+      if (has_next) wait_vmcnt(nbw(s) + 2 + nbw(s + 1) + 2);
+    } else {
     read_b(0, R, bq2[0][0]);
     if (NT > 1) read_b(1, R, bq2[0][1]);
     if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
     if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
       constexpr int dummy = 0; (void)dummy;
       const int n0 = 2 * pp, n1 = 2 * pp + 1;
-      if (pp + 1 < NP) {
+      if (PIPE && pp + 1 == NP) {
+        // in front of the last pair: publish slab s + 1, start the DMA of slab s + 2 into the buffer slab s - 1 was read from
+        // (every wave is past that slab), and read slab s + 1's first pair
+        if (has_next) {
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // this wave's share of B(s+1): only A(s+3) is younger
+          if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();
+          if (s + 2 < nslab) fetch_b(s + 2, (R + 2) % 3);
+          read_b(0, (R + 1) % 3, bq2[(pp + 1) & 1][0]);
+          if (NT > 1) {
+            read_b(1, (R + 1) % 3, bq2[(pp + 1) & 1][1]);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+          }
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      } else if (pp + 1 < NP) {
         read_b(n0 + 2, R, bq2[(pp + 1) & 1][0]);
         if (n1 + 2 < NT) {
           read_b(n1 + 2, R, bq2[(pp + 1) & 1][1]);
@@ -217,10 +280,13 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     }
     if (has_next) {
       ch = nh; cm = nm; cl = nl;
+      if constexpr (!PIPE) {
       if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2);                       // this wave's share of B(s+1) is in LDS
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();   // ... and everybody's; all reads of this slab's buffer are done
+      }
     }
+    if (s < 16) MRG_X3S_STAMP(2 + s);
   };
   int s = 0;
   for (; s + 2 < nslab; s += 3) {
@@ -233,10 +299,21 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's unused A fills: their registers must stay until they land
   asm volatile("" :: "v"(xr[0][0]), "v"(xr[0][1]), "v"(xr[1][0]), "v"(xr[1][1]), "v"(xr[2][0]), "v"(xr[2][1]));
 
+  MRG_X3S_STAMP(18);
   if ((MRG_X3S_DBG & 1) && acc[0][0] != 123.456f) return;
   if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc, roww, col0, li, lh);
   else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc, roww, col0, li, lh);
   else gemm_epilogue<NT, EPI>(a, acc, roww, col0, li, lh, row0 + GBM <= a.rows);
+#if MRG_X3S_DBG & 16
+  MRG_X3S_STAMP(19);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MRG_X3S_STAMP(20);
+  if (lane == 0) {
+    mrg_x3s_trace[trace_slot * 24 + 21] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))            // HW_REG_HW_ID
+                                        | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_XCC_ID
+    mrg_x3s_trace[trace_slot * 24 + 22] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 inline bool x3s_eligible(const GemmArgs& a) { return x3_eligible(a) && a.rows > 0; }
