@@ -43,6 +43,7 @@ MFMA_BOUND = {"mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_weight",
 # benchmark shapes (11.6 MB entity table, 0.4 MB relation table): pricing those bytes against HBM gave "fractions"
 # above 1 in round 1.  They are priced against the L2 ceiling and carry their compulsory HBM bytes separately.
 L2_BOUND = {"mrg_distmult_score", "mrg_gather_compose_fwd", "mrg_zero_stats_coef", "mrg_zero_colstats"}
+VALU_F32_PEAK_TFS = 157.3  # f32 vector peak (same guide): the O(D^2)-per-edge circular correlation of mrg_fused_gcs is priced against it
 HBM_ACHIEVABLE_GBS = 6290.0   # the guide's measured float4 copy rate: what an HBM-bound kernel can be read against
 # Entry points grouped by the DEVICE kernel that does their work (rocprofv3 kernel names in brackets): the GEMMs are spread over
 # eight entry-point names, so "the entry point with the largest time" (rounds 1-2) named the wrong kernel.  `roofline` is the
@@ -100,7 +101,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fb15k237_supernet_full",
                     choices=["fb15k237_supernet_full", "fb15k237_supernet_30k", "fb15k237_supernet_300", "wn18rr_supernet_full",
-                             "fb15k237_fixed_d64", "c5_fixed_cell"])
+                             "fb15k237_fixed_d64", "c5_fixed_cell", "compgcn_fb15k237"])
+    ap.add_argument("--caller", default="fused", choices=["fused", "reference"],
+                    help="'reference': the MixedOp / cell written as the reference's models/cell_lp.py:25-33 (one operator call, "
+                         "nn.BatchNorm1d, ReLU and a scaled add per candidate; gathers materialised as models/model_search_lp.py:144-145) "
+                         "on this package's operators -- what the UNCHANGED reference caller gets from the operator swap alone")
+    ap.add_argument("--comp-fn", default="sub", choices=["sub", "mul", "ccorr"], help="compgcn_fb15k237: the layer's composition")
+    ap.add_argument("--no-caller-leg", action="store_true", help="skip the extra timed steps with the reference's literal caller")
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--negative", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,6 +241,38 @@ class FixedStep:
         self.last_loss = loss.detach()
 
 
+class CompGCNStep:
+    """A 2-layer CompGCN forward + backward on the FB15k-237-shaped graph (reference models/compgcn.py:116-185: basis-decomposed
+    relation table, CompGraphConv x 2 with BatchNorm, tanh and dropout; no driver of the reference reaches it, so the step is
+    the module itself: forward, a squared-norm loss on both outputs, backward, Adam)."""
+
+    def __init__(self, args, device):
+        from mr_gnas_amd import compgcn as C, graph as G, synth
+        N, R, T = synth.SHAPES["fb15k237"]
+        tri = synth.synth_kg(N, R, T, args.seed)
+        torch.manual_seed(args.seed)
+        g = G.build_train_graph(N, R, tri, device=device)               # un-sorted halves: first half original, second half inverse
+        self.E = g.num_edges()
+        b0, _ = g.bounds()
+        in_mask = torch.arange(self.E, device=device) < b0
+        g.edata.update(etype=g.edata["e_type"], norm=g.edata["norm"].view(-1), in_edges_mask=in_mask, out_edges_mask=~in_mask)
+        self.g = g
+        self.model = C.CompGCN(100, 2 * R, N, in_dim=args.dim, layer_size=[args.dim, args.dim], comp_fn=args.comp_fn, batchnorm=True,
+                               dropout=0.1, layer_dropout=[0.3, 0.3]).to(device)
+        self.model.train()
+        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3)
+        self.samples = torch.empty(0, 3)
+        self.last_loss = None
+
+    def __call__(self):
+        n, r = self.model(self.g)
+        loss = n.square().mean() + r.square().mean()
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        self.last_loss = loss.detach()
+
+
 def kernel_table(stats):
     rows = {}
     for name, r in stats.items():
@@ -358,6 +397,35 @@ def load_traffic(kernel):
     return best
 
 
+def traffic_source(kernel):
+    """Which committed counter pass `load_traffic(kernel)` read (the PMC passes need rocprofv3 around the process: they are
+    collected by tools/profile_r3.sh, not inside this run)."""
+    import glob
+    src = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            with open(path) as f:
+                if kernel in json.load(f).get("per_launch_bytes", {}):
+                    src = os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None if src is None else f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
+
+
+def cpu_full_graph_record():
+    """One full-graph CPU-oracle step recorded on a GPU box's host (tools/cpu_full_graph.py -> profiles/*cpu_full_graph*.json)."""
+    import glob
+    rec = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_full_graph*.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            rec["source"] = os.path.relpath(path, ROOT) + " (recorded once; the default run stays within minutes)"
+        except Exception:
+            pass
+    return rec
+
+
 def cpu_baseline(args, state, alphas):
     """The CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores
     on a bounded sample: one supernet step on a `--cpu-sample`-triple sampled step graph."""
@@ -398,7 +466,8 @@ def cpu_baseline(args, state, alphas):
             "sample": f"median of {max(len(times), 1)} supernet fwd+bwd steps after 1 warm-up, sampled step graph "
                       f"graph_batch_size={args.cpu_sample} (E={E}, n={og.n}), D={args.dim}, torch {torch.__version__} CPU, "
                       f"{dt:.2f} s/step (the full {args.workload} graph needs ~4 min and 64 GB per step on CPU)",
-            "seconds_per_step": round(dt, 3), "steps_timed": [round(t, 3) for t in times]}
+            "seconds_per_step": round(dt, 3), "steps_timed": [round(t, 3) for t in times],
+            "full_graph": cpu_full_graph_record()}
 
 
 def log(msg):
@@ -425,6 +494,8 @@ def main():
     if lib.mrg_gemm_set_mode(MATRIX_CORE["mode"]) != 0:
         raise SystemExit("mrg_gemm_set_mode failed")
 
+    from mr_gnas_amd import cell_lp as CL
+    CL.CALLER = args.caller
     sharded = world > 1 or os.environ.get("MRG_FORCE_SHARDED") == "1"     # the env switch rehearses the N>1 code on one GPU
     if args.hip_graph:
         # a captured step runs on ONE stream: capturing the candidate / segment side streams of the full-size step
@@ -457,6 +528,9 @@ def main():
     elif args.workload == "c5_fixed_cell":
         args.dim = 256
         step = FixedStep(args, device, shape="synthetic10m", dim=256, init_dim=64, nbase=64)
+        barrier = lambda: None
+    elif args.workload == "compgcn_fb15k237":
+        step = CompGCNStep(args, device)
         barrier = lambda: None
     else:
         step = Step(args, device, build_step_inputs(args.workload, args.negative, args.seed))
@@ -549,6 +623,8 @@ def main():
                                    "(error vs float64 pinned <= 1.5x the exact-f32 core in tests)"),
                    "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL",
                    "launch": "hip graph replay" if args.hip_graph else "eager",
+                   "caller": ("cell_lp.MixedOp on the fused HIP epilogue (this package's cell_lp.py / supernet.py)" if args.caller == "fused" else
+                              "the reference's literal MixedOp formulation (models/cell_lp.py:25-33) on this package's operators"),
                    "step_graph": ("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
                                   "inside the timed region)" if args.resample else "resident, built before timing")},
         "loss": float(step.last_loss) if step.last_loss is not None else None,
@@ -559,7 +635,8 @@ def main():
         f = families[dom_family]
         big = max(f["entry_points"], key=lambda n: table[n]["ms_total"] if n in table else 0.0)
         out["roofline"] = {"kernel": dom_family, "bound": f["bound"], "achieved": f["achieved"], "peak": f["peak"], "unit": f["unit"],
-                           "frac": f["frac"], "traffic": load_traffic(big), "traffic_entry_point": big, "launches": f["launches"],
+                           "frac": f["frac"], "traffic": load_traffic(big), "traffic_entry_point": big,
+                           "traffic_source": traffic_source(big), "launches": f["launches"],
                            "us_per_launch": round(f["ms_total"] * 1e3 / f["launches"], 2), "ms_per_step": f["ms_total"],
                            "entry_points": f["entry_points"],
                            "timed_in": "the instrumented single-stream step before the timed steps (HIP events on the launch stream)",
@@ -580,8 +657,21 @@ def main():
         out["hbm_bound_total"] = {"ms_per_step": round(tot_ms, 3), "achieved": round(tot_b / tot_ms, 1), "unit": "GB/s",
                                   "frac": round(tot_b / tot_ms / HBM_PEAK_GBS, 4), "frac_achievable": round(tot_b / tot_ms / HBM_ACHIEVABLE_GBS, 4)}
     out["kernels"] = table
-    fixed = args.workload in ("fb15k237_fixed_d64", "c5_fixed_cell")
-    if fixed:
+    fixed = args.workload in ("fb15k237_fixed_d64", "c5_fixed_cell", "compgcn_fb15k237")
+    if args.workload == "compgcn_fb15k237":
+        out["metric"] = f"million edges/sec per 2-layer CompGCN fwd+bwd step (FB15k-237 shape, dim={args.dim}, comp_fn={args.comp_fn})"
+        out["config"]["step"] = "CompGCN(num_bases=100, layers [D, D], BatchNorm, tanh, dropout) fwd + squared-norm loss + bwd + Adam"
+        out["config"]["comp_fn"] = args.comp_fn
+        if "mrg_fused_gcs" in table:              # ccorr: D multiply-adds per output element and edge on the vector pipe
+            r = raw_stats["mrg_fused_gcs"]
+            flops = 2.0 * args.dim * args.dim * step.E * r["launches"] / max(1, r["launches"])
+            sec = r["ms"] / 1e3 / r["launches"]
+            out["ccorr_kernel"] = {"kernel": "mrg_fused_gcs [gcs_corr_k]", "bound": "valu", "flop_per_launch": flops, "us_per_launch": round(sec * 1e6, 1),
+                                   "achieved": round(flops / sec / 1e12, 2), "peak": VALU_F32_PEAK_TFS, "unit": "TFLOP/s",
+                                   "frac": round(flops / sec / 1e12 / VALU_F32_PEAK_TFS, 4),
+                                   "note": "circular correlation by its definition, 2 D^2 flop per edge (the reference's FFT form is O(D log D) but "
+                                           "torch.rfft no longer exists; SURVEY 8a8)"}
+    elif fixed:
         out["metric"] = ("million edges/sec per fixed-genotype train step (FB15k-237, dim=64, batch 256)" if args.workload == "fb15k237_fixed_d64"
                          else "million edges/sec per fixed-genotype train step (synthetic KG 10M edges / 1M nodes / 512 relations, dim=256, batch 256)")
         out["config"]["layers"] = 1
@@ -600,7 +690,27 @@ def main():
         lib.mrg_gemm_set_mode(0)
         out["exact_f32"] = {"ms_per_step": round(ms, 3), "value": round(E_total / ms / 1e3, 4), "unit": "M edges/s",
                             "matrix_core": "exact f32 MFMA (v_mfma_f32_32x32x2_f32) for every GEMM"}
-    if world == 1 and not sharded and args.workload != "c5_fixed_cell":
+    if (world == 1 and not sharded and not fixed and args.caller == "fused" and not args.no_caller_leg and not args.hip_graph
+            and not args.resample):
+        # the same step through the reference's literal caller formulation: what models/cell_lp.py gets unchanged
+        CL.CALLER = "reference"
+        try:
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            out["caller_reference"] = {"ms_per_step": round(ms, 3), "value": round(E_total / ms / 1e3, 4), "unit": "M edges/s",
+                                       "what": "per-candidate operator call + nn.BatchNorm1d + ReLU + scaled add, Python sums, gathers materialised "
+                                               "(reference models/cell_lp.py:25-33,95-113; models/model_search_lp.py:144-145) on the same HIP operators",
+                                       "loss": float(step.last_loss)}
+        except torch.cuda.OutOfMemoryError as e:
+            out["caller_reference"] = {"error": "out of memory: " + str(e)[:120]}
+        CL.CALLER = "fused"
+        torch.cuda.empty_cache()
+    if world == 1 and not sharded and args.workload not in ("c5_fixed_cell", "compgcn_fb15k237"):
         log("timing the fused compose+scatter kernel (north-star kernel) on the benchmark graph")
         out["north_star_kernel"] = north_star_kernel(step.g, args.dim, tag=args.workload.split("_")[0])
         if not args.no_c5:

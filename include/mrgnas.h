@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 9   /* 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 10   /* 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -370,12 +370,17 @@ int64_t mrg_gemm_workspace_bytes(int K, int Nout);
  * plain epilogue.  2, 3 and 4 are tested comparison points with bit-identical results.  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 /* Store order of the split-core row GEMM's elementwise epilogues (bias / activation, gate, scale, accumulate):
- * 0 (default): accumulator-order 4-byte stores; 1: a 32-row strip of results goes through wave-private LDS and leaves as
+ * 0 (default): accumulator-order 4-byte stores (two 128-byte row pieces per store instruction);
+ * 2 (round 4): the LDS-weight kernel exchanges the MFMA operands, so that a lane holds one output row's 4-column chunks and
+ * every epilogue load and store is 16 bytes per lane with no LDS round trip (needs N % 4 == 0 and 16-byte aligned rows of every
+ * [rows, N] operand and of the bias; otherwise, and for the fused aggregators' epilogues, mode 0) -- bit-identical, measured
+ * 8-30 % slower per launch, kept as a tested comparison point;
+ * 1: (one-wave kernel, mrg_gemm_set_mode(2)) a 32-row strip of results goes through wave-private LDS and leaves as
  * row-order 16-byte stores (1 KB of consecutive addresses per store instruction; the gate multiplicand / accumulate input are
  * read the same way) whenever N % 4 == 0 and the rows of every [rows, N] operand are 16-byte aligned.  Bit-identical results;
  * measured slower for the plain epilogue and in the whole step, kept as a tested comparison point.
  * Process-wide. */
-int mrg_gemm_set_epilogue(int row_order);
+int mrg_gemm_set_epilogue(int mode);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
  * (wgrad_x3_k, rounds 1-2).  Same operands and products in the same order: bit-identical gradients for any shape. */

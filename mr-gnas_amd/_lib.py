@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MrgnasLibraryError(RuntimeError):

@@ -330,6 +330,76 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
   }
 }
 
+// ---- the same epilogues on a TRANSPOSED accumulator tile (rowgemm_x3s_k<..., TR = true>) ---------------------------------------
+// With the MFMA operands exchanged, lane (li, lh) holds row rowbase + li and, in registers 4g .. 4g+3 of tile n, the columns
+// col0 + 32 n + 8 g + 4 lh + {0..3}: sixteen consecutive bytes of C.  Bias, gate multiplicand and accumulate input are read as
+// float4 and the results leave as global_store_dwordx4: 4 * NT store (and load) instructions per strip instead of 16 * NT, one
+// address computation per row instead of per (row, array).  Arithmetic and its order per element are gemm_epilogue's.
+// Requires gemm_epilogue_tr_ok (N % 4 == 0: a 4-column chunk is valid or invalid as a whole; 16-byte aligned rows).
+template <int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue_tr(const GemmArgs& a, f32x16 (&acc)[NT], int64_t rowbase, int col0, int li, int lh) {
+  if (rowbase >= a.rows) return;                           // wave-uniform: the whole 32-row strip is out of range
+  const int64_t row = rowbase + li;
+  const bool rok = row < a.rows;
+  const int64_t rc = rok ? row : a.rows - 1;
+  const int cb = col0 + 4 * lh;                            // this lane's first column of (tile 0, group 0)
+  const bool cstore = EPI != EPI_GATE || a.C != nullptr;   // EPI_GATE with C == NULL: only the gate is stored (see gemm_epilogue)
+  float* crow = cstore ? a.C + rc * a.ldc + cb : nullptr;
+  const float* srow = nullptr;
+  if (EPI == EPI_GATE && cstore) srow = a.S + rc * a.ld_s + cb;
+  if (EPI == EPI_ACCUM) srow = a.Cin + rc * a.ld_cin + cb;
+  float* xrow = (EPI == EPI_GATE && a.aux) ? a.aux + rc * a.N + cb : nullptr;
+  float cs = 1.0f;
+  if (EPI == EPI_GATE || EPI == EPI_SCALE) cs = a.scale * (a.rowscale ? a.rowscale[rc] : 1.0f);
+  const float* brow = a.bias ? a.bias + cb : nullptr;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int off = n * 32 + g * 8;
+      if (cb + off >= a.N) continue;                       // beyond the last column (whole chunk)
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), in = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (brow) bv = *reinterpret_cast<const float4*>(brow + off);
+      if (srow) in = *reinterpret_cast<const float4*>(srow + off);
+      const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ii[4] = {in.x, in.y, in.z, in.w};
+      float v[4], gt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = acc[n][4 * g + j] + bb[j];
+        if (EPI == EPI_BIAS_ACT) {
+          v[j] = (a.act == MRG_ACT_RELU) ? (x > 0.f ? x : 0.f) : (a.act == MRG_ACT_SIGMOID ? sigmoidf_fast(x) : x);
+        } else if (EPI == EPI_GATE) {
+          gt[j] = sigmoidf_fast(x);
+          v[j] = gt[j] * ii[j] * cs;
+        } else if (EPI == EPI_SCALE) {
+          v[j] = x * cs;
+        } else {
+          v[j] = x + ii[j];
+        }
+      }
+      if (rok) {
+        if (cstore) *reinterpret_cast<float4*>(crow + off) = make_float4(v[0], v[1], v[2], v[3]);
+        if (EPI == EPI_GATE && xrow) *reinterpret_cast<float4*>(xrow + off) = make_float4(gt[0], gt[1], gt[2], gt[3]);
+      }
+    }
+  }
+}
+
+// host side: may this launch run on transposed accumulators?
+template <int EPI>
+inline bool gemm_epilogue_tr_ok(const GemmArgs& a) {
+  if (EPI != EPI_BIAS_ACT && EPI != EPI_GATE && EPI != EPI_SCALE && EPI != EPI_ACCUM) return false;
+  if (a.N % 4 != 0) return false;
+  const bool gate_only = EPI == EPI_GATE && !a.C && a.aux;
+  if (!gate_only && (!a.C || a.ldc % 4 != 0 || !aligned16(a.C))) return false;
+  if (EPI == EPI_GATE && ((a.C && (a.ld_s % 4 != 0 || !aligned16(a.S))) || (a.aux && !aligned16(a.aux)))) return false;
+  if (EPI == EPI_ACCUM && (a.ld_cin % 4 != 0 || !aligned16(a.Cin))) return false;
+  if (a.bias && !aligned16(a.bias)) return false;
+  for (int i = 0; i < a.grp.n && i < 3; ++i)
+    if (a.grp.bias[i] && !aligned16(a.grp.bias[i])) return false;
+  return true;
+}
+
 // ---- the same epilogues with the stores (and the [rows, N] inputs) in ROW order, through a wave-private LDS strip -----------
 // gemm_epilogue above stores an accumulator register as it stands: one global_store_dword per (row quad, column tile) =
 // two 128-byte pieces of two rows, 16 * NT store instructions per 32-row strip.  The row GEMM's store tail is bound by the

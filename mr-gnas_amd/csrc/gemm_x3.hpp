@@ -156,6 +156,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // overhead), the accumulate epilogue 5-8 % faster (its input is read in row order too), the gate epilogue equal; in the supernet
 // step the row GEMM entry points lose 0.9 ms / step in total (profiles/r3_rowgemm_epilogue.txt).  Kept as a tested option.
 inline int& gemm_epi_lds() { static int m = 0; return m; }
+// Round 4: 2 = TRANSPOSED accumulators in the LDS-weight kernel (gemm_x3s.hpp, gemm_epilogue_tr): the MFMA operands change
+// places, a lane owns one row's 4-column chunks, and every epilogue load / store is 16 bytes per lane with no LDS round trip (28
+// store instructions per 32-row strip instead of 112).  Bit-identical, and SLOWER (rows 558 771, K = N = 200: plain 0.426 vs
+// 0.393 ms, accumulate 0.598 vs 0.463, gate 0.717 vs 0.611): a store instruction that writes 32 rows x 32 bytes costs the memory
+// pipeline more than one that writes 2 rows x 128 bytes, and the epilogue is not bound by its instruction count -- the same
+// 112 stores alone, at the kernel's grid, move 4.0 TB/s (profiles/r4_rowgemm_phases.txt).  Kept as a tested comparison point.
+inline int& gemm_epi_mode() { static int m = 0; return m; }
 
 constexpr int X3_THREADS = 256;     // 4 waves, one per SIMD
 constexpr int X3_SLOTS = 4;         // per-wave LDS ring of A slabs

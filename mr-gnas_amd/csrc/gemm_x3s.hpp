@@ -20,7 +20,7 @@
 #include "gemm_x3.hpp"
 
 // lab switches (tools/x3s_dbg_lab.hip, timing only -- wrong results): 1 no epilogue, 2 no A loads after the prologue,
-// 4 no B DMA after the prologue, 8 no barriers.  (A "no splits" switch left asynchronous register fills unconsumed and
+// 4 no B DMA after the prologue, 8 no barriers, 16 phase stamps, 64 no split arithmetic, 128 no fragment reads after the first slab.  (A "no splits" switch left asynchronous register fills unconsumed and
 // faulted: every asm load's registers must be read after its wait -- see gemm_x3.hpp.)
 #ifndef MRG_X3S_DBG
 #define MRG_X3S_DBG 0
@@ -30,11 +30,16 @@
 #ifndef MRG_X3S_STAGGER
 #define MRG_X3S_STAGGER 0
 #endif
-// 1 (default): the weight fragments of a slab's FIRST column-tile pair are read during the previous slab's LAST pair -- the
+// 1 (round 4 lab; bit-identical, measured equal): the weight fragments of a slab's FIRST column-tile pair are read during the previous slab's LAST pair -- the
 // barrier that publishes slab s + 1 stands in front of slab s's last pair instead of behind it -- so that the LDS round trip and
 // the barrier's skew no longer open every slab (round 4; 0 = round 3's schedule).  Needs an even number of tile pairs per slab.
 #ifndef MRG_X3S_PIPE
-#define MRG_X3S_PIPE 1
+#define MRG_X3S_PIPE 0
+#endif
+// 1: the slabs with s + 4 < nslab run a branch-free instance of the slab body with a running activation pointer (round 4 lab;
+// bit-identical, measured equal: 0.407-0.414 vs 0.410-0.414 ms at rows 558 771 -- profiles/r4_rowgemm_phases.txt).  0 (default) = round 3's form.
+#ifndef MRG_X3S_STEADY
+#define MRG_X3S_STEADY 0
 #endif
 
 namespace mrg {
@@ -49,7 +54,11 @@ __device__ unsigned long long* mrg_x3s_trace;
 #define MRG_X3S_STAMP(i) do { } while (0)
 #endif
 
-template <int NT, int EPI, bool DUAL>
+// TR: the MFMA operands change places (weight fragment first, activation fragment second), which transposes the accumulator
+// tile -- a lane then holds ONE row's columns 8g + 4 lh + {0..3} in registers 4g..4g+3 -- so that the epilogue loads and stores
+// 16 bytes per lane (gemm_epilogue_tr below): 4 * NT store instructions per strip instead of 16 * NT.  Same products, same
+// order of accumulation: bit-identical results.
+template <int NT, int EPI, bool DUAL, bool TR>
 __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
   constexpr int GBM = 128;
   constexpr int NCH = NT * 3;                   // 1 KB chunks (64 lanes x 16 B) of one pre-split B slab of this column block
@@ -93,6 +102,18 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
+#if MRG_X3S_DBG & 256
+  // lab: nothing but the epilogue (what the store pattern alone costs at this grid and residency)
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = (float)(lane + n + r);
+  if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc, roww, col0, li, lh);
+  else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc, roww, col0, li, lh);
+  else if constexpr (TR) gemm_epilogue_tr<NT, EPI>(a, acc, roww, col0, li, lh);
+  else gemm_epilogue<NT, EPI>(a, acc, roww, col0, li, lh, row0 + GBM <= a.rows);
+  return;
+#endif
   // ---- A: this lane's fragment of a slab = row li, k = slab * 16 + lh * 8 + {0..3, 4..7}: two 16-byte loads
   int64_t rc = roww + li < a.rows ? roww + li : a.rows - 1;
   if (rc < 0) rc = 0;
@@ -117,6 +138,14 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[0]) : "v"(p0));
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[1]) : "v"(p1));
   };
+  // steady state (slab + 3 < nslab - 1, single source): no clamp is needed, and the address is a running pointer that advances by one
+  // slab per call -- two VALU instructions instead of thirteen
+  const float* pa = ar1 + 3 * 16 + lh * 8;
+  auto load_a_run = [&](v4f (&x)[2]) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[0]) : "v"(pa));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(x[1]) : "v"(pa));
+    pa += 16;
+  };
   // ---- B: the slab's NCH chunks, NBW per wave (the last wave repeats the last chunk: same bytes to the same place)
   const char* bcol = Bq + (int64_t)blockIdx.y * NT * 3072;
   auto fetch_b = [&](int slab, int buf) {
@@ -130,7 +159,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   };
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_b + (unsigned)lane * 16u;
   u32x4 bq2[2][2][3];                                    // [double buffer][tile of the pair][plane]
+  bool lab_reads = true;                                 // lab switch 128: no fragment reads after the first slab
   auto read_b = [&](int n, int buf, u32x4 (&q)[3]) {
+    if ((MRG_X3S_DBG & 128) && !lab_reads) return;
     const unsigned ad = lds0 + (unsigned)(buf * BSLAB + n * 3072);
     asm volatile("ds_read_b128 %0, %1" : "=v"(q[0]) : "v"(ad));
     asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(q[1]) : "v"(ad));
@@ -140,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   auto split_pair_of = [&](const v4f (&x)[2], int q, u32x4& H, u32x4& M, u32x4& L) {     // q = 0..3: floats 2q, 2q + 1 of the 8
     const v4f& v = x[q >> 1];
     unsigned h, m, l;
-    if (q & 1) split_pair(v.z, v.w, h, m, l); else split_pair(v.x, v.y, h, m, l);
+    if (MRG_X3S_DBG & 64) { h = __builtin_bit_cast(unsigned, (q & 1) ? v.z : v.x); m = __builtin_bit_cast(unsigned, (q & 1) ? v.w : v.y); l = h; }   // lab: no split
+    else if (q & 1) split_pair(v.z, v.w, h, m, l); else split_pair(v.x, v.y, h, m, l);
     H[q] = h; M[q] = m; L[q] = l;
   };
   auto nb_issued = [&](int j) { return (j >= -2 && j + 2 < nslab) ? NBW : 0; };   // B DMAs issued at the top of slab j (j < 0: prologue)
@@ -184,11 +216,19 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   //        the raw registers slab s-1 split from;
   //   the splits need A(s+1): younger = B(s+1) A(s+2) B(s+2) A(s+3);
   //   end: B(s+1) must be in LDS before the barrier: younger = A(s+2) B(s+2) A(s+3).
-  auto slab = [&](auto r_c, int s) {
+#define MRG_MM(AF, BF, C) (TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, C, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, C, 0, 0, 0))
+  // ST (steady state, s + 4 < nslab): every condition and every wait count below is a compile-time constant -- the scalar branches of
+  // the run-time form cost a wave that has its SIMD's matrix pipe to itself about one MFMA slot each, ~450 of a slab's 1 800 cycles
+  // with nothing but MFMAs left in the loop (profiles/r4_rowgemm_phases.txt)
+  auto slab = [&](auto r_c, auto st_c, int s) {
     constexpr int R = decltype(r_c)::value;
-    const bool has_next = s + 1 < nslab;
-    if (!PIPE && s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
-    if (!(MRG_X3S_DBG & 2)) load_a(s + 3, xr[R]);
+    constexpr bool ST = decltype(st_c)::value;
+    const bool has_next = ST ? true : (s + 1 < nslab);
+    if (!PIPE && (ST || s + 2 < nslab) && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
+    if (!(MRG_X3S_DBG & 2)) {
+      if constexpr (ST && !DUAL) load_a_run(xr[R]);
+      else load_a(s + 3, xr[R]);
+    }
     // Column tiles in PAIRS: the twelve MFMAs of a pair alternate between its two accumulators (a dependent MFMA issued back to
     // back waits for its predecessor's result; with another accumulator's MFMA in between the pipe stays busy) and the VALU
     // instructions of the A split are spread between them (sched_group_barrier: 1 MFMA, then up to 3 VALU) instead of
@@ -196,11 +236,13 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     constexpr int SPP = (4 + NP - 1) / NP;                    // split pairs handled in the shadow of one tile pair
     if constexpr (PIPE) {
       // A(s+1) is split during this slab; younger than it: B(s) [unless s == 0: B(0) leads the prologue] A(s+2) B(s+1) A(s+3)
-      if (has_next) wait_vmcnt(nbw(s) + 2 + nbw(s + 1) + 2);
+      if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nbw(s) + 2 + nbw(s + 1) + 2);
+      if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     read_b(0, R, bq2[0][0]);
     if (NT > 1) read_b(1, R, bq2[0][1]);
-    if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
+    if constexpr (ST && !(MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBW + 4) : "memory");
+    else if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
     if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #pragma unroll
@@ -211,9 +253,10 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
         // in front of the last pair: publish slab s + 1, start the DMA of slab s + 2 into the buffer slab s - 1 was read from
         // (every wave is past that slab), and read slab s + 1's first pair
         if (has_next) {
-          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // this wave's share of B(s+1): only A(s+3) is younger
+          if (MRG_X3S_DBG & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // this wave's share of B(s+1): only A(s+3) is younger
           if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();
-          if (s + 2 < nslab) fetch_b(s + 2, (R + 2) % 3);
+          if (s + 2 < nslab && !(MRG_X3S_DBG & 4)) fetch_b(s + 2, (R + 2) % 3);
           read_b(0, (R + 1) % 3, bq2[(pp + 1) & 1][0]);
           if (NT > 1) {
             read_b(1, (R + 1) % 3, bq2[(pp + 1) & 1][1]);
@@ -247,25 +290,25 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
         const bf16x8 Bh1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][0]), Bm1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][1]),
                      Bl1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][2]);
         // small terms first, the leading term last (same order per accumulator as rowgemm_x3_k)
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[n1], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[n1], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[n1], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[n1], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[n1], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[n0], 0, 0, 0);
-        acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[n1], 0, 0, 0);
+        acc[n0] = MRG_MM(Am, Bm0, acc[n0]);
+        acc[n1] = MRG_MM(Am, Bm1, acc[n1]);
+        acc[n0] = MRG_MM(Al, Bh0, acc[n0]);
+        acc[n1] = MRG_MM(Al, Bh1, acc[n1]);
+        acc[n0] = MRG_MM(Ah, Bl0, acc[n0]);
+        acc[n1] = MRG_MM(Ah, Bl1, acc[n1]);
+        acc[n0] = MRG_MM(Am, Bh0, acc[n0]);
+        acc[n1] = MRG_MM(Am, Bh1, acc[n1]);
+        acc[n0] = MRG_MM(Ah, Bm0, acc[n0]);
+        acc[n1] = MRG_MM(Ah, Bm1, acc[n1]);
+        acc[n0] = MRG_MM(Ah, Bh0, acc[n0]);
+        acc[n1] = MRG_MM(Ah, Bh1, acc[n1]);
       } else {
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[n0], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[n0], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[n0], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[n0], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[n0], 0, 0, 0);
-        acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[n0], 0, 0, 0);
+        acc[n0] = MRG_MM(Am, Bm0, acc[n0]);
+        acc[n0] = MRG_MM(Al, Bh0, acc[n0]);
+        acc[n0] = MRG_MM(Ah, Bl0, acc[n0]);
+        acc[n0] = MRG_MM(Am, Bh0, acc[n0]);
+        acc[n0] = MRG_MM(Ah, Bm0, acc[n0]);
+        acc[n0] = MRG_MM(Ah, Bh0, acc[n0]);
       }
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
@@ -281,21 +324,34 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
     if (has_next) {
       ch = nh; cm = nm; cl = nl;
       if constexpr (!PIPE) {
-      if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2);                       // this wave's share of B(s+1) is in LDS
+      if constexpr (ST && !(MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 4) : "memory");
+      else if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2);                       // this wave's share of B(s+1) is in LDS
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();   // ... and everybody's; all reads of this slab's buffer are done
       }
     }
+#if MRG_X3S_DBG & 16
     if (s < 16) MRG_X3S_STAMP(2 + s);
+#endif
+    if (MRG_X3S_DBG & 128) lab_reads = false;
   };
+#undef MRG_MM
   int s = 0;
-  for (; s + 2 < nslab; s += 3) {
-    slab(std::integral_constant<int, 0>{}, s);
-    slab(std::integral_constant<int, 1>{}, s + 1);
-    slab(std::integral_constant<int, 2>{}, s + 2);
+  constexpr bool STEADY = MRG_X3S_STEADY && !PIPE;
+  if constexpr (STEADY) {
+    for (; s + 6 < nslab; s += 3) {             // all three slabs satisfy s' + 4 < nslab
+      slab(std::integral_constant<int, 0>{}, std::true_type{}, s);
+      slab(std::integral_constant<int, 1>{}, std::true_type{}, s + 1);
+      slab(std::integral_constant<int, 2>{}, std::true_type{}, s + 2);
+    }
   }
-  if (s < nslab) { slab(std::integral_constant<int, 0>{}, s); ++s; }
-  if (s < nslab) { slab(std::integral_constant<int, 1>{}, s); ++s; }
+  for (; s + 2 < nslab; s += 3) {
+    slab(std::integral_constant<int, 0>{}, std::false_type{}, s);
+    slab(std::integral_constant<int, 1>{}, std::false_type{}, s + 1);
+    slab(std::integral_constant<int, 2>{}, std::false_type{}, s + 2);
+  }
+  if (s < nslab) { slab(std::integral_constant<int, 0>{}, std::false_type{}, s); ++s; }
+  if (s < nslab) { slab(std::integral_constant<int, 1>{}, std::false_type{}, s); ++s; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's unused A fills: their registers must stay until they land
   asm volatile("" :: "v"(xr[0][0]), "v"(xr[0][1]), "v"(xr[1][0]), "v"(xr[1][1]), "v"(xr[2][0]), "v"(xr[2][1]));
 
@@ -303,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* 
   if ((MRG_X3S_DBG & 1) && acc[0][0] != 123.456f) return;
   if constexpr (EPI == EPI_SEGMAX) gemm_epilogue_segmax<NT>(a, acc, roww, col0, li, lh);
   else if constexpr (EPI == EPI_SEGSUM) gemm_epilogue_segsum<NT>(a, acc, roww, col0, li, lh);
+  else if constexpr (TR) gemm_epilogue_tr<NT, EPI>(a, acc, roww, col0, li, lh);
   else gemm_epilogue<NT, EPI>(a, acc, roww, col0, li, lh, row0 + GBM <= a.rows);
 #if MRG_X3S_DBG & 16
   MRG_X3S_STAMP(19);
@@ -335,11 +392,21 @@ inline int launch_rowgemm_x3s(GemmArgs a, const void* Bp, hipStream_t st) {
     if (a.grp.tile0[3] == 0) return MRG_OK;
   }
   dim3 grid((unsigned)(a.grp.n > 0 ? a.grp.tile0[3] : (a.rows + gbm - 1) / gbm), (unsigned)(ntile / nt));
-  const size_t lds = (size_t)3 * nt * 3 * 1024;
+  size_t lds = (size_t)3 * nt * 3 * 1024;
+#if MRG_X3S_DBG
+  if (getenv("MRG_X3S_LDS_EXTRA")) lds += (size_t)atoi(getenv("MRG_X3S_LDS_EXTRA"));     // lab: one workgroup per CU
+#endif
+  bool tr = false;
+  if constexpr (EPI != EPI_SEGMAX && EPI != EPI_SEGSUM) tr = gemm_epi_mode() == 2 && gemm_epilogue_tr_ok<EPI>(a);
+#define MRG_GOS3(NTV, DV, TV)                                                                                         \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s_k<NTV, EPI, DV, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((rowgemm_x3s_k<NTV, EPI, DV, TV>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);       \
+  } while (0)
 #define MRG_GOS2(NTV, DV)                                                                                             \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s_k<NTV, EPI, DV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((rowgemm_x3s_k<NTV, EPI, DV>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);           \
+    if constexpr (EPI == EPI_SEGMAX || EPI == EPI_SEGSUM) MRG_GOS3(NTV, DV, false);                                   \
+    else { if (tr) MRG_GOS3(NTV, DV, true); else MRG_GOS3(NTV, DV, false); }                                          \
   } while (0)
 #define MRG_GOS(NTV) do { if (a.K2 > 0) MRG_GOS2(NTV, true); else MRG_GOS2(NTV, false); } while (0)
   switch (nt) {
@@ -350,6 +417,7 @@ inline int launch_rowgemm_x3s(GemmArgs a, const void* Bp, hipStream_t st) {
   }
 #undef MRG_GOS
 #undef MRG_GOS2
+#undef MRG_GOS3
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MRG_OK : (int)e;
 }

@@ -943,9 +943,10 @@ extern "C" int mrg_wgrad_set_variant(int variant) {
   return MRG_OK;
 }
 
-extern "C" int mrg_gemm_set_epilogue(int row_order) {
-  if (row_order != 0 && row_order != 1) return MRG_E_ENUM;
-  gemm_epi_lds() = row_order;
+extern "C" int mrg_gemm_set_epilogue(int mode) {
+  if (mode < 0 || mode > 2) return MRG_E_ENUM;
+  gemm_epi_lds() = mode == 1 ? 1 : 0;
+  gemm_epi_mode() = mode;
   return MRG_OK;
 }
 

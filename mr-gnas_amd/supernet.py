@@ -16,8 +16,6 @@ cannot travel).  Module/attribute names follow the reference so that its
 """
 import collections
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -57,166 +55,10 @@ def _xavier_param(*shape):
 # ---------------------------------------------------------------------------
 # supernet
 # ---------------------------------------------------------------------------
-# HIP streams the candidates of a MixedOp are spread over.  Rounds 1-2 ran them on four: the one-wave row GEMM owns a CU's whole
-# register file, and other candidates' kernels filled its tails (71.4 -> 69.9 ms/step).  With the LDS-weight row GEMM (two
-# workgroups per CU) the step is the same on one stream as on four (62.3 / 62.8 vs 62.3 / 62.8 ms, profiles/r3_streams.txt), so the
-# default is ONE: no event traffic, no cross-stream allocator bookkeeping; 2-4 remain available.
-MIXED_STREAMS = int(os.environ.get("MRG_MIXED_STREAMS", "1"))
-
-
-class MixedOp(nn.Module):
-    """sum_k w_k * ReLU(BN_k(op_k(g, h, h_in)))   (reference models/cell_lp.py:12-33)."""
-
-    def __init__(self, feature_dim, drop_aggr, operations, registry=OPS.MIXED_OPS):
-        super().__init__()
-        args = {'feature_dim': feature_dim, 'drop_aggr': drop_aggr}
-        self._ops = nn.ModuleList(nn.ModuleList([registry[name](args), nn.BatchNorm1d(feature_dim), nn.ReLU()])
-                                  for name in operations)
-
-    def forward(self, weights, g, h, h_in, group=None, total_rows=None, addend=None, prepare_only=False):
-        """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
-        BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
-        materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks."""
-        if not (h.x if isinstance(h, K.Fan) else h).is_cuda:    # reference formulation (registry of non-HIP test operators)
-            if isinstance(h, K.LazyRows):
-                h, h_in = h.materialize(), h_in.materialize()
-            total = 0 if addend is None else addend
-            for w, (op, bn, act) in zip(weights, self._ops):
-                total = total + w * act(bn(op(g, h, h_in).float()))
-            return total
-        if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
-            if (K.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(self._ops) <= 3
-                    and all(isinstance(op, OPS._PreOp) for op, _, _ in self._ops)):
-                # ... and are never stored: statistics, combine and gradients recompute them from the two tables
-                return K.cell_zero_mixed([op.kind for op, _, _ in self._ops], h, h_in, [bn for _, bn, _ in self._ops], weights,
-                                         group, total_rows)
-            ys = [op(g, h, h_in) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
-        # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
-        # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
-        n = len(self._ops)
-        fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
-        fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
-        # f_dense_comp and f_comp read the same (h, h_in): one autograd node whose backward leaves ONE gradient per operand
-        pair = self._dense_pair(fh.x)
-        paired = {}
-        # f_sparse_comp as a row factor: only next to the gate-only f_dense_comp, whose folded gradient store receives its gradient
-        row_ok = pair is not None and K.GATED_RECOMPUTE and K.FOLD_ROW_SCALE
-        # The candidates are independent: they run round-robin on a few HIP streams so that the tail of one
-        # kernel (a GEMM workgroup owns a whole CU) is filled by another candidate's kernels.  Autograd replays
-        # each candidate's backward on the stream its forward ran on.
-        dev = fh.x.device
-        # (launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows)
-        nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
-        if nstreams <= 1:
-            ys = []
-            for k, (op, _, _) in enumerate(self._ops):
-                if isinstance(op, OPS.f_zero_op):
-                    ys.append(None)
-                elif pair is not None and k in pair:
-                    if not paired:
-                        paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take(), for_epilogue=True)
-                    ys.append(paired[k])
-                elif row_ok and type(op) is OPS.f_sparse_op_comp:
-                    ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))
-                else:
-                    ys.append(op(g, fh.take(), fi.take()))
-            prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
-            # prepare_only (dist.py): the caller issues the statistics collective of several MixedOps at once (functional.StatChain)
-            return prep if prepare_only else prep(weights, addend)
-        fork = K.Fork(dev, nstreams, tag="candidates")
-        ys = []
-        for k, (op, _, _) in enumerate(self._ops):
-            if isinstance(op, OPS.f_zero_op):
-                ys.append(None)
-                continue
-            if pair is not None and k in pair and paired:
-                ys.append(paired[k])                   # computed with its partner
-                continue
-            side = fork.stream(k)
-            a, b = fh.take(), fi.take()
-            if side is not fork.main:                  # h / h_in live in main-stream blocks and are read (forward and,
-                a.record_stream(side)                  # through the saved tensors, backward) on the side stream: the
-                b.record_stream(side)                  # allocator must not recycle them before that stream is done
-            with torch.cuda.stream(side):
-                if pair is not None and k in pair:
-                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b, for_epilogue=True)
-                    y = paired[k]
-                    paired[pair[0] + pair[1] - k].record_stream(fork.main)
-                elif row_ok and type(op) is OPS.f_sparse_op_comp:
-                    y = op(g, a, b, for_epilogue=True)
-                else:
-                    y = op(g, a, b)
-            y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
-            ys.append(y)
-        fork.join()
-        prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
-        return prep if prepare_only else prep(weights, addend)
-
-
-    def _identity_index(self):
-        ids = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_identity_op]
-        return ids[0] if len(ids) == 1 else None
-
-    def _dense_pair(self, x):
-        """(index of f_dense_comp, index of f_comp) when both are candidates of this MixedOp and may share a node, else None."""
-        if not x.is_cuda:
-            return None
-        d = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_dense_op_comp]
-        c = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_comp_op]
-        if len(d) != 1 or len(c) != 1:
-            return None
-        return (d[0], c[0])
-
-
-
-class _Stage(nn.Module):
-    """A list of MixedOps under the attribute name ``_ops`` (the reference's Cell_* classes)."""
-
-    def __init__(self, count, feature_dim, drop_aggr, operations, registry):
-        super().__init__()
-        self._ops = nn.ModuleList(MixedOp(feature_dim, drop_aggr, operations, registry) for _ in range(count))
-
-
-class SuperCell(nn.Module):
-    """Zero -> First -> Middle -> Last stages and the concat linear
-    (reference models/cell_lp.py:53-188)."""
-
-    def __init__(self, n_zero, n_first, n_last, feature_dim, drop_aggr, registry=OPS.MIXED_OPS):
-        super().__init__()
-        self.n_first, self.n_last = n_first, n_last
-        mk = lambda cnt, names: _Stage(cnt, feature_dim, drop_aggr, names, registry)
-        self.cell_zero = mk(1, OPS.PRE_OPS)
-        self.cell_first = mk(sum(i + 1 for i in range(n_first)), OPS.FIRST_OPS)
-        self.cell_middle = mk(n_first, OPS.MIDDLE_OPS)
-        self.cell_last = mk(sum(n_first + i for i in range(n_last)), OPS.LAST_OPS)
-        self.concat_weights = nn.Linear((n_first + n_last) * feature_dim, feature_dim)
-
-    def _fan(self, x):
-        """Reader bookkeeping for one state: every candidate of every MixedOp of the cell may read it."""
-        if not x.is_cuda:
-            return x
-        n_mixed = 1 + len(self.cell_first._ops) + len(self.cell_middle._ops) + len(self.cell_last._ops)
-        width = max(len(m._ops) for st in (self.cell_first, self.cell_middle, self.cell_last) for m in st._ops)
-        return K.Fan(x, 2 * n_mixed * width + 2)
-
-    def _dense_stage(self, stage, states, weights, g, h_in, steps):
-        off = 0
-        for _ in range(steps):
-            s = None                                   # the MixedOps feeding one state: each adds onto the previous one's output
-            for j, h in enumerate(states):
-                s = stage._ops[off + j](weights[off + j], g, h, h_in, addend=s)
-            off += len(states)
-            states.append(self._fan(s))
-        return states
-
-    def forward(self, g, src_emb, hr, w_zero, w_first, w_middle, w_last):
-        h_in = self._fan(self.cell_zero._ops[0](w_zero[0], g, src_emb, hr))
-        states = self._dense_stage(self.cell_first, [h_in], w_first, g, h_in, self.n_first)[1:]
-        states = [self._fan(self.cell_middle._ops[i](w_middle[i], g, states[i], h_in)) for i in range(self.n_first)]
-        states = self._dense_stage(self.cell_last, states, w_last, g, h_in, self.n_last)
-        states = [s.take() if isinstance(s, K.Fan) else s for s in states]
-        return self.concat_weights(torch.cat(states, dim=1))
+# The cell and its MixedOps live in cell_lp.py under the reference's own class names (the module a maintainer swaps in for
+# models/cell_lp.py); the names below are what rounds 1-3 called them.
+from .cell_lp import MixedOp, Cell as SuperCell            # noqa: E402,F401
+from . import cell_lp as _cell_lp                          # noqa: E402
 
 
 class SearchNetwork(nn.Module):
@@ -289,9 +131,14 @@ class SearchNetwork(nn.Module):
         weights = self.row_weights()
         for l, cell in enumerate(self.cells):
             wz, wf, wm, wl = weights[l]
-            # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
-            x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
-            ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
+            if _cell_lp.CALLER == "reference" and ent_all.is_cuda:
+                # the reference's own lines (:144-145, :153-154): index, cat, index -- plain tensors into the cell
+                x = ent_all[p_ent.idx] if l == 0 else torch.cat((ent[src_in.long()], ent), dim=0)
+                ent = self.batchnorm_h(cell(g_train, x, rel[p_rel.idx], wz, wf, wm, wl))
+            else:
+                # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
+                x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
+                ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
             if l > 0 or self._layers == 1:
                 ent = F.relu(ent)
             ent = F.dropout(ent, self._dropout, training=self.training)

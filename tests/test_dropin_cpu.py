@@ -58,6 +58,29 @@ try:
 except (TypeError, AttributeError) as e:     # constructor contract differs from what this test assumes: report, do not hide
     out["fixed_error"] = repr(e)
 
+# round 4: models.cell_lp swapped for mr_gnas_amd.cell_lp as well -- the reference's model_search_lp.Network then builds OUR cells
+# (same constructor arguments, same state_dict keys) and its forward runs through them (CPU: the literal formulation)
+import importlib
+from mr_gnas_amd import cell_lp as OCL
+sys.modules["models.cell_lp"] = OCL
+models.cell_lp = OCL
+MS2 = importlib.reload(MS)
+assert MS2.Cell is OCL.Cell and MS2.Cell_SF is OCL.Cell_SF, "model_search_lp did not pick up the swapped cell module"
+ref_net2 = MS2.Network("cpu", 60, 7, 2, 1, 2, 2, 24, 12, 15, 40.0, 0.0, 0.0)
+out["net_ref_swapped_cells"] = shape(ref_net2)
+out["swapped_cell_types"] = sorted({type(c).__module__ for c in ref_net2.cells})
+ref_net2.load_state_dict(ref_net.state_dict(), strict=True)
+out["cell_lp_exports"] = sorted(n for n in ("MixedOp", "MixedOp_SF", "Cell_Zero", "Cell_Final", "Cell_First", "Cell_Middle", "Cell_Last", "Cell", "Cell_SF")
+                                if hasattr(OCL, n))
+for name in ("MixedOp", "Cell_Zero", "Cell_First", "Cell_Middle", "Cell_Last", "Cell"):      # constructor / forward argument names of the reference
+    r_init = list(inspect.signature(getattr(CL, name).__init__).parameters)
+    o_init = list(inspect.signature(getattr(OCL, name).__init__).parameters)
+    r_fwd = list(inspect.signature(getattr(CL, name).forward).parameters)
+    o_fwd = list(inspect.signature(getattr(OCL, name).forward).parameters)
+    assert o_init[:len(r_init)] == r_init, (name, r_init, o_init)
+    assert o_fwd[:len(r_fwd)] == r_fwd, (name, r_fwd, o_fwd)
+# (a forward needs the HIP device -- the product has no CPU path: tests/test_nets_gpu.py::test_cell_lp_on_plain_tensors)
+
 # every operator the reference's MixedOp / OpModule would call binds (g, src_emb, src_emb_in)
 sig = {}
 for name, ctor in OPS.MIXED_OPS.items():
@@ -95,3 +118,7 @@ def test_reference_callers_construct_on_the_swapped_registry():
     assert out["fixed_ref"] == out["fixed_ours"]
     assert all(out["signatures"].values()), out["signatures"]
     assert out["mixed_op_types"] == ["mr_gnas_amd.operations_lp"] or all("operations_lp" in t for t in out["mixed_op_types"])
+    # models.cell_lp swapped too (round 4): the reference's Network builds this package's cells under the same names
+    assert out["net_ref_swapped_cells"] == out["net_ref"]
+    assert all("cell_lp" in t and "mr_gnas_amd" in t or t.endswith("cell_lp") for t in out["swapped_cell_types"]), out["swapped_cell_types"]
+    assert len(out["cell_lp_exports"]) == 9, out["cell_lp_exports"]

@@ -620,9 +620,10 @@ def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
 @pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 0, 200), (66000, 200, 200, 200), (513, 64, 0, 40), (259, 400, 0, 8), (65537, 128, 0, 452),
                                              (300001, 128, 0, 128), (33, 200, 0, 200), (20000, 96, 0, 96), (9000, 52, 0, 300), (131073, 256, 0, 256)])
 def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
-    """The three forms of the split-core row GEMM compute the same sums in the same order: the default kernel with the
-    weight slabs shared through LDS (mode 0, gemm_x3s.hpp), the wave-autonomous kernel (mode 2) with accumulator-order
-    stores and with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1)).  Bias / ReLU / sigmoid, gate (+ stored
+    """The four forms of the split-core row GEMM compute the same sums in the same order: the default kernel with the
+    weight slabs shared through LDS (mode 0, gemm_x3s.hpp) with accumulator-order stores (the default) and on transposed
+    accumulators with 16-byte epilogue accesses (mrg_gemm_set_epilogue(2), round 4's comparison point), the wave-autonomous kernel
+    (mode 2) with accumulator-order stores and with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1)).  Bias / ReLU / sigmoid, gate (+ stored
     gate), row scale, accumulate -- bit-identical outputs; ragged last strips, partial last column tiles, two column blocks,
     both row-tile shapes, dual-source K."""
     from mr_gnas_amd._lib import call, ptr, stream_of
@@ -638,7 +639,7 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
     base = torch.randn(rows, K1, generator=gen).to(DEV)
     res = {}
     try:
-        for order in ((0, 0), (2, 0), (2, 1)):
+        for order in ((0, 0), (0, 2), (2, 0), (2, 1)):
             assert lib.mrg_gemm_set_mode(order[0]) == 0 and lib.mrg_gemm_set_epilogue(order[1]) == 0
             outs = []
             if K2 == 0:
@@ -663,7 +664,7 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
         lib.mrg_gemm_set_epilogue(0)
         lib.mrg_gemm_set_mode(0)
     assert len(res[(0, 0)]) > 0
-    for other in ((2, 0), (2, 1)):
+    for other in ((0, 2), (2, 0), (2, 1)):
         assert len(res[other]) == len(res[(0, 0)])
         for i, (x, y) in enumerate(zip(res[(0, 0)], res[other])):
             assert torch.equal(x, y), (other, i, float((x - y).abs().max()))

@@ -97,6 +97,37 @@ int main(int argc, char** argv) {
     }
     launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
   }
+  {   // round 4: transposed accumulators (16-byte epilogue accesses) against accumulator-order stores, every epilogue, bit for bit
+    std::vector<float> r0(rows * N), r1(rows * N), x0(rows * N), x1(rows * N);
+    float* AUX; hipMalloc(&AUX, rows * N * 4);
+    auto cmp = [&](const char* what, std::vector<float>& u, std::vector<float>& v) {
+      int64_t bad = 0; for (size_t i = 0; i < u.size(); ++i) bad += (u[i] != v[i]);
+      printf("   %s: %lld of %lld outputs differ between the two accumulator layouts\n", what, (long long)bad, (long long)u.size());
+    };
+    for (int e = 0; e < 4; ++e) {
+      if ((e == 2 || e == 3) && K1 != N) continue;
+      GemmArgs g = a;
+      const char* name = e == 0 ? "bias+act" : e == 1 ? "accumulate" : e == 2 ? "gate (+aux)" : "gate only";
+      if (e == 1) { g.Cin = C2; g.ld_cin = N; g.bias = nullptr; }
+      if (e == 2 || e == 3) { g.S = A1; g.ld_s = K1; g.aux = AUX; g.scale = 1.f / 3; if (e == 3) g.C = nullptr; }
+      for (int mode = 0; mode <= 2; mode += 2) {
+        gemm_epi_mode() = mode;
+        hipMemset(C, 0, rows * N * 4); hipMemset(AUX, 0, rows * N * 4);
+        char label[96]; snprintf(label, sizeof label, "x3s %s, %s", name, mode ? "transposed acc" : "acc-order");
+        timeit(label, [&] {
+          if (e == 0) launch_rowgemm_x3s<EPI_BIAS_ACT>(g, Bp, 0); else if (e == 1) launch_rowgemm_x3s<EPI_ACCUM>(g, Bp, 0);
+          else launch_rowgemm_x3s<EPI_GATE>(g, Bp, 0);
+        });
+        hipMemcpy((mode ? r1 : r0).data(), C, r0.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy((mode ? x1 : x0).data(), AUX, x0.size() * 4, hipMemcpyDeviceToHost);
+      }
+      cmp(name, r0, r1);
+      if (e >= 2) cmp("its gate", x0, x1);
+    }
+    gemm_epi_mode() = 2;
+    hipFree(AUX);
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
+  }
   if (x3p_eligible(a)) {
     hipMemset(C, 0, rows * N * 4);
     timeit("x3 persistent (gemm only)", [&] { launch_rowgemm_x3p<EPI_BIAS_ACT>(a, Bp, 0); });

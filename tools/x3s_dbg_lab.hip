@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   std::vector<float> hb((size_t)N * K); for (auto& v : hb) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
   hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  if (argc > 4) gemm_epi_mode() = atoi(argv[4]);
   const int nt = gemm_pick_nt(N);
   hipMalloc(&Bp, x3_bsplit_bytes(N, K, nt));
   launch_bsplit(B, K, 1, N, K, nt, Bp, 0);
@@ -22,6 +23,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 20; ++i) launch_rowgemm_x3s<EPI_BIAS_ACT>(a, Bp, 0);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("x3s dbg=%d rows=%lld K=%d N=%d: %.3f ms  %s\n", MRG_X3S_DBG, (long long)rows, K, N, ms / 20, hipGetErrorString(hipGetLastError()));
+  printf("x3s dbg=%d epilogue mode %d rows=%lld K=%d N=%d: %.3f ms  %s\n", MRG_X3S_DBG, gemm_epi_mode(), (long long)rows, K, N, ms / 20, hipGetErrorString(hipGetLastError()));
   return 0;
 }

@@ -74,6 +74,41 @@ int main(int argc, char** argv) {
     const double span = (double)(rt1 - rt0);
     any.push_back(t1 / span); both.push_back(t2 / span);
   }
+  {   // one CU's workgroups in time order (us since the first wave's start): start | k-loop from..to | stores issued | end
+    int shown = 0;
+    for (auto& kv : cu) {
+      if (shown++ != 37) continue;
+      struct Row { double t0, a, b, c, d; };
+      std::vector<Row> rows;
+      for (int64_t w = 0; w < nw; w += 4) {
+        const unsigned long long* q = &t[w * 24];
+        if (!q[20] || q[22] <= q[23]) continue;
+        const unsigned long long hw = q[21] & 0xffffffffull, xcc = q[21] >> 32;
+        const unsigned long long key = (xcc & 15) << 16 | ((hw >> 13) & 7) << 12 | ((hw >> 12) & 1) << 8 | ((hw >> 8) & 15);
+        if (key != kv.first) continue;
+        const double f = (double)(q[22] - q[23]) / (double)(q[20] - q[0]) / 100.0, b0 = (double)(q[23] - rt0) / 100.0;
+        rows.push_back({b0, b0 + (q[1] - q[0]) * f, b0 + (q[18] - q[0]) * f, b0 + (q[19] - q[0]) * f, b0 + (q[20] - q[0]) * f});
+      }
+      std::sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.t0 < y.t0; });
+      printf("timeline of one CU (key %llx), %zu workgroups:\n", (unsigned long long)kv.first, rows.size());
+      for (auto& r : rows) printf("   start %7.1f | k-loop %7.1f .. %7.1f | stores issued %7.1f | end %7.1f\n", r.t0, r.a, r.b, r.c, r.d);
+    }
+    // chip-wide: workgroups inside their k-loop / inside their epilogue, sampled every 10 us
+    const double span_us = (double)(rt1 - rt0) / 100.0;
+    printf("chip-wide occupancy (workgroups in k-loop | in epilogue) every 10 us:");
+    for (double x = 5; x < span_us; x += 10) {
+      int nl = 0, ne = 0;
+      for (int64_t w = 0; w < nw; w += 4) {
+        const unsigned long long* q = &t[w * 24];
+        if (!q[20] || q[22] <= q[23]) continue;
+        const double f = (double)(q[22] - q[23]) / (double)(q[20] - q[0]) / 100.0, b0 = (double)(q[23] - rt0) / 100.0;
+        const double a = b0 + (q[1] - q[0]) * f, b = b0 + (q[18] - q[0]) * f, d = b0 + (q[20] - q[0]) * f;
+        if (x >= a && x < b) ++nl; else if (x >= b && x < d) ++ne;
+      }
+      printf(" %d|%d", nl, ne);
+    }
+    printf("\n");
+  }
   printf("CUs seen %zu; share of the launch span with >= 1 workgroup of the CU inside its k-loop: median %.2f, with 2: %.2f\n", cu.size(), med(any), med(both));
   return 0;
 }
