@@ -365,9 +365,9 @@ int mrg_zero_bwd_apply(const float *g, const float *ent, const float *rel, const
 int64_t mrg_gemm_workspace_bytes(int K, int Nout);
 /* 0 (default): split core where possible, on the kernel that shares the pre-split weight slabs of a 128-row workgroup through
  * LDS (two workgroups per CU); 1: exact-f32 core only; 2: split core on the wave-autonomous one-wave-per-SIMD kernel (the
- * default of rounds 1-2); 3: split core on the persistent transposed-accumulator kernel; 4: split core on the
- * two-waves-per-SIMD kernel (64 rows x 4 / 3 column tiles per wave) for >= 65 536 rows, more than 128 output columns and a
- * plain epilogue.  2, 3 and 4 are tested comparison points with bit-identical results.  Process-wide. */
+ * default of rounds 1-2; also what mode 0 falls back to for operands the LDS-weight kernel does not take): a tested comparison
+ * point with bit-identical results.  Modes 3 / 4 of rounds 2-3 (persistent and two-waves-per-SIMD kernels)
+ * left the library in round 4 (tools/lab/).  Process-wide. */
 int mrg_gemm_set_mode(int mode);
 /* Store order of the split-core row GEMM's elementwise epilogues (bias / activation, gate, scale, accumulate):
  * 0 (default): accumulator-order 4-byte stores (two 128-byte row pieces per store instruction);

@@ -6,7 +6,7 @@
 //   f_dense_op       reference models/operations_lp.py:345-354   out = sigmoid(W [s ; s_in] + b) * s
 // One call handles one direction segment (rows with one weight matrix); the caller loops over
 // in / out / self.  MFMA-bound: 2*rows*K*D flop, K = 2D (or D for f_dense_last).
-#include "gemm_x3p.hpp"
+#include "gemm_dispatch.hpp"
 
 namespace mrg {
 

@@ -4,7 +4,7 @@
 // forward / input-gradient use the pipelined row GEMM; the weight gradient is a split-over-rows
 // GEMM (each workgroup reduces a chunk of rows into register-resident output tiles, partial
 // tiles are combined in a fixed order), also software-pipelined, and optionally dual-source.
-#include "gemm_x3p.hpp"
+#include "gemm_dispatch.hpp"
 
 namespace mrg {
 
@@ -932,7 +932,7 @@ extern "C" int64_t mrg_gemm_workspace_bytes(int K, int Nout) {
 }
 
 extern "C" int mrg_gemm_set_mode(int mode) {
-  if (mode < 0 || mode > 4) return MRG_E_ENUM;
+  if (mode < 0 || mode > 2) return MRG_E_ENUM;
   gemm_mode() = mode;
   return MRG_OK;
 }

@@ -121,13 +121,33 @@ class EdgeShard(RelGraph):
 # ---------------------------------------------------------------------------
 # collectives with adjoint backward
 # ---------------------------------------------------------------------------
+def _is_direct(group):
+    """A communicator of rccl.py (RCCL bound directly: stream-ordered launches, HIP-graph capturable) instead of a c10d group."""
+    return getattr(group, "is_direct_rccl", False)
+
+
 def _is_gloo(group):
-    return dist.get_backend(group) == "gloo"
+    return not _is_direct(group) and dist.get_backend(group) == "gloo"
+
+
+_OPNAME = {dist.ReduceOp.SUM: "sum", dist.ReduceOp.MAX: "max"}
+
+
+def all_reduce(t, op, group):
+    """In-place all-reduce of `t` over `group` (a c10d process group, None = the default one, or a direct RCCL communicator)."""
+    if _is_direct(group):
+        group.all_reduce(t, _OPNAME[op])
+    else:
+        dist.all_reduce(t, op=op, group=group)
 
 
 def reduce_scatter_tensor(out, padded, op, group, async_op=False):
     """dist.reduce_scatter_tensor over equal chunks; on gloo (no such primitive) all-reduce + slice of the SAME padded
-    tensor, so callers run identical chunk arithmetic on both backends.  Returns the async work handle or None."""
+    tensor, so callers run identical chunk arithmetic on both backends.  Returns the async work handle or None (a direct RCCL
+    communicator launches on the current stream: ordered by the stream itself, nothing to wait for)."""
+    if _is_direct(group):
+        group.reduce_scatter_tensor(out, padded, _OPNAME[op])
+        return None
     if not _is_gloo(group):
         return dist.reduce_scatter_tensor(out, padded, op=op, group=group, async_op=async_op)
     tmp = padded.clone()
@@ -139,6 +159,9 @@ def reduce_scatter_tensor(out, padded, op, group, async_op=False):
 
 def all_gather_into_tensor(full, mine, group):
     """dist.all_gather_into_tensor over equal chunks; on gloo the list form into the same output tensor."""
+    if _is_direct(group):
+        group.all_gather_into_tensor(full, mine)
+        return
     if not _is_gloo(group):
         dist.all_gather_into_tensor(full, mine, group=group)
         return
@@ -159,13 +182,13 @@ class _AllReduceSum(torch.autograd.Function):
         y = x if inplace else x.clone()
         if inplace:
             ctx.mark_dirty(x)
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(y, dist.ReduceOp.SUM, group)
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        all_reduce(g, dist.ReduceOp.SUM, ctx.group)
         return g, None, None
 
 
@@ -271,7 +294,7 @@ class _SyncBatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, total_rows, eps, group):
         stats = torch.stack((x.sum(0), (x * x).sum(0)))
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(stats, dist.ReduceOp.SUM, group)
         mean = stats[0] / total_rows
         var = (stats[1] / total_rows - mean * mean).clamp_(min=0)
         invstd = torch.rsqrt(var + eps)
@@ -286,7 +309,7 @@ class _SyncBatchNorm(torch.autograd.Function):
         xhat, weight, invstd = ctx.saved_tensors
         gw_local, gb_local = (g * xhat).sum(0), g.sum(0)
         red = torch.stack((gw_local, gb_local))
-        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=ctx.group)
+        all_reduce(red, dist.ReduceOp.SUM, ctx.group)
         gx = (g - red[1] / ctx.total - xhat * (red[0] / ctx.total)) * (weight * invstd)
         return gx, gw_local, gb_local, None, None, None
 
@@ -504,7 +527,7 @@ def all_reduce_gradients(tensors, group=None):
     tensors that received no gradient on this rank contribute zeros."""
     tensors = [t for t in tensors if t.requires_grad]
     flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(flat, dist.ReduceOp.SUM, group)
     off = 0
     for t in tensors:                                   # views of the one reduced buffer: no per-parameter copy
         n = t.numel()
@@ -548,5 +571,5 @@ class ShardedStep:
         for a in self.arch:
             a.grad = None
         total = loss.detach().clone()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce(total, dist.ReduceOp.SUM, self.group)
         self.last_loss = total

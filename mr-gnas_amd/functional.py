@@ -245,7 +245,14 @@ class _GateRow(torch.autograd.Function):
         for gW, gb, ga in zip(gWs, gbs, gas):
             gparams += [gW, gb, ga]
         gs = None
-        if getattr(ctx, "s_grad_folded_ptr", None) != gq.data_ptr():
+        folded = getattr(ctx, "s_grad_folded_ptr", None)
+        ctx.s_grad_folded_ptr = None
+        if folded is not None and folded != gq.data_ptr():
+            # the epilogue has ALREADY added its share (dz_r * u_seg) into the direct term of the gated partner; recomputing it here
+            # from another gradient tensor would count that share twice (advisor r3) -- the paired dense-filter node raises as well
+            raise _lib.MrgnasError("f_sparse_comp (row factor): the MixedOp epilogue folded the gradient w.r.t. s, but a different gradient "
+                                   "tensor reached the factor's node -- the factor has a second consumer, which the folded form does not support")
+        if folded is None:
             # nobody added dz_r * u_seg to the gradient w.r.t. s (the factor was multiplied out by plain tensor arithmetic)
             dz = gq * hvec
             gs = torch.empty_like(s)
@@ -367,7 +374,12 @@ class _AggRows(torch.autograd.Function):
         gh = g * keep if keep is not None else g
         node = ctx.fan_node
         if node is not None and ctx.mode == 0 and getattr(node, "gathered", None) is None:
-            node.gathered = (gh, g if ctx.add_self else None, graph)          # one gathered term per fan; further ones are materialised
+            # one gathered term per fan; further ones are materialised.  The hand-over bypasses autograd's input buffer (the edge
+            # carries None), which is what orders a gradient produced on a candidate's side stream before its consumer: the
+            # event below does that instead (advisor r3: MRG_MIXED_STREAMS >= 2)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(g.device))
+            node.gathered = (gh, g if ctx.add_self else None, graph, ev)
             return None, None, None, None, None
         gx = torch.empty(E + N, D, dtype=torch.float32, device=g.device)
         if ctx.add_self:
@@ -1025,7 +1037,7 @@ class _MixedEpilogue(torch.autograd.Function):
                 else:
                     sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
                     call("mrg_mix_colstats", (ypa, K_, rows, D, ptr(sums), ptr(ws), gb, st), nbytes=4 * D * rows * nz_rd)
-                    dist.all_reduce(sums, group=cfg.group)
+                    _all_reduce_sum(sums, cfg.group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:                                      # one multi-tensor launch instead of one per BatchNorm
                 torch._foreach_add_([b.num_batches_tracked for b in cfg.bns], 1)
@@ -1041,7 +1053,7 @@ class _MixedEpilogue(torch.autograd.Function):
         ctx.cfg, ctx.training, ctx.total, ctx.nz, ctx.nz_rd = cfg, training, total, nz, nz_rd
         ctx.save_for_backward(w, coef, *ys_nz)
         if cfg.chain is not None:
-            cfg.chain[0].ctx[cfg.chain[1]] = ctx
+            cfg.chain[0].register(cfg.chain[1], ctx)
         return out
 
     @staticmethod
@@ -1075,14 +1087,14 @@ class _MixedEpilogue(torch.autograd.Function):
             shared = cfg.chain[0].reduced_gradient_sums(cfg.chain[1], g, _MixedEpilogue._launch_bwd_reduce)
         if shared is not None:
             red_local, red = shared
+            cfg.chain[0].release(cfg.chain[1])
         else:
             red = torch.empty(K_, 3, D, dtype=torch.float32, device=dev)
             _MixedEpilogue._launch_bwd_reduce(ctx, g, red)
             red_local = red
             if cfg.group is not None and ctx.training:
-                import torch.distributed as dist
                 red = red.clone()
-                dist.all_reduce(red, group=cfg.group)
+                _all_reduce_sum(red, cfg.group)
         coef2 = torch.empty(K_, 2, D, dtype=torch.float32, device=dev)
         dw = torch.empty(K_, dtype=torch.float32, device=dev)
         call("mrg_mix_finalize_bwd", (ptr(red), K_, ctx.total, D, ptr(coef2), None, None, ptr(dw), st))
@@ -1181,6 +1193,16 @@ class PreparedEpilogue:
         return _MixedEpilogue.apply(self.cfg, w, *tensors)
 
 
+def _all_reduce_sum(t, group):
+    """In-place sum over the ranks of `group`: a c10d process group, or a communicator of rccl.py (RCCL bound directly -- one
+    stream-ordered launch on the current stream, which is what lets a sharded step be captured in a HIP graph)."""
+    if getattr(group, "is_direct_rccl", False):
+        group.all_reduce(t, "sum")
+    else:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+
+
 class StatChain:
     """ONE collective for the BatchNorm statistics of several MixedOp epilogues over row-sharded candidates (VERDICT r2 #4b).
     Forward: the column sums of every member are computed first (they do not depend on one another: an `addend` only enters the
@@ -1191,14 +1213,18 @@ class StatChain:
 
     def __init__(self, members, group, summed):
         import torch.distributed as dist
-        self.members, self.group, self.summed = members, group, summed
+        # Only counts are kept: the members' candidate tensors stay owned by their PreparedEpilogue (advisor r3: a chain that held
+        # `members` kept every [rows, D] candidate of every member alive until Python's cyclic collector ran).
+        self.group, self.summed = group, summed
+        self.ks = [len(m.cfg.bns) for m in members]
         self.ctx = [None] * len(members)
+        self.served = [False] * len(members)
         self.bwd = None                                    # (g data_ptr, [red_local_j], [red_global_j])
         self.sums = None
         cfgs = [m.cfg for m in members]
         if not members or not all(self._trains(c) for c in cfgs):
             return                                         # eval mode: fixed statistics, no collective at all
-        ks = [len(c.bns) for c in cfgs]
+        ks = self.ks
         first = next(y for y in _row_candidate_as_s(cfgs[0], self._ys(members[0])) if y is not None)
         D = first.shape[1]
         sums = torch.empty(sum(ks), 2, D, dtype=torch.float64, device=first.device)
@@ -1213,7 +1239,7 @@ class StatChain:
             call("mrg_mix_colstats", (ptr_array(ys), ks[j], rows, D, ptr(sums[off:off + ks[j]]), ptr(ws), _lib.gated_branch(m.cfg.gated), stream_of(y0)),
                  nbytes=4 * D * rows * nz_rd)
             off += ks[j]
-        dist.all_reduce(sums, group=group)
+        _all_reduce_sum(sums, group)
         self.sums, off = [], 0
         for k_ in ks:
             self.sums.append(sums[off:off + k_])
@@ -1229,6 +1255,19 @@ class StatChain:
         it = iter(f32c(t) for t in m.cand)
         return [next(it) if p else None for p in m.cfg.present]
 
+    def register(self, j, ctx):
+        """Member j's autograd context, needed only when the members share ONE backward reduction (`summed`).  cfg -> chain -> ctx ->
+        cfg is a reference cycle: release() breaks it as soon as the last member's backward has taken its slice."""
+        if self.summed:
+            self.ctx[j] = ctx
+
+    def release(self, j):
+        self.served[j] = True
+        if all(self.served):
+            self.ctx = [None] * len(self.ks)
+            self.bwd = None
+            self.served = [False] * len(self.ks)
+
     def reduced_gradient_sums(self, j, g, launch):
         """(red_local, red_global) of member j for upstream gradient g; `launch(ctx, g, red_out)` runs one member's reduction."""
         import torch.distributed as dist
@@ -1237,7 +1276,7 @@ class StatChain:
         if self.bwd is None or self.bwd[0] != g.data_ptr():
             if any(c is None for c in self.ctx):
                 return None
-            ks = [len(m.cfg.bns) for m in self.members]
+            ks = self.ks
             D = g.shape[1]
             red = torch.empty(sum(ks), 3, D, dtype=torch.float32, device=g.device)
             off, loc = 0, []
@@ -1246,7 +1285,7 @@ class StatChain:
                 loc.append(red[off:off + ks[i]])
                 off += ks[i]
             glob = red.clone()
-            dist.all_reduce(glob, group=self.group)
+            _all_reduce_sum(glob, self.group)
             off, gl = 0, []
             for k_ in ks:
                 gl.append(glob[off:off + k_])
@@ -1286,8 +1325,11 @@ def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales
         s_r, rb0, rb1 = spec
         D_ = s_r.shape[1]
         wants_grad = torch.is_grad_enabled() and (y.requires_grad or s_r.requires_grad)
+        # one float4 step per lane (KMAX == 1 in mrg_mix_bwd_apply's row dot) needs 16-byte aligned rows of EVERY tensor the kernels
+        # touch: an offset view would pass here and fail in the middle of loss.backward() (advisor r3)
+        aligned = all(t.data_ptr() % 16 == 0 for t in [s_r] + [t for t in ys if t is not None and t.dim() == 2])
         ok = (gated is not None and "row_k" not in gated and gated["s"].data_ptr() == s_r.data_ptr() and gated["s"].shape == s_r.shape
-              and ((D_ % 4 == 0 and D_ <= 256) or D_ <= 64))
+              and ((D_ % 4 == 0 and D_ <= 256 and aligned) or D_ <= 64))
         if ok and wants_grad:                              # the gated candidate's folded gradient store is where the gradient w.r.t. s goes
             rs_g = rowscale[gated["k"]]
             ok = rs_g is not None and rs_g[4] is not None and y.grad_fn is not None
@@ -1344,7 +1386,7 @@ class _CellZeroMixed(torch.autograd.Function):
                 import torch.distributed as dist
                 sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
                 call("mrg_zero_colstats", (*src, rows, D, ptr(sums), ptr(ws), st), nbytes=gathered)
-                dist.all_reduce(sums, group=group)
+                _all_reduce_sum(sums, group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
@@ -1377,7 +1419,7 @@ class _CellZeroMixed(torch.autograd.Function):
         if group is not None and ctx.training:
             import torch.distributed as dist
             red = red.clone()
-            dist.all_reduce(red, group=group)
+            _all_reduce_sum(red, group)
         coef2 = torch.empty(K_, 2, D, dtype=torch.float32, device=dev)
         dw = torch.empty(K_, dtype=torch.float32, device=dev)
         call("mrg_mix_finalize_bwd", (ptr(red), K_, ctx.total, D, ptr(coef2), None, None, ptr(dw), st))
@@ -1906,8 +1948,13 @@ class _Fanout(torch.autograd.Function):
         gs = [g for g in grads if g is not None]
         gathered = getattr(ctx, "gathered", None)
         if gathered is not None:                            # a reader (a_sum) left its gradient as a gather of an [N, D] tensor
-            gh, gself, graph = gathered
+            gh, gself, graph, ev = gathered
             ctx.gathered = None
+            cur = torch.cuda.current_stream(gh.device)
+            cur.wait_event(ev)                                # the producer's stream may not be this one
+            for t in (gh, gself):
+                if t is not None:
+                    t.record_stream(cur)                      # ... and its allocator must not recycle the blocks under this launch
             E, N, D = graph.num_edges(), graph.number_of_nodes(), gh.shape[1]
             if len(gs) <= 8 and all(g.is_cuda and g.shape == (E + N, D) for g in gs):
                 gs = [f32c(g) for g in gs]

@@ -87,6 +87,57 @@ def _supernet_step(case):
     assert repr(net.show_genotype(0)) == z["genotype0"]
 
 
+@pytest.mark.parametrize("case", ["supernet_tiny", "supernet_d24", "supernet_d200_sampled"])
+def test_supernet_step_through_the_reference_caller_formulation(case, monkeypatch):
+    """the literal caller of the reference (models/cell_lp.py:25-33,95-113: one operator call, nn.BatchNorm1d,
+    ReLU and a scaled add per candidate, Python sums; gathers materialised as models/model_search_lp.py:144-145,153-154) on this
+    package's HIP operators reproduces the reference's golden step too -- it is what `bench.py --caller reference` times."""
+    from mr_gnas_amd import cell_lp as CL
+    monkeypatch.setattr(CL, "CALLER", "reference")
+    _supernet_step(case)
+
+
+def test_cell_lp_on_plain_tensors():
+    """mr_gnas_amd.cell_lp.Cell called as the reference's model_search_lp.Network calls it -- plain [M, D] tensors gathered by
+    the caller, weight matrices indexed per MixedOp (models/model_search_lp.py:139-158, models/cell_lp.py:173-188) -- runs the
+    fused path (paired dense filters, gate-only / row-factor candidates, fused epilogue, fan-in sums) and agrees with the literal
+    formulation on the same parameters: output and every gradient."""
+    from mr_gnas_amd import cell_lp as CL
+    z = load_golden("supernet_d24")
+    n = z["node_id"].numel()
+    g = G.RelGraph(n, z["src"], z["dst"], z["edge_type"], z["norm"], device=DEV)
+    D = z["D"]
+    E = g.num_edges()
+    gen = torch.Generator().manual_seed(5)
+    cell = CL.Cell(1, 2, 2, D, 0.0).to(DEV)
+    cell.train()
+    x0 = torch.randn(E + n, D, generator=gen)
+    hr0 = torch.randn(E + n, D, generator=gen)
+    W = [torch.softmax(torch.randn(r, c, generator=gen), 1).to(DEV).requires_grad_(True)
+         for r, c in ((1, len(CL.PRE_OPS)), (3, len(CL.FIRST_OPS)), (2, len(CL.MIDDLE_OPS)), (5, len(CL.LAST_OPS)))]
+    gout = torch.randn(n, D, generator=gen).to(DEV)
+    res = {}
+    for caller in ("fused", "reference"):
+        CL.CALLER = caller
+        try:
+            x, hr = x0.clone().to(DEV).requires_grad_(True), hr0.clone().to(DEV).requires_grad_(True)
+            for p in list(cell.parameters()) + W:
+                p.grad = None
+            for m in cell.modules():                      # same running statistics at the start of both passes
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            out = cell(g, x, hr, *W)
+            out.backward(gout)
+            res[caller] = [out.detach(), x.grad, hr.grad] + [w.grad.clone() for w in W] + [p.grad.clone() for p in cell.parameters()]
+        finally:
+            CL.CALLER = "fused"
+    assert len(res["fused"]) == len(res["reference"])
+    for i, (a, b) in enumerate(zip(res["fused"], res["reference"])):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-3 * scale, (i, float((a - b).abs().max()), scale)
+    torch.testing.assert_close(res["fused"][0], res["reference"][0], rtol=1e-4, atol=2e-5)
+
+
 def test_sharded_step_world1_on_hip():
     """The relation-block sharded forward (RCCL process group of one rank) on the HIP kernels
     must reproduce the reference like the plain path does; multi-rank behaviour of the same
@@ -115,6 +166,87 @@ def test_sharded_step_world1_on_hip():
         grads_close(net, z, 2e-3, "sharded world=1")
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_step_frees_its_tensors_without_the_cyclic_collector():
+    """Advisor r3: functional.StatChain used to sit in a reference cycle (cfg -> chain -> autograd ctx -> cfg) and to hold every
+    member's candidates, so a sharded step's [rows, D] tensors stayed allocated until Python's cyclic GC ran.  With the collector
+    switched off, three sharded steps in a row must not grow the allocation."""
+    import gc
+    import os
+    import torch.distributed as dist
+    from mr_gnas_amd import dist as MD
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29633")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        z = load_golden("supernet_d200_sampled")
+        n = z["node_id"].numel()
+        net = S.SearchNetwork(DEV, z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0).to(DEV)
+        load_net_state(net, z)
+        net.train()
+        shard = MD.EdgeShard(n, z["src"], z["dst"], z["edge_type"], z["norm"], z["R"], 0, 1, DEV)
+        data, labels = z["data"].to(DEV), z["labels"].to(DEV)
+
+        def one():
+            sn = MD.ShardedSupernet(net, shard, z["node_id"])
+            ent, rel = sn.forward()
+            loss = sn.loss(ent, rel, data, labels, len(data))
+            loss.backward()
+            for p in list(net.parameters()) + net.arch_parameters():
+                p.grad = None
+
+        one()                                   # plans, workspaces and the allocator's pools settle
+        gc.collect()
+        gc.disable()
+        try:
+            used = []
+            for _ in range(3):
+                one()
+                torch.cuda.synchronize()
+                used.append(torch.cuda.memory_allocated())
+        finally:
+            gc.enable()
+        assert used[2] <= used[0] + (1 << 20), used     # no step leaves its tensors behind
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lazy_asum_gradient_is_ordered_across_candidate_streams(monkeypatch):
+    """Advisor r3: a_sum's input gradient is handed to the state's fan-in sum outside autograd's input buffer (functional._AggRows
+    -> _Fanout); with the candidates on side HIP streams the consumer must wait for the producer's stream.  Side streams forced on
+    a small graph with dropout inside a_sum, lazy hand-over against the materialised gradient (MRG_LAZY_ASUM=0), several times."""
+    from mr_gnas_amd import cell_lp as CL, functional as K
+    monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+    monkeypatch.setattr(CL, "MIXED_STREAMS", 4)
+    z = load_golden("supernet_d24")
+    n = z["node_id"].numel()
+    g = G.RelGraph(n, z["src"], z["dst"], z["edge_type"], z["norm"], device=DEV)
+    net = S.SearchNetwork(DEV, z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.3).to(DEV)    # drop_aggr 0.3
+    load_net_state(net, z)
+    net.load_alpha([z[f"alpha/{i}"].to(DEV) for i in range(5)])
+    net.train()
+    node_id, src_in, et = z["node_id"].to(DEV), z["src_in"].to(DEV), z["edge_type"].to(DEV)
+    data, labels = z["data"].to(DEV), z["labels"].to(DEV)
+
+    def grads(lazy):
+        monkeypatch.setattr(K, "LAZY_ASUM", lazy)
+        torch.manual_seed(11)                       # the same dropout masks
+        for p in list(net.parameters()) + net.arch_parameters():
+            p.grad = None
+        ent, rel = net(g, node_id, src_in, et)
+        net.get_loss(g, ent, rel, data, labels).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    ref = grads(False)
+    for rep in range(4):
+        junk = [torch.full((m,), 7.0, device=DEV) for m in (1000, 5000, 20000, 100000) for _ in range(4)]      # stir the allocator's pools
+        del junk
+        got = grads(True)
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6) + 1e-9, (rep, float((a - b).abs().max()))
 
 
 def test_cold_first_step_with_side_streams_matches_reference(monkeypatch):

@@ -261,7 +261,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     ref_gx = gy.double() @ W.double()
     errs = {}
     try:
-        for mode in (0, 1, 2, 3, 4):                # 2: one-wave kernel, 3: persistent variant, 4: two waves / SIMD where eligible (all opt-in)
+        for mode in (0, 1, 2):                      # 2: the one-wave kernel (opt-in comparison point)
             assert lib.mrg_gemm_set_mode(mode) == 0
             if K2 == 0:
                 out = K.linear(x, W, b, None)
@@ -278,7 +278,7 @@ def test_split_core_is_as_accurate_as_the_exact_f32_core(rows, K1, K2, Nout):
     finally:
         lib.mrg_gemm_set_mode(0)
     for i, scale in ((0, float(ref.abs().max())), (1, float(ref_gx.abs().max()))):
-        for mode in (0, 2, 3, 4):
+        for mode in (0, 2):
             assert errs[mode][i] <= 1.5 * errs[1][i] + 1e-6 * scale, (mode, errs, scale)
             assert errs[mode][i] <= 2e-5 * scale
 

@@ -1,12 +1,12 @@
 // Lab bench for the 3-way bf16 split GEMM core against the exact-f32 MFMA core: time + error vs float64.
-// build: hipcc --offload-arch=gfx950 -O3 -I mr-gnas_amd/csrc tools/gemm_x3_lab.hip -o /tmp/gemm_x3_lab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mr-gnas_amd/csrc -I tools/lab -I include tools/gemm_x3_lab.hip -o tools/labbin/gemm_x3_lab
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
-#include "gemm_x3p.hpp"
-#include "gemm_x3s.hpp"
+#include "gemm_dispatch.hpp"
+#include "gemm_x3p.hpp"        // tools/lab: the persistent and the two-waves-per-SIMD kernels (lab only since round 4)
 using namespace mrg;
 
 static float frand() { return (float)rand() / RAND_MAX - 0.5f; }

@@ -1,3 +1,5 @@
+// LAB ONLY since round 4 (it lost to gemm_x3s.hpp and ran only behind mrg_gemm_set_mode(3); build with
+// -I mr-gnas_amd/csrc -I tools/lab, see tools/gemm_x3_lab.hip).
 // Persistent form of the split-core row GEMM (gemm_x3.hpp) with transposed accumulators.
 //
 // What the lab measured on the round-1 kernel (tools/gemm_x3_lab.hip, rows 272 115, N = 200): K = 200 ran 0.236 ms of
@@ -327,67 +329,6 @@ inline int launch_rowgemm_x3p(GemmArgs a, const void* Bp, hipStream_t st) {
 #undef MRG_GOP3
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MRG_OK : (int)e;
-}
-
-// ---- dispatch between the two cores ---------------------------------------------------------------
-// mode 0 (default): split-bf16 core whenever the operands qualify and a workspace was given;
-// mode 3: the same arithmetic on the persistent kernel of this file (comparison point);
-// mode 4: the same arithmetic on the two-waves-per-SIMD kernel of gemm_x3w.hpp where it applies (comparison point);
-// mode 1: exact-f32 core only (v_mfma_f32_32x32x2_f32) -- the comparison point of the tests and of bench.py.
-// mode 2: the same arithmetic on the wave-autonomous one-wave-per-SIMD kernel of gemm_x3.hpp (rounds 1-2's default).
-// Since round 3 the default split-core kernel is gemm_x3s.hpp (weight slabs shared through LDS, 128-row workgroups, two per
-// CU): bit-identical results; alone 0.191 vs 0.22-0.23 ms at rows 272 115, K = N = 200 and equal at 558 771 rows, but inside the
-// supernet step every row-GEMM entry point gains 9-22 % (input gradients 10.3 -> 8.4 ms, fused a_max / a_mean 4.1 -> 3.2,
-// dense-filter forward 6.5 -> 5.9; 68.2 -> 65.5 ms / step, profiles/r3_rowgemm_lds_weight.txt).
-inline int& gemm_mode() { static int m = 0; return m; }
-
-// the split-core row GEMM of the current mode for launches that prepared their own weight split (grouped launches, fused aggregators)
-template <int EPI>
-inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
-  if (gemm_mode() != 2 && x3s_eligible(a)) return launch_rowgemm_x3s<EPI>(a, Bp, st);
-  return launch_rowgemm_x3<EPI>(a, Bp, st);
-}
-
-inline size_t gemm_workspace_bytes(int K, int N) {
-  const size_t split = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
-  const size_t transp = (size_t)K * N * sizeof(float);
-  return split > transp ? split : transp;
-}
-
-// B(n, k) = a.B[n * b_sn + k * b_sk] (a.ldb is ignored).  ws: gemm_workspace_bytes(K, N) bytes, may be NULL
-// when b_sk == 1 (then only the exact-f32 core is available).
-template <int EPI>
-inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStream_t st) {
-  if (a.rows <= 0) return MRG_OK;
-  if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
-  const int K = a.K1 + a.K2;
-  if (ws && gemm_mode() != 1 && x3_eligible(a)) {
-    launch_bsplit(a.B, b_sn, b_sk, a.N, K, gemm_pick_nt(a.N), ws, st);
-    // mode 3: the persistent, transposed-accumulator kernel above.  Measured (tools/gemm_x3_lab.hip, rows 272 115, N = 200):
-    // K = 200 0.246 ms vs 0.255 ms, K = 400 0.378 vs 0.382 ms -- no better than the one-tile-per-wave kernel, whose k-loop it
-    // shares: that loop runs at ~60 % of the MFMA micro-benchmark's rate whatever is removed from it, so hiding the
-    // prologue / epilogue latencies does not pay.  Kept opt-in (tested) as the comparison point; the default stays round 1's.
-    if (gemm_mode() == 3 && x3p_eligible(a)) return launch_rowgemm_x3p<EPI>(a, ws, st);
-    // mode 4: the two-waves-per-SIMD kernel (gemm_x3w.hpp) for plain epilogues.  Alone it is 12-23 % faster than the one-wave
-    // kernel (lab: 0.195 / 0.172 ms with non-temporal stores vs 0.223 ms at rows 272 115, K = N = 200) and 13 % faster inside a
-    // single-stream step (253 vs 290 us), but the step that runs its MixedOp candidates on four streams already fills the
-    // one-wave kernel's idle phases with the other candidates' kernels: 70.0-70.6 ms/step (one-wave, 4 streams) vs 70.5-71.4
-    // (two-wave, 4 streams) vs 71.1-71.5 (two-wave, 1 stream) on the same box.  The gate epilogue (three pointers per
-    // accumulator row) does not fit its 256 registers (331 vs 295 us) and dual-source K = 2D products gain nothing.
-    if constexpr (EPI != EPI_GATE) {
-      if (gemm_mode() == 4 && a.K2 == 0 && x3w_eligible(a)) return launch_rowgemm_x3w<EPI>(a, ws, st);
-    }
-    return launch_rowgemm_x3_mode<EPI>(a, ws, st);
-  }
-  if (b_sk != 1) {                                   // present B^T row-major to the f32 core
-    if (!ws) return MRG_E_WORKSPACE;
-    launch_transpose(a.B, (float*)ws, (int)(K), a.N, (int)b_sk, st);
-    a.B = (const float*)ws;
-    a.ldb = K;
-  } else {
-    a.ldb = (int)b_sn;
-  }
-  return launch_rowgemm<EPI>(a, st);
 }
 
 }  // namespace mrg

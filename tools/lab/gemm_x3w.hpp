@@ -1,3 +1,4 @@
+// LAB ONLY since round 4 (it ran only behind mrg_gemm_set_mode(4); build with -I mr-gnas_amd/csrc -I tools/lab).
 // Split-bf16 row GEMM, two waves per SIMD.
 //
 // What round 2 measured on rowgemm_x3_k (gemm_x3.hpp; tools/gemm_x3_lab.hip, profiles/r2_rowgemm_rounds.txt): with 224
