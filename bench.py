@@ -122,6 +122,14 @@ def parse():
     ap.add_argument("--resample", action="store_true",
                     help="sampled workloads only: draw a NEW step graph inside every timed step (device sampler, negative "
                          "sampling, graph build, index plans: reference search/mr_lp_search.py:187-214), so `value` pays for it")
+    ap.add_argument("--comm", default=os.environ.get("MRG_COMM", "direct"), choices=["direct", "c10d"],
+                    help="N > 1: 'direct' = RCCL bound through ctypes (mr_gnas_amd/rccl.py: stream-ordered launches, the step is captured in a "
+                         "HIP graph when every rank's capture succeeds; torch.distributed/gloo only bootstraps and times); 'c10d' = "
+                         "torch.distributed's nccl backend for the data path (rounds 1-3)")
+    ap.add_argument("--rehearse-shard", default=None, metavar="R/W",
+                    help="TIMING ONLY, one GPU: run rank R of a W-way sharded step (its relation block, its node chunk, every collective "
+                         "launch of the real run on a one-rank RCCL communicator; the other ranks' contributions are zeros)")
+    ap.add_argument("--no-shard-graph", action="store_true", help="N > 1 with --comm direct: do not capture the sharded step in a HIP graph")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -496,31 +504,51 @@ def main():
 
     from mr_gnas_amd import cell_lp as CL
     CL.CALLER = args.caller
-    sharded = world > 1 or os.environ.get("MRG_FORCE_SHARDED") == "1"     # the env switch rehearses the N>1 code on one GPU
-    if args.hip_graph:
+    rehearse = None
+    if args.rehearse_shard:
+        r_, w_ = (int(v) for v in args.rehearse_shard.split("/"))
+        if not (0 <= r_ < w_) or world != 1:
+            raise SystemExit("--rehearse-shard R/W needs 0 <= R < W and a single process")
+        rehearse = (r_, w_)
+    sharded = world > 1 or os.environ.get("MRG_FORCE_SHARDED") == "1" or rehearse is not None     # the env switch rehearses the N>1 code on one GPU
+    direct = sharded and args.comm == "direct"
+    comm = None
+    if args.hip_graph or direct:
         # a captured step runs on ONE stream: capturing the candidate / segment side streams of the full-size step
         # segfaults inside the HIP runtime (with and without RCCL in the capture)
         os.environ["MRG_MIXED_STREAMS"] = "1"
         os.environ["MRG_SEGMENT_STREAMS"] = "1"
+        CL.MIXED_STREAMS = 1
+        from mr_gnas_amd import functional as _KF
+        _KF.SEGMENT_STREAMS = 1
     if sharded:
-        if args.hip_graph:
-            # Capturing a step that contains RCCL collectives works (measured with an RCCL group of one rank: 300-edge graph
-            # 27.0 -> 12.2 ms/step, 30 000-edge graph 25.4 -> 18.0 ms/step, full graph captured and replayed) under two
-            # conditions found the hard way: c10d's watchdog must not poll events while the capture is open, and the step
-            # must run on ONE stream (capturing the candidate / segment side streams together with RCCL segfaults).
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-            os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
-            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
-            os.environ["MRG_MIXED_STREAMS"] = "1"
-            os.environ["MRG_SEGMENT_STREAMS"] = "1"
         import torch.distributed as dist
+        from mr_gnas_amd import dist as MD
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29671")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        from mr_gnas_amd import dist as MD
-        step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), rank, world)
-        barrier = dist.barrier
+        if direct:
+            # control plane on gloo (rendezvous, barriers, the max over ranks of the measured time): no c10d RCCL group exists, so no
+            # watchdog thread polls HIP events while a capture is open (what aborted round 3's sharded capture); data plane = rccl.py
+            from mr_gnas_amd import rccl
+            if rehearse is None:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                comm = rccl.Comm(rank, world, device)
+                barrier = dist.barrier
+            else:
+                comm = rccl.VirtualWorld(rehearse[0], rehearse[1], device)
+                barrier = lambda: None
+        else:
+            if args.hip_graph:
+                # Capturing a step that contains c10d collectives worked in round 2 and aborted in round 3 on the same settings (the
+                # watchdog polls an event recorded inside the capture: timing dependent) -- opt-in, see --comm direct
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+                os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+                os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            barrier = dist.barrier
+        s_rank, s_world = rehearse if rehearse is not None else (rank, world)
+        step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), s_rank, s_world, group=comm)
     elif args.workload == "fb15k237_fixed_d64":
         args.dim = 64
         step = FixedStep(args, device)
@@ -564,30 +592,47 @@ def main():
     run_step = step
     if args.resample and (args.hip_graph or sharded):
         raise SystemExit("--resample is a single-GPU eager mode")
-    if args.hip_graph and sharded and os.environ.get("MRG_GRAPH_SHARDED") != "1":
-        # measured in round 1: capturing a step with RCCL collectives kills the watchdog thread
-        # (hipErrorStreamCaptureUnsupported) in the default capture mode and segfaults in thread_local mode on the full graph.
-        # MRG_GRAPH_SHARDED=1 retries it with the watchdog's event polling switched off (see main()).
-        raise SystemExit("--hip-graph is only supported for the single-GPU step (MRG_GRAPH_SHARDED=1 to try it with RCCL)")
-    if args.hip_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread polls events while this thread captures; in the default (global)
-        # capture mode that poll is an error (hipErrorStreamCaptureUnsupported) and takes the process down
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            step()
-        run_step = graph.replay
-        log("one step captured in a HIP graph")
+    if args.hip_graph and sharded and not direct and os.environ.get("MRG_GRAPH_SHARDED") != "1":
+        # c10d collectives inside a capture: worked in round 2, aborted in round 3 (the watchdog polls an event recorded inside the
+        # capture).  MRG_GRAPH_SHARDED=1 retries it; the supported way is --comm direct (the default)
+        raise SystemExit("--hip-graph with --comm c10d is opt-in (MRG_GRAPH_SHARDED=1); use --comm direct")
+    capture = args.hip_graph or (direct and not args.no_shard_graph)
+    launch_mode = "eager"
+    if capture:
+        graph, ok = None, 1
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: another thread of the process (a c10d watchdog, when there is one) may touch the HIP runtime meanwhile
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step()
+        except Exception as e:                       # a failed capture is not fatal: the step stays eager in this same process
+            if args.hip_graph and not sharded:
+                raise
+            ok, graph = 0, None
+            log(f"capture failed ({type(e).__name__}: {str(e)[:160]}): the step stays eager")
+            torch.cuda.synchronize()
+        if sharded and world > 1:
+            # replay only if EVERY rank captured: a rank that replays while another launches eagerly would still rendezvous inside
+            # RCCL, but the agreement keeps the ranks' launch modes -- and their timings -- the same
+            import torch.distributed as dist
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok and graph is not None:
+            run_step = graph.replay
+            launch_mode = "hip graph replay"
+            log("one step captured in a HIP graph")
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides --------------------
     rows_local = int(getattr(step, "E_global", step.E)) // world + int(step.g.number_of_nodes())
     multi_stream = KF.FORK_MIN_ROWS <= rows_local
-    live = bool(dominant) and not args.hip_graph and not multi_stream
+    live = bool(dominant) and launch_mode == "eager" and not multi_stream
     if live:
         _lib.meter.start([dominant])
     barrier()
@@ -600,9 +645,9 @@ def main():
     dt = time.perf_counter() - t0
     dom_stats = (kernel_table(_lib.meter.stop()) if live else table) if dominant else {}
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    if sharded:
+    if sharded and world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=("cpu" if direct else device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -621,8 +666,9 @@ def main():
                    "matrix_core": ("exact f32 MFMA (v_mfma_f32_32x32x2_f32)" if args.exact_f32 else
                                    "f32 via 3-way bf16 split: 6 cross terms on v_mfma_f32_32x32x16_bf16, f32 accumulate "
                                    "(error vs float64 pinned <= 1.5x the exact-f32 core in tests)"),
-                   "parallelism": "single" if world == 1 else f"relation-block edge shards x{world} + RCCL",
-                   "launch": "hip graph replay" if args.hip_graph else "eager",
+                   "parallelism": ("single" if world == 1 and not sharded else
+                                   f"relation-block edge shards x{world} + RCCL ({'bound directly, stream-ordered' if direct else 'torch.distributed nccl backend'})"),
+                   "launch": launch_mode,
                    "caller": ("cell_lp.MixedOp on the fused HIP epilogue (this package's cell_lp.py / supernet.py)" if args.caller == "fused" else
                               "the reference's literal MixedOp formulation (models/cell_lp.py:25-33) on this package's operators"),
                    "step_graph": ("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
@@ -677,6 +723,12 @@ def main():
         out["config"]["layers"] = 1
         out["config"]["step"] = "fixed README genotype fwd + DistMult [B,N] + BCE + bwd + Adam"
         out["config"]["hbm_peak_GiB"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+    if rehearse is not None:
+        out["config"]["parallelism"] = (f"TIMING-ONLY rehearsal of rank {rehearse[0]} of {rehearse[1]} on one GPU: its relation block and node chunk, every collective "
+                                        f"launch on a one-rank RCCL communicator ({getattr(comm, 'launches', 0) // max(1, args.steps + args.warmup + 2)} per step); the other ranks contribute zeros")
+        out["config"]["rank_edges"] = int(step.E)
+        out["value"] = None
+        out["rehearsal_ms_per_step"] = round(ms_per_step, 3)
     if world == 1 and not sharded and not args.exact_f32 and not args.no_exact_f32_leg and not args.hip_graph and not fixed:
         # the same step with every GEMM on the exact-f32 MFMA pipe (v_mfma_f32_32x32x2_f32), next to the headline number
         lib.mrg_gemm_set_mode(1)
@@ -724,9 +776,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, state, step.model.arch_parameters())
     if rank == 0:
         print(json.dumps(out))
-    if sharded:
+    if comm is not None:
+        comm.destroy()
+    if sharded and world > 1 or (sharded and not direct):
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

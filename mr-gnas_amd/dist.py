@@ -94,6 +94,9 @@ class EdgeShard(RelGraph):
     """Rank-local view of a step graph: a relation block of edges + a node range."""
 
     def __init__(self, n, src, dst, etype, norm, num_rels, rank, world, device):
+        if torch.is_tensor(src) and src.is_cuda:
+            self._init_on_device(n, src, dst, etype, norm, num_rels, rank, world, device)
+            return
         src, dst, etype = (np.asarray(t.cpu() if torch.is_tensor(t) else t).astype(np.int64) for t in (src, dst, etype))
         norm = np.asarray(norm.cpu() if torch.is_tensor(norm) else norm, dtype=np.float32).reshape(-1)
         order = np.lexsort((np.arange(len(src)), dst, etype))          # (relation, dst, caller id)
@@ -108,6 +111,38 @@ class EdgeShard(RelGraph):
         self.node_lo, self.node_hi = lo[rank], lo[rank + 1]
         self.node_cuts = lo
         self.global_in_degree = torch.from_numpy(np.bincount(dst, minlength=n)).to(device)
+        self.cuts = cuts
+
+    def _init_on_device(self, n, src, dst, etype, norm, num_rels, rank, world, device):
+        """The same partition from device tensors (the host np.lexsort of a 544 230-edge list took longer than the
+        rank's step): ONE stable device sort by the key relation * n + dst (stable = ties in caller order, what the lexsort's third
+        key does), group boundaries by a difference + nonzero, and the cut arithmetic of relation_block_cuts on the boundary list
+        (a few thousand integers on the host).  Same cuts, same local edge order as the host path (tests/test_dist_cpu.py)."""
+        src, dst, etype = (t.to(device).long() for t in (src, dst, etype))
+        norm = norm.to(device).reshape(-1).float()
+        E = int(src.numel())
+        key = etype * int(n) + dst
+        skey, order = torch.sort(key, stable=True)
+        if E:
+            starts = torch.nonzero(skey[1:] != skey[:-1]).view(-1) + 1
+            bounds = np.concatenate(([0], starts.cpu().numpy(), [E]))
+            cuts = [0]
+            for k in range(1, world):
+                j = int(np.argmin(np.abs(bounds - k * E / world)))
+                cuts.append(max(int(bounds[j]), cuts[-1]))
+            cuts.append(E)
+        else:
+            cuts = [0] * (world + 1)
+        mine = order[cuts[rank]:cuts[rank + 1]]
+        RelGraph.__init__(self, n, src[mine], dst[mine], etype[mine], norm[mine], device=device)
+        self.rank, self.world = rank, world
+        self.global_edge_ids = mine
+        self.E_global = E
+        self._b0 = int((etype[mine] < num_rels).sum())
+        lo, self.node_chunk = node_chunks(n, world)
+        self.node_lo, self.node_hi = lo[rank], lo[rank + 1]
+        self.node_cuts = lo
+        self.global_in_degree = torch.bincount(dst, minlength=n)
         self.cuts = cuts
 
     def bounds(self):
@@ -544,6 +579,8 @@ class ShardedStep:
         N, R, node_id, gtri, samples, labels = inputs
         torch.manual_seed(args.seed)                      # identical parameters on every rank
         g = G.build_search_graph(len(node_id), R, gtri)
+        if torch.device(device).type == "cuda":
+            g = g.to(device)                              # the partition then runs on the device too (EdgeShard._init_on_device)
         src, dst, _ = g.edges(form="all")
         self.g = EdgeShard(len(node_id), src, dst, g.edata["e_type"], g.edata["norm"], R, rank, world, device)
         self.E, self.E_global = self.g.num_edges(), self.g.E_global

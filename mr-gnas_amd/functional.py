@@ -994,6 +994,13 @@ def _row_candidate_as_s(cfg, ys):
     return ys
 
 
+# Test instrumentation (tests/test_configs_gpu.py, "mask replay"): when set, called as MASK_TAP(bns, masks) right after a fused
+# epilogue's combine with the ReLU decision of every candidate, [rows, D] bool each, taken from the combine kernel ITSELF (one extra
+# launch per candidate with a one-hot weight vector: w_k * relu(bn_k(y_k)) with w_k = 1, so `> 0` is the kernel's own decision, not a
+# re-evaluation that could round differently).  None in the product.
+MASK_TAP = None
+
+
 class _MixedEpilogue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, w, *tensors):
@@ -1050,6 +1057,15 @@ class _MixedEpilogue(torch.autograd.Function):
                 coef[k, 3] = b.running_mean * invstd
         out = torch.empty(rows, D, dtype=torch.float32, device=dev)
         call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(w), ptr(addend), ptr(out), rows, D, gb, st), nbytes=4 * D * rows * (nz_rd + 1 + (addend is not None)))
+        if MASK_TAP is not None:
+            masks = []
+            for k in range(K_):
+                one = torch.zeros(K_, dtype=torch.float32, device=dev)
+                one[k] = 1.0
+                o = torch.empty(rows, D, dtype=torch.float32, device=dev)
+                call("mrg_mix_fwd", (ypa, K_, ptr(coef), ptr(one), None, ptr(o), rows, D, gb, st))
+                masks.append(o > 0)
+            MASK_TAP(cfg.bns, masks)
         ctx.cfg, ctx.training, ctx.total, ctx.nz, ctx.nz_rd = cfg, training, total, nz, nz_rd
         ctx.save_for_backward(w, coef, *ys_nz)
         if cfg.chain is not None:
@@ -1399,6 +1415,15 @@ class _CellZeroMixed(torch.autograd.Function):
                 coef[k, 3] = b.running_mean * invstd
         out = torch.empty(rows, D, dtype=torch.float32, device=dev)
         call("mrg_zero_fwd", (*src, ptr(coef), ptr(w), ptr(out), rows, D, st), nbytes=4 * D * rows)
+        if MASK_TAP is not None:
+            masks = []
+            for k in range(K_):
+                one = torch.zeros(K_, dtype=torch.float32, device=dev)
+                one[k] = 1.0
+                o = torch.empty(rows, D, dtype=torch.float32, device=dev)
+                call("mrg_zero_fwd", (*src, ptr(coef), ptr(one), ptr(o), rows, D, st))
+                masks.append(o > 0)
+            MASK_TAP(bns, masks)
         ctx.cfg, ctx.training, ctx.total, ctx.opc = cfg, training, total, opc
         ctx.save_for_backward(w, coef, ent, rel)
         return out

@@ -80,8 +80,17 @@ class Comm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(bootstrap, 0) if bootstrap is not None else 0, group=bootstrap)
             ctypes.memmove(ctypes.byref(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
         self._comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        # RCCL prints a version banner on the process's stdout when it initialises: keep stdout clean (bench.py prints ONE JSON line there)
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            with torch.cuda.device(self.device):
+                _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         self.launches = 0
 
     def size(self):

@@ -12,6 +12,16 @@ import torch.nn.functional as F
 from . import ops as O
 
 
+# Test instrumentation ("mask replay", tests/test_configs_gpu.py): RELU_HOOK(site, z) -> tensor replaces F.relu(z) at the ReLU
+# sites of the supernet -- site = the BatchNorm's state_dict prefix ("cells.0.cell_first._ops.1._ops.2.1.") or ("net", layer) --
+# so that a float64 run can be made to take another run's ReLU decisions.  None = plain F.relu.
+RELU_HOOK = None
+
+
+def _relu(site, z):
+    return F.relu(z) if RELU_HOOK is None else RELU_HOOK(site, z)
+
+
 def _sub(S, prefix):
     n = len(prefix)
     return {k[n:]: v for k, v in S.items() if k.startswith(prefix)}
@@ -77,7 +87,7 @@ def mixed_op(g, S, prefix, names, w, a, b):
     for k, name in enumerate(names):
         h = O.OPS[name](g, _sub(S, f"{prefix}_ops.{k}.0."), a, b)
         h = h if h.dtype == torch.float64 else h.float()      # reference: `.float()`; kept float64 when the tests run the checker in float64
-        out = out + w[k] * F.relu(_bn(S, f"{prefix}_ops.{k}.1.", h))
+        out = out + w[k] * _relu(f"{prefix}_ops.{k}.1.", _bn(S, f"{prefix}_ops.{k}.1.", h))
     return out
 
 
@@ -123,7 +133,7 @@ def supernet_forward(g, S, alphas, node_id, src_in, edge_type, num_rel_rows, lay
         ent = super_cell(g, S, f"cells.{i}.", nfirst, nlast, x, rel_emb[et_f], Wz, Wf, Wm, Wl)
         ent = _bn(S, "batchnorm_h.", ent)
         if i > 0 or layers == 1:                      # model_search_lp.py:147-148,156
-            ent = F.relu(ent)
+            ent = _relu(("net", i), ent)
         rel_emb = torch.matmul(rel_emb, S["w_rel"])
     return ent, rel_emb
 

@@ -59,18 +59,37 @@ def step_inputs(ds, negative, seed=0):
     return N, R, tri, samples, labels
 
 
-def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels):
+def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels, imposed=None):
     """The oracle restatement of one supernet step in float64 on the device; returns ent, rel, loss and
-    {name: grad}, [alpha grads]."""
+    {name: grad}, [alpha grads].  `imposed` ({site: bool mask}, the HIP run's ReLU decisions from functional.MASK_TAP): the run takes
+    THOSE decisions instead of its own (z * mask in place of relu(z)) and counts where its own would have differed -- "mask replay":
+    both runs then evaluate the same piecewise-linear function, so what is left between their gradients is rounding alone."""
     src, dst, _ = g.edges(form="all")
     og = OGraph(g.number_of_nodes(), src.cpu(), dst.cpu(), edge_type.cpu(), g.edata["norm"].cpu()).to(DEV, torch.float64)
     P = {k: v.detach().double().requires_grad_(True) for k, v in model.named_parameters()}
     al = [a.detach().double().requires_grad_(True) for a in model.arch_parameters()]
-    ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
-    loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
-    loss.backward()
+    flips, near = {}, {}
+
+    def hook(site, z):
+        if imposed is None or site not in imposed:
+            return F.relu(z)
+        m = imposed[site]
+        own = z > 0
+        diff = own != m
+        flips[site] = int(diff.sum())
+        if flips[site]:                                   # how close to zero the disputed pre-activations are (relative to the tensor's scale)
+            near[site] = float(z.detach()[diff].abs().max() / z.detach().abs().max().clamp(min=1e-30))
+        return z * m.to(z.dtype)
+
+    ON.RELU_HOOK = hook
+    try:
+        ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
+        loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
+        loss.backward()
+    finally:
+        ON.RELU_HOOK = None
     out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss.detach()), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
-               ga=[a.grad for a in al[:4]])
+               ga=[a.grad for a in al[:4]], flips=flips, near=near)
     del og, P, al, ent, rel, loss
     free()
     return out
@@ -92,7 +111,22 @@ def supernet_case(ds, D, negative):
             if p.dim() == 1:
                 p.add_(0.05 * torch.randn_like(p))
     model.train()
-    ent, rel = model(g, node_id, src, edge_type)
+    # the HIP run's own ReLU decisions, site by site (functional.MASK_TAP): site = the BatchNorm's state_dict prefix / ("net", layer)
+    names = {id(m): n + "." for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm1d)}
+    masks = {}
+
+    def tap(bns, ms):
+        if isinstance(bns, tuple):
+            masks[bns] = ms[0]
+        else:
+            for b, m in zip(bns, ms):
+                masks[names[id(b)]] = m
+
+    K.MASK_TAP = tap
+    try:
+        ent, rel = model(g, node_id, src, edge_type)
+    finally:
+        K.MASK_TAP = None
     loss = model.get_loss(g, ent, rel, samples_t, labels_t)
     loss.backward()
     torch.cuda.synchronize()
@@ -105,8 +139,12 @@ def supernet_case(ds, D, negative):
         a.grad = None
     free()
     ref = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t)
+    replay = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t, imposed=masks)
+    replay["sites"], replay["entries"] = len(masks), int(sum(m.numel() for m in masks.values()))
+    masks.clear()
+    free()
     return dict(model=model, g=g, node_id=node_id, src=src, edge_type=edge_type, R=R, N=N, samples=samples_t, labels=labels_t,
-                samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref)
+                samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref, replay=replay)
 
 
 # full-size gradient bound relative to a tensor's largest entry (f32 step against the float64 oracle over 5.6e5 rows).  The
@@ -116,6 +154,40 @@ GRAD_MEDIAN = 2.5e-4   # over the tensors of a step: 2x the measured median (C3:
 GRAD_P90 = 1e-3        # ... and 2x the measured 90th percentile (C3: 4.8e-4)
 ALPHA_RTOL = 5e-4      # architecture-parameter gradients: measured <= 1.2e-4
 OUT_RTOL = 1e-5        # outputs and loss: measured <= 1.8e-6 (north_star asks for 1e-4)
+
+
+REPLAY_RTOL = 1e-3     # gradients against the float64 run that takes the HIP run's ReLU decisions: per tensor, NO outlier clause
+
+
+def check_replay(hip, replay, what):
+    """the outlier clause of check_step is justified by MEASURING the flips.  `replay` is the float64 oracle made to
+    take the HIP run's ReLU decisions at every MixedOp / network ReLU site (mask replay): it reports how many decisions differ from
+    its own (the flips, each a pre-activation within rounding of zero), and against IT every gradient tensor must agree to
+    REPLAY_RTOL of its largest entry with no tolerated outliers at all."""
+    from conftest import record_margin
+    flips = replay["flips"]
+    total = sum(flips.values())
+    record_margin(what + " [mask replay]", f"ReLU decisions that differ from the float64 run's own ({replay['sites']} sites, {replay['entries']} entries)",
+                  total, max(replay["entries"], 1), 1e-5 * replay["entries"])
+    for site, n in sorted(flips.items(), key=lambda kv: -kv[1])[:12]:
+        if n:
+            record_margin(what + " [mask replay]", f"flips at {site} (largest disputed |z| / max|z| = {replay['near'].get(site, 0.0):.1e})", n, 1.0, float("inf"))
+    assert total <= 1e-5 * replay["entries"], f"{what}: {total} of {replay['entries']} ReLU decisions differ -- more than rounding explains"
+    assert all(v <= 1e-4 for v in replay["near"].values()), f"{what}: a disputed pre-activation is not near zero: {replay['near']}"
+    assert rel_err(hip["ent"], replay["ent"]) <= OUT_RTOL and abs(hip["loss"] - replay["loss"]) <= OUT_RTOL * max(1.0, abs(replay["loss"]))
+    bad = []
+    for k, b in replay["g"].items():
+        err, scale = grad_err(hip["g"][k], b)
+        tol = REPLAY_RTOL * max(scale, 1e-6) + 5e-6
+        record_margin(what + " [mask replay]", k, err, scale, tol, 0.0)
+        if err > tol:
+            bad.append(f"{k}: {err:.3e} (scale {scale:.3e})")
+    for i, (a, b) in enumerate(zip(hip["ga"], replay["ga"])):
+        err, scale = grad_err(a, b)
+        record_margin(what + " [mask replay]", f"alpha grad {i}", err, scale, ALPHA_RTOL * max(scale, 1e-8) + 1e-7)
+        assert err <= ALPHA_RTOL * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i} under mask replay: {err:.3e}"
+    print(f"{what}: mask replay: {total} flipped ReLU decisions in {replay['entries']} entries; gradients off beyond {REPLAY_RTOL:g}: {len(bad)}")
+    assert not bad, f"{what}: with the ReLU decisions replayed, {len(bad)} gradients still differ: " + " | ".join(bad[:12])
 
 
 def check_step(hip, ref, what):
@@ -177,6 +249,10 @@ def test_c2_fb15k237_supernet_step_matches_float64_oracle(fb_case):
     check_step(fb_case["hip"], fb_case["ref"], "C2 FB15k-237 supernet D=200")
 
 
+def test_c2_gradients_under_mask_replay(fb_case):
+    check_replay(fb_case["hip"], fb_case["replay"], "C2 FB15k-237 supernet D=200")
+
+
 def test_c4_sharded_step_world1_rccl_full_size(fb_case):
     """mr-gnas_amd/dist.py at FB15k-237 size: relation-block shard (world = 1: the whole graph, re-ordered by
     (relation, dst)), collectives through RCCL, SyncBN epilogues, flat gradient all-reduce -- against the plain
@@ -221,6 +297,7 @@ def test_c3_wn18rr_supernet_step_matches_float64_oracle():
         rel_hist = torch.bincount(c["edge_type"])
         assert float(rel_hist.sort(descending=True).values[:4].sum()) / c["g"].num_edges() > 0.45  # 4 of 22 directed relations hold half the edges
         check_step(c["hip"], c["ref"], "C3 WN18RR supernet D=200")
+        check_replay(c["hip"], c["replay"], "C3 WN18RR supernet D=200")
     finally:
         c.clear()
         free()

@@ -58,6 +58,14 @@ def test_world8_partition_of_the_wn18rr_shape():
         assert sh.node_hi - sh.node_lo <= sh.node_chunk and sh.node_cuts[-1] == n
     assert (seen == 1).all()
     assert max(sizes) <= 1.1 * g.num_edges() / 8, sizes
+    # the tensor formulation of the same partition (what EdgeShard runs for device tensors: one stable sort by relation * n + dst)
+    for rank in (0, 3, 7):
+        host = MD.EdgeShard(n, src, dst, et, g.edata["norm"], r, rank, 8, "cpu")
+        dev = MD.EdgeShard.__new__(MD.EdgeShard)
+        dev._init_on_device(n, src, dst, et, g.edata["norm"], r, rank, 8, "cpu")
+        assert host.cuts == dev.cuts and host.bounds() == dev.bounds()
+        assert torch.equal(host.global_edge_ids, dev.global_edge_ids)
+        assert torch.equal(host.edata["norm"], dev.edata["norm"]) and torch.equal(host.global_in_degree, dev.global_in_degree)
     cuts, chunk = MD.node_chunks(n, 8)
     assert chunk * 8 >= n and cuts[0] == 0 and cuts[-1] == n and all(b - a in (chunk, n - 7 * chunk) for a, b in zip(cuts, cuts[1:]))
     assert MD.node_chunks(5, 8) == ([0, 1, 2, 3, 4, 5, 5, 5, 5], 1) and MD.node_chunks(0, 3) == ([0, 0, 0, 0], 0)

@@ -1,0 +1,144 @@
+"""The sharded step on RCCL bound directly (mr_gnas_amd/rccl.py): communicator of one rank on the GPU box -- the collectives are
+real RCCL launches on the step's own HIP stream -- against the reference golden, eager and replayed from a HIP graph; the
+device-side relation-block partition against the host one.  Multi-rank arithmetic of the same code: tests/test_dist_cpu.py (gloo)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from mr_gnas_amd import dist as MD, supernet as S
+from test_nets_gpu import grads_close, load_net_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def comm():
+    from mr_gnas_amd import rccl
+    c = rccl.Comm(0, 1, DEV)
+    yield c
+    c.destroy()
+
+
+def _golden_net(case):
+    z = load_golden(case)
+    net = S.SearchNetwork(DEV, z["Nall"], z["R"], z["layers"], 1, 2, 2, z["D"], z["D0"], z["nbase"], 9.0, 0.0, 0.0).to(DEV)
+    load_net_state(net, z)
+    net.load_alpha([z[f"alpha/{i}"].to(DEV) for i in range(5)])
+    net.train()
+    return z, net
+
+
+def test_direct_rccl_collectives_of_one_rank(comm):
+    x = torch.randn(1000, 64, device=DEV)
+    y = x.clone()
+    comm.all_reduce(y, "sum")
+    out = torch.empty_like(x)
+    comm.reduce_scatter_tensor(out, x, "max")
+    full = torch.empty_like(x)
+    comm.all_gather_into_tensor(full, x)
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(out, x) and torch.equal(full, x)
+    with pytest.raises(Exception):
+        comm.reduce_scatter_tensor(torch.empty(10, device=DEV), torch.empty(30, device=DEV), "sum")
+
+
+@pytest.mark.parametrize("case", ["supernet_d24", "supernet_d200_sampled"])
+def test_sharded_step_on_direct_rccl_matches_reference(case, comm):
+    z, net = _golden_net(case)
+    n = z["node_id"].numel()
+    shard = MD.EdgeShard(n, z["src"].to(DEV), z["dst"].to(DEV), z["edge_type"].to(DEV), z["norm"].to(DEV), z["R"], 0, 1, DEV)
+    sn = MD.ShardedSupernet(net, shard, z["node_id"], group=comm)
+    before = comm.launches
+    ent, rel = sn.forward()
+    loss = sn.loss(ent, rel, z["data"].to(DEV), z["labels"].to(DEV), len(z["data"]))
+    loss.backward()
+    MD.all_reduce_gradients(list(net.parameters()) + net.arch_parameters()[:4], comm)
+    assert comm.launches - before >= 20                    # exchanges, statistics, layer all-gathers, the flat gradient all-reduce
+    torch.testing.assert_close(ent.cpu(), z["ent"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss.detach().cpu(), z["loss"], rtol=1e-4, atol=1e-6)
+    grads_close(net, z, 2e-3, "sharded, direct RCCL")
+
+
+def test_sharded_step_replays_from_a_hip_graph(comm):
+    """Forward + loss + backward + flat gradient all-reduce of the sharded step captured ONCE and replayed: the RCCL launches sit in
+    the graph like kernels (no c10d work objects, no watchdog).  The replayed loss and gradients are those of the eager step."""
+    z, net = _golden_net("supernet_d200_sampled")
+    n = z["node_id"].numel()
+    shard = MD.EdgeShard(n, z["src"].to(DEV), z["dst"].to(DEV), z["edge_type"].to(DEV), z["norm"].to(DEV), z["R"], 0, 1, DEV)
+    data, labels = z["data"].to(DEV), z["labels"].to(DEV)
+    params = list(net.parameters()) + net.arch_parameters()[:4]
+    sn = MD.ShardedSupernet(net, shard, z["node_id"], group=comm)
+    static = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        ent, rel = sn.forward()
+        loss = sn.loss(ent, rel, data, labels, len(data))
+        loss.backward()
+        MD.all_reduce_gradients(params, comm)
+        static["loss"], static["ent"] = loss.detach(), ent.detach()
+        static["grads"] = [p.grad for p in params]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()                                          # plans, workspaces, allocator pools
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager_loss = float(static["loss"])
+    eager_grads = [g.clone() for g in static["grads"]]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(static["loss"]) - eager_loss) <= 1e-6 * max(1.0, abs(eager_loss))
+    torch.testing.assert_close(static["ent"].cpu(), z["ent"], rtol=1e-4, atol=2e-5)
+    for a, b in zip(static["grads"], eager_grads):
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6) + 1e-9
+
+
+def test_device_partition_equals_the_host_partition():
+    """EdgeShard built from device tensors (stable device sort by relation * n + dst) cuts and orders exactly like the host
+    np.lexsort path: same cuts, same local edges in the same order, for every rank of a world of 8 -- on a graph whose largest
+    relation exceeds a rank's share (the WN18RR situation, reference utils/utils_rgcn.py:151's order)."""
+    rng = np.random.default_rng(5)
+    n, R, E = 3000, 6, 40000
+    et = rng.choice(2 * R, size=E, p=np.array([0.45, 0.25, 0.05, 0.05, 0.02, 0.02, 0.05, 0.05, 0.02, 0.02, 0.01, 0.01]))
+    src, dst = rng.integers(0, n, E), rng.integers(0, n, E)
+    norm = rng.random(E).astype(np.float32)
+    for rank in range(8):
+        host = MD.EdgeShard(n, src, dst, et, norm, R, rank, 8, DEV)
+        dev = MD.EdgeShard(n, torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV), torch.from_numpy(et).to(DEV),
+                           torch.from_numpy(norm).to(DEV), R, rank, 8, DEV)
+        assert host.cuts == dev.cuts and host.bounds() == dev.bounds()
+        assert torch.equal(host.global_edge_ids, dev.global_edge_ids)
+        for a, b in zip(host.edges(form="all")[:2], dev.edges(form="all")[:2]):
+            assert torch.equal(a, b)
+        assert torch.equal(host.edata["e_type"], dev.edata["e_type"]) and torch.equal(host.edata["norm"], dev.edata["norm"])
+        assert torch.equal(host.global_in_degree, dev.global_in_degree)
+
+
+def test_virtual_world_rehearsal_runs(comm):
+    """rccl.VirtualWorld (bench.py --rehearse-shard): rank 3 of 8 on one GPU -- timing only, values finite."""
+    from mr_gnas_amd import rccl
+    z, net = _golden_net("supernet_d24")
+    n = z["node_id"].numel()
+    vw = rccl.VirtualWorld(3, 8, DEV)
+    try:
+        shard = MD.EdgeShard(n, z["src"].to(DEV), z["dst"].to(DEV), z["edge_type"].to(DEV), z["norm"].to(DEV), z["R"], 3, 8, DEV)
+        sn = MD.ShardedSupernet(net, shard, z["node_id"], group=vw)
+        ent, rel = sn.forward()
+        lo = MD.node_ranges(len(z["data"]), 8)
+        loss = sn.loss(ent, rel, z["data"][lo[3]:lo[4]].to(DEV), z["labels"][lo[3]:lo[4]].to(DEV), len(z["data"]))
+        loss.backward()
+        MD.all_reduce_gradients(list(net.parameters()) + net.arch_parameters()[:4], vw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and ent.shape[0] == n and vw.launches >= 20
+    finally:
+        vw.destroy()
