@@ -441,6 +441,8 @@ class _LinReluAgg(torch.autograd.Function):
                  nbytes=4 * E * D + 8 * E + 4 * D * D + 4 * N * D * 4, flops=2 * E * D * D)
             ctx.mode, ctx.graph, ctx.fused = mode, graph, True
             ctx.save_for_backward(x, W, arg, mx)
+            if MASK_TAP is not None:                       # test instrumentation: which edge won, and whether the maximum is positive
+                MASK_TAP(("a_max", W.data_ptr()), [arg, mx > 0])
             return out
         if (mode == 1 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and hasattr(graph, "plan")
                 and _fused_agg_ws(N, D) > 0):
@@ -461,6 +463,8 @@ class _LinReluAgg(torch.autograd.Function):
                  nbytes=8 * N * D + 4 * E)
             ctx.mode, ctx.graph, ctx.fused = mode, graph, "mean"
             ctx.save_for_backward(x, W, bits)
+            if MASK_TAP is not None:                       # test instrumentation: the inner ReLU's decisions, one bit per message element
+                MASK_TAP(("a_mean", W.data_ptr()), [bits])
             return out
         y = torch.empty(E, D, dtype=torch.float32, device=x.device)
         gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", D, D), x)
@@ -536,6 +540,8 @@ class _LinReluPartial(torch.autograd.Function):
                  nbytes=4 * E * D + 8 * E + 4 * D * D + 4 * N * D * 3, flops=2 * E * D * D)
             ctx.mode, ctx.graph, ctx.fused = mode, graph, True
             ctx.save_for_backward(x, W, arg, mx)
+            if MASK_TAP is not None:                       # test instrumentation: which edge won, and whether the maximum is positive
+                MASK_TAP(("a_max", W.data_ptr()), [arg, mx > 0])
             return out, x[E:].clone()
         if (mode != 2 and FUSED_AMEAN and E >= FUSED_AMAX_MIN_ROWS and _fused_agg_ws(N, D) > 0):
             # the partial SUM of ReLU(linear) without the [E, D] messages (see _LinReluAgg): run sums in the GEMM epilogue + heads reducer

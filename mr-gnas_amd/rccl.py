@@ -9,7 +9,8 @@ kernels around them by the stream itself (no events, no host synchronisation).
 
 The library is the ``librccl.so`` PyTorch ships and has already loaded (one RCCL per process).  The communicator is bootstrapped
 over the existing ``torch.distributed`` group of any backend: rank 0 draws the ``ncclUniqueId`` and broadcasts its 128 bytes.
-``Comm`` duck-types what dist.py needs from a process group (``comm.py`` dispatches on it).
+``Comm`` duck-types what dist.py needs from a process group (dist.all_reduce / reduce_scatter_tensor / all_gather_into_tensor and
+functional._all_reduce_sum dispatch on ``is_direct_rccl``).
 
 Reference counterpart: none -- the reference is single-device (collectives NONE); the exchange steps are
 SURVEY section 8(e)'s.

@@ -110,16 +110,30 @@ def f_dense_last(g, P, a, b):
 
 
 # --- aggregators [M, D] -> [N, D] ---------------------------------------------
+# Test instrumentation ("mask replay", tests/test_configs_gpu.py): AGG_HOOK(kind, P, lin, g) -> aggregated [n, D] tensor or None
+# lets a float64 run take another run's decisions inside a_max / a_mean (which edge wins the maximum, which messages the inner
+# ReLU passes) instead of its own.  None (the default) = the reference's arithmetic.
+AGG_HOOK = None
+
+
 def a_max(g, P, a, b):
     # a4 -- reference models/operations_lp.py:223-235
-    m = F.relu(_lin(P, "linear", a[: g.E]))
-    return seg_max(m, g.dst, g.n) + a[g.E:]
+    lin = _lin(P, "linear", a[: g.E])
+    if AGG_HOOK is not None:
+        h = AGG_HOOK("a_max", P, lin, g)
+        if h is not None:
+            return h + a[g.E:]
+    return seg_max(F.relu(lin), g.dst, g.n) + a[g.E:]
 
 
 def a_mean(g, P, a, b):
     # a6 -- reference models/operations_lp.py:238-250
-    m = F.relu(_lin(P, "linear", a[: g.E]))
-    return seg_mean(m, g.dst, g.n) + a[g.E:]
+    lin = _lin(P, "linear", a[: g.E])
+    if AGG_HOOK is not None:
+        h = AGG_HOOK("a_mean", P, lin, g)
+        if h is not None:
+            return h + a[g.E:]
+    return seg_mean(F.relu(lin), g.dst, g.n) + a[g.E:]
 
 
 def a_sum(g, P, a, b, drop_aggr=0.0, training=True):

@@ -81,13 +81,41 @@ def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels
             near[site] = float(z.detach()[diff].abs().max() / z.detach().abs().max().clamp(min=1e-30))
         return z * m.to(z.dtype)
 
+    ids = {id(v): k for k, v in P.items()}
+
+    def agg_hook(kind, Pop, lin, og_):
+        key = (kind, ids.get(id(Pop["linear.weight"])))
+        if imposed is None or key not in imposed:
+            return None
+        from oracle import ops as OO
+        if kind == "a_max":                               # the HIP run's winning edge per (node, column) and "the maximum is positive"
+            arg, pos = imposed[key]
+            sel = lin.gather(0, arg.clamp(min=0).long()) * ((arg >= 0) & pos).to(lin.dtype)
+            own = OO.seg_max(F.relu(lin.detach()), og_.dst, og_.n)
+            d = (own - sel.detach()).abs()
+            flips[key] = int((d > 0).sum())
+            if flips[key]:
+                near[key] = float(d.max() / own.abs().max().clamp(min=1e-30))
+            return sel
+        bits = imposed[key][0]                            # a_mean: the inner ReLU's decisions, bit c % 32 of word c // 32 per message row
+        D_ = lin.shape[1]
+        m = ((bits.unsqueeze(-1) >> torch.arange(32, device=bits.device, dtype=torch.int32)) & 1).reshape(bits.shape[0], -1)[:, :D_].bool()
+        diff = (lin.detach() > 0) != m
+        flips[key] = int(diff.sum())
+        if flips[key]:
+            near[key] = float(lin.detach()[diff].abs().max() / lin.detach().abs().max().clamp(min=1e-30))
+        return OO.seg_mean(lin * m.to(lin.dtype), og_.dst, og_.n)
+
+    from oracle import ops as _OO
     ON.RELU_HOOK = hook
+    _OO.AGG_HOOK = agg_hook
     try:
         ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
         loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
         loss.backward()
     finally:
         ON.RELU_HOOK = None
+        _OO.AGG_HOOK = None
     out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss.detach()), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
                ga=[a.grad for a in al[:4]], flips=flips, near=near)
     del og, P, al, ent, rel, loss
@@ -115,8 +143,12 @@ def supernet_case(ds, D, negative):
     names = {id(m): n + "." for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm1d)}
     masks = {}
 
+    pnames = {p.data_ptr(): n for n, p in model.named_parameters()}
+
     def tap(bns, ms):
-        if isinstance(bns, tuple):
+        if isinstance(bns, tuple) and bns[0] in ("a_max", "a_mean"):          # decisions inside the fused aggregators, keyed by their Linear's name
+            masks[(bns[0], pnames[bns[1]])] = tuple(ms)
+        elif isinstance(bns, tuple):
             masks[bns] = ms[0]
         else:
             for b, m in zip(bns, ms):
@@ -140,7 +172,9 @@ def supernet_case(ds, D, negative):
     free()
     ref = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t)
     replay = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t, imposed=masks)
-    replay["sites"], replay["entries"] = len(masks), int(sum(m.numel() for m in masks.values()))
+    replay["sites"] = len(masks)
+    replay["entries"] = int(sum((m[0].numel() * (32 if m[0].dtype == torch.int32 and len(m) == 1 else 1)) if isinstance(m, tuple) else m.numel()
+                                for m in masks.values()))
     masks.clear()
     free()
     return dict(model=model, g=g, node_id=node_id, src=src, edge_type=edge_type, R=R, N=N, samples=samples_t, labels=labels_t,
@@ -169,7 +203,7 @@ def check_replay(hip, replay, what):
     total = sum(flips.values())
     record_margin(what + " [mask replay]", f"ReLU decisions that differ from the float64 run's own ({replay['sites']} sites, {replay['entries']} entries)",
                   total, max(replay["entries"], 1), 1e-5 * replay["entries"])
-    for site, n in sorted(flips.items(), key=lambda kv: -kv[1])[:12]:
+    for site, n in sorted(flips.items(), key=lambda kv: -kv[1])[:16]:
         if n:
             record_margin(what + " [mask replay]", f"flips at {site} (largest disputed |z| / max|z| = {replay['near'].get(site, 0.0):.1e})", n, 1.0, float("inf"))
     assert total <= 1e-5 * replay["entries"], f"{what}: {total} of {replay['entries']} ReLU decisions differ -- more than rounding explains"
