@@ -48,6 +48,11 @@ def _literal(h):
     return CALLER == "reference" or not (x.table if isinstance(x, K.LazyRows) else x).is_cuda
 
 
+def _tensor(y):
+    """The autograd tensor of a candidate (a functional.Candidate wraps it)."""
+    return y.y if isinstance(y, K.Candidate) else y
+
+
 def _plain(h):
     if isinstance(h, K.Fan):
         h = h.take()
@@ -112,8 +117,8 @@ class MixedOp(nn.Module):
                     if not paired:
                         paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take(), for_epilogue=True)
                     ys.append(paired[k])
-                elif row_ok and type(op) is OPS.f_sparse_op_comp:
-                    ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))
+                elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
+                    ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))      # a functional.Candidate: consumed by the epilogue only
                 else:
                     ys.append(op(g, fh.take(), fi.take()))
             prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
@@ -137,12 +142,12 @@ class MixedOp(nn.Module):
                 if pair is not None and k in pair:
                     paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b, for_epilogue=True)
                     y = paired[k]
-                    paired[pair[0] + pair[1] - k].record_stream(fork.main)
-                elif row_ok and type(op) is OPS.f_sparse_op_comp:
+                    _tensor(paired[pair[0] + pair[1] - k]).record_stream(fork.main)
+                elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
                     y = op(g, a, b, for_epilogue=True)
                 else:
                     y = op(g, a, b)
-            y.record_stream(fork.main)                 # consumed by the epilogue on the main stream
+            _tensor(y).record_stream(fork.main)        # consumed by the epilogue on the main stream
             ys.append(y)
         fork.join()
         prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())

@@ -93,6 +93,12 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_k(const float* __restrict__ X, 
 
 // circular correlation / convolution modes: per edge O(D^2) through an LDS copy of both rows
 //   CCORR: val[k] = sum_i x[i] * (y[(i+k) % D] * s)      CCONV: val[k] = s * sum_i x[i] * y[(k-i) % D]
+// VEC == 4 (D % 4 == 0), round 4: a lane owns four consecutive outputs k0 .. k0+3 and slides a REGISTER window over y.  The y row
+// is stored twice in LDS (z | z: no modulo), for CCONV index-reversed (z[m] = y[(D - m) % D]: conv(x, y)[k] = corr(x, z)[(D - k) % D], so
+// the lane's accumulators belong to the mirrored outputs and only the final store permutes).  Four steps of i cost ONE ds_read_b128
+// of the next four window values + ONE broadcast ds_read_b128 of x for sixteen multiply-adds; round 3's form read x[t] and four
+// y[(t + k) % D] words from LDS for every four multiply-adds and was bound by LDS issue (10.5 TF/s = 0.067 of the vector peak, 4.1 ms
+// per launch at the FB15k-237 shape).  VEC == 1 (odd D) keeps the element-wise form.  Sums run over i ascending in both.
 template <int VEC, int LPR, int KMAX, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict__ X, const int32_t* __restrict__ xi,
                                                         const float* __restrict__ Y, const int32_t* __restrict__ yi,
@@ -102,10 +108,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
                                                         int64_t n_chunks, float* __restrict__ out, float* __restrict__ ws_val, int D) {
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
-  __shared__ float lds[RPB * 2 * WIDTH];
+  constexpr int ROWF = VEC == 4 ? 3 * WIDTH : 2 * WIDTH;     // x | z | z   or   x | y
+  __shared__ __align__(16) float lds[RPB * ROWF];
   const int sl = threadIdx.x % LPR, rw = row_group_of_thread<LPR>();
   const int dv = D / VEC;
-  float* lx = lds + rw * 2 * WIDTH;
+  float* lx = lds + rw * ROWF;
   float* ly = lx + WIDTH;
   for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
     const int v = chunk_node[ch];
@@ -127,10 +134,25 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
         int c = sl + k * LPR;
         if (c < dv) {
           Vec<VEC> a = Vec<VEC>::load(xr + c * VEC), b = Vec<VEC>::load(yr + c * VEC);
+          if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(lx + c * 4) = a.v;
+            if (MODE == MRG_GCS_CCORR) {
+              *reinterpret_cast<float4*>(ly + c * 4) = b.v;
+              *reinterpret_cast<float4*>(ly + D + c * 4) = b.v;
+            } else {                            // z[m] = y[(D - m) % D]: y[4c + i] lands at m = (D - 4c - i) % D, in both copies
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            lx[c * VEC + i] = a[i];
-            ly[c * VEC + i] = b[i];
+              for (int i = 0; i < 4; ++i) {
+                const int m = (c * 4 + i) == 0 ? 0 : D - (c * 4 + i);
+                ly[m] = b[i];
+                ly[D + m] = b[i];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              lx[c * VEC + i] = a[i];
+              ly[c * VEC + i] = b[i];
+            }
           }
         }
       }
@@ -140,21 +162,38 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
       for (int k = 0; k < KMAX; ++k) {
         int c = sl + k * LPR;
         if (c < dv) {
-          float part[VEC];
-          int idx[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) { part[i] = 0.f; idx[i] = c * VEC + i; }
-          for (int t = 0; t < D; ++t) {
-            const float xv = lx[t];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              part[i] += xv * ly[idx[i]];
-              if (MODE == MRG_GCS_CCORR) { idx[i] = idx[i] + 1 == D ? 0 : idx[i] + 1; }
-              else { idx[i] = idx[i] == 0 ? D - 1 : idx[i] - 1; }
+          if constexpr (VEC == 4) {
+            // outputs k0 + jj (jj = 0..3) of corr(x, z): sum_i x[i] z[i + k0 + jj]; window w = z[i + k0 .. i + k0 + 3], wn the next four
+            const float* zp = ly + c * 4;
+            float4 w = *reinterpret_cast<const float4*>(zp);
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            for (int i = 0; i < D; i += 4) {
+              const float4 xv = *reinterpret_cast<const float4*>(lx + i);
+              const float4 wn = *reinterpret_cast<const float4*>(zp + i + 4);
+              p0 += xv.x * w.x;  p1 += xv.x * w.y;  p2 += xv.x * w.z;  p3 += xv.x * w.w;
+              p0 += xv.y * w.y;  p1 += xv.y * w.z;  p2 += xv.y * w.w;  p3 += xv.y * wn.x;
+              p0 += xv.z * w.z;  p1 += xv.z * w.w;  p2 += xv.z * wn.x; p3 += xv.z * wn.y;
+              p0 += xv.w * w.w;  p1 += xv.w * wn.x; p2 += xv.w * wn.y; p3 += xv.w * wn.z;
+              w = wn;
             }
-          }
+            acc[k][0] += p0 * s; acc[k][1] += p1 * s; acc[k][2] += p2 * s; acc[k][3] += p3 * s;
+          } else {
+            float part[VEC];
+            int idx[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[k][i] += part[i] * s;
+            for (int i = 0; i < VEC; ++i) { part[i] = 0.f; idx[i] = c * VEC + i; }
+            for (int t = 0; t < D; ++t) {
+              const float xv = lx[t];
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                part[i] += xv * ly[idx[i]];
+                if (MODE == MRG_GCS_CCORR) { idx[i] = idx[i] + 1 == D ? 0 : idx[i] + 1; }
+                else { idx[i] = idx[i] == 0 ? D - 1 : idx[i] - 1; }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[k][i] += part[i] * s;
+          }
         }
       }
     }
@@ -162,7 +201,18 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       int c = sl + k * LPR;
-      if (c < dv) acc[k].store(dst + c * VEC);
+      if (c < dv) {
+        if constexpr (VEC == 4 && MODE != MRG_GCS_CCORR) {
+          // the accumulators are corr(x, z)[k'] for k' = 4c .. 4c+3 = conv(x, y)[(D - k') % D]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int kp = c * 4 + i;
+            dst[kp == 0 ? 0 : D - kp] = acc[k][i];
+          }
+        } else {
+          acc[k].store(dst + c * VEC);
+        }
+      }
     }
   }
 }

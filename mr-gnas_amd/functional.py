@@ -8,6 +8,7 @@ price the kernels against the roofline.
 """
 import contextlib
 import os
+import weakref
 
 import torch
 
@@ -38,6 +39,11 @@ def same_rows(a, b):
     # empty tensors all share data_ptr 0 and are never aliases of each other
     return (a.numel() > 0 and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
             and a.dtype == b.dtype and a.requires_grad == b.requires_grad)
+
+
+def _same_memory(a, b):
+    """Do two tensors denote the same [rows, D] block of device memory (e.g. two Fan aliases of one state)?"""
+    return a is not None and b is not None and a.numel() > 0 and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
 
 
 def _cnt(plan, name):
@@ -194,16 +200,77 @@ def gate_last(s, W, b, a):
 ROW_FACTOR = os.environ.get("MRG_ROW_FACTOR", "1") == "1"     # lab switch: 0 = f_sparse_comp's output is stored for the epilogue
 
 
+class Link:
+    """Mailbox between ONE producing autograd node (a dense filter, the dense-filter pair, the scalar gate as a row factor) and the
+    MixedOp epilogue that is the only reader of its output(s).  The producer's wrapper creates it, hands it to the node's forward
+    (which keeps it on its ctx and fills in what the epilogue recomputes candidates from) and returns it inside the Candidate; the
+    epilogue's BACKWARD then writes the producer's first backward pass itself and says so here, and the producer's backward reads
+    it.  This replaces the attributes rounds 2-3 hung on tensors and on grad_fn objects: nothing is inferred from a
+    tensor's identity any more -- a Candidate either reaches mixed_epilogue_prepare with its Link or it is a plain stored tensor.
+
+    slot = which of the node's outputs (0; the pair: 0 = f_dense_comp, 1 = f_comp)."""
+
+    __slots__ = ("folded", "written", "gs_direct", "s", "gate", "row_h", "row_uvc", "row_written")
+
+    def __init__(self, slots=1):
+        self.folded = [False] * slots       # claimed by an epilogue: it will write this output's gradient as the producer's `dz`
+        self.written = [None] * slots       # address of the gradient buffer the epilogue wrote for the slot (checked on arrival)
+        self.gs_direct = None               # gated kinds: the direct term of the gradient w.r.t. s, written by the epilogue
+        self.s = self.gate = None           # what a gate-only candidate is recomputed from (the node's own saved tensors)
+        self.row_h = self.row_uvc = None    # row factor: h_r = t_r g (1 - g) and the collapsed gate vectors
+        self.row_written = None             # row factor: address of the [rows] gradient the epilogue wrote AND folded into gs
+
+    def claim(self, slot):
+        if self.folded[slot]:
+            return False                    # a second epilogue reads the same output: that one gets the stored form
+        self.folded[slot] = True
+        return True
+
+    def arrived(self, slot, g, what):
+        """In the producer's backward: was gradient `g` of output `slot` written by the epilogue in the folded form?  A folded slot
+        whose gradient is NOT the buffer the epilogue wrote means the output had a second consumer and autograd combined the two."""
+        if not self.folded[slot] or self.written[slot] is None:
+            return False
+        if self.written[slot] != g.data_ptr():
+            raise _lib.MrgnasError(f"{what}: the folded epilogue gradient was combined with another consumer's gradient; "
+                                   "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
+        return True
+
+
+class Candidate:
+    """What an operator's `for_epilogue=True` path hands to mixed_epilogue_prepare instead of a bare [rows, D] tensor.
+
+      kind "stored"     y = the operator's output; `rowscale` (norm, b1, scale_edge, scale_self, gated) lets the epilogue's gradient
+                        store perform the producer's first backward pass (dz = g * c_r [* s gate (1 - gate)], direct term)
+      kind "gate"       y = f_dense_comp's GATE; the candidate gate * s * c_r is recomputed wherever it is read (never stored)
+      kind "rowfactor"  y = f_sparse_comp's gate as ONE factor per row, [rows]; the candidate is s * y[:, None]
+
+    `y` is the tensor that takes part in autograd; `link` the producer's mailbox; `slot` the producer's output index."""
+
+    __slots__ = ("kind", "y", "s", "c", "rowscale", "link", "slot", "b0", "b1")
+
+    def __init__(self, kind, y, link=None, slot=0, s=None, c=None, rowscale=None, b0=0, b1=0):
+        self.kind, self.y, self.link, self.slot, self.s, self.c, self.rowscale, self.b0, self.b1 = kind, y, link, slot, s, c, rowscale, b0, b1
+
+    def materialize(self):
+        """The candidate as a plain [rows, D] tensor (for consumers other than the fused epilogue)."""
+        if self.kind == "stored":
+            return self.y
+        if self.kind == "rowfactor":
+            return self.s * self.y.unsqueeze(1)
+        return self.y * self.s * self.c.unsqueeze(1)
+
+
 class _GateRow(torch.autograd.Function):
     """f_sparse_comp as a ROW FACTOR: returns fvec [M] with  f_sparse_comp(s, s_in) == s * fvec[:, None]  bit for bit (the gate is
     one scalar per row: reference models/operations_lp.py:317-343).  Its consumer -- the MixedOp epilogue -- recomputes the
     candidate from s in every pass instead of reading a stored [M, D] tensor, and in backward returns the true gradient
     w.r.t. fvec (the row dots sum_c gy * s).  This node turns it into the parameter and s_in gradients; the part of the gradient
     w.r.t. s that goes through the gate (dz_r * u) is added by the epilogue's gradient store when it says so
-    (`s_grad_folded_ptr`), and formed here otherwise.  Arguments as _Gate."""
+    (Link.row_written), and formed here otherwise.  Arguments: the Link (or None), then as _Gate."""
 
     @staticmethod
-    def forward(ctx, s, s_in, norm, b0, b1, scale, *params):
+    def forward(ctx, link, s, s_in, norm, b0, b1, scale, *params):
         tied = s_in is not None and same_rows(s, s_in)
         s, s_in, norm = f32c(s), (None if tied else f32c(s_in)), f32c(norm)
         params = tuple(f32c(p) for p in params)
@@ -221,6 +288,9 @@ class _GateRow(torch.autograd.Function):
         call("mrg_gate_row_fwd", (ptr(s), ptr(s_in), ptr(norm), ptr(uvc), ptr(fvec), ptr(hvec), b0, b1, M, D, scale, st), nbytes=nb)
         ctx.save_for_backward(s, s_in, norm, uvc, hvec, *params)
         ctx.cfg = (b0, b1, scale, in_dim, tied)
+        ctx.link = link
+        if link is not None:
+            link.row_h, link.row_uvc = hvec, uvc
         return fvec
 
     @staticmethod
@@ -245,8 +315,9 @@ class _GateRow(torch.autograd.Function):
         for gW, gb, ga in zip(gWs, gbs, gas):
             gparams += [gW, gb, ga]
         gs = None
-        folded = getattr(ctx, "s_grad_folded_ptr", None)
-        ctx.s_grad_folded_ptr = None
+        folded = ctx.link.row_written if ctx.link is not None else None
+        if ctx.link is not None:
+            ctx.link.row_written = None
         if folded is not None and folded != gq.data_ptr():
             # the epilogue has ALREADY added its share (dz_r * u_seg) into the direct term of the gated partner; recomputing it here
             # from another gradient tensor would count that share twice (advisor r3) -- the paired dense-filter node raises as well
@@ -259,16 +330,16 @@ class _GateRow(torch.autograd.Function):
             for seg, (lo, hi) in enumerate(((0, b0), (b0, b1), (b1, M))):
                 if hi > lo:
                     torch.mul(dz[lo:hi, None], uvc[seg, :D][None, :], out=gs[lo:hi])
-        return (gs, gs_in, None, None, None, None, *gparams)
+        return (None, gs, gs_in, None, None, None, None, *gparams)
 
 
 def gate_comp_row_factor(s, s_in, norm, b0, b1, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self):
-    """f_sparse_comp as a row factor for mixed_epilogue: a [M] tensor tagged `_mrg_rowfactor`; the candidate is s * fvec[:, None]
-    (mixed_epilogue multiplies it out itself when it cannot recompute it in its kernels)."""
+    """f_sparse_comp as a row factor for mixed_epilogue: Candidate("rowfactor") around the [M] factor; the candidate is
+    s * fvec[:, None] (mixed_epilogue_prepare multiplies it out itself when it cannot recompute it in its kernels)."""
     s = f32c(s)
-    fvec = _GateRow.apply(s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self)
-    fvec._mrg_rowfactor = (s, int(b0), int(b1))
-    return fvec
+    link = Link()
+    fvec = _GateRow.apply(link, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, W_in, b_in, a_in, W_out, b_out, a_out, W_self, b_self, a_self)
+    return Candidate("rowfactor", fvec, link=link, s=s, b0=int(b0), b1=int(b1))
 
 
 # ---------------------------------------------------------------------------
@@ -360,7 +431,7 @@ class _AggRows(torch.autograd.Function):
         ctx.has = (arg is not None, keep is not None)
         # x is an alias handed out by a Fan: a_sum's gradient w.r.t. it is a gather of the [N, D] node gradient, which the fan-in
         # sum can read itself (mrg_sum_rows_gather) instead of receiving an [M, D] copy
-        ctx.fan_node = getattr(x, "_mrg_fan_node", None) if (LAZY_ASUM and mode == 0 and x.is_cuda) else None
+        ctx.fan_node = Fan.node_of(x) if (LAZY_ASUM and mode == 0 and x.is_cuda) else None
         return out
 
     @staticmethod
@@ -373,7 +444,7 @@ class _AggRows(torch.autograd.Function):
         E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
         gh = g * keep if keep is not None else g
         node = ctx.fan_node
-        if node is not None and ctx.mode == 0 and getattr(node, "gathered", None) is None:
+        if node is not None and ctx.mode == 0 and node.gathered is None:
             # one gathered term per fan; further ones are materialised.  The hand-over bypasses autograd's input buffer (the edge
             # carries None), which is what orders a gradient produced on a candidate's side stream before its consumer: the
             # event below does that instead (advisor r3: MRG_MIXED_STREAMS >= 2)
@@ -1133,8 +1204,7 @@ class _MixedEpilogue(torch.autograd.Function):
             pos = sum(cfg.present[:cfg.identity])
             for k in range(K_):
                 if (rs[k] is not None and rs[k][4] is not None and need_y[pos] and k != cfg.identity
-                        and rs[k][4].saved_tensors[0].data_ptr() == ys[cfg.identity].data_ptr()
-                        and rs[k][4].saved_tensors[0].shape == ys[cfg.identity].shape):
+                        and _same_memory(rs[k][4].s, ys[cfg.identity])):
                     add_from = (k, cfg.identity)
                     need_y[pos] = False                    # no gradient tensor of its own: None flows back to the alias
                     break
@@ -1146,11 +1216,10 @@ class _MixedEpilogue(torch.autograd.Function):
         if row_k is not None:                              # the row-factor candidate: a [rows] gradient w.r.t. its factor, no [rows, D] one
             row_dq = gys[row_k] if gys[row_k] is not None else torch.empty(rows, dtype=torch.float32, device=dev)
             gys[row_k] = None
-            node = cfg.gated["row_node"]
-            if node is not None:
-                node.s_grad_folded_ptr = row_dq.data_ptr()
-                gb = _lib.gated_branch(dict(cfg.gated, row_h=node.saved_tensors[4], row_uvc=node.saved_tensors[3],
-                                            row_ld=node.saved_tensors[3].shape[1]), row_dq)
+            rlink = cfg.gated["row_link"]
+            if rlink is not None:
+                rlink.row_written = row_dq.data_ptr()     # the factor's node checks that THIS buffer reaches it (one reader)
+                gb = _lib.gated_branch(dict(cfg.gated, row_h=rlink.row_h, row_uvc=rlink.row_uvc, row_ld=rlink.row_uvc.shape[1]), row_dq)
         n_out = sum(t is not None and t.dim() == 2 for t in gys_nz)
         if rs is not None and any(r is not None for r in rs):
             import ctypes
@@ -1168,9 +1237,9 @@ class _MixedEpilogue(torch.autograd.Function):
             for k in range(K_):
                 if gated[k]:
                     on[k] = 2
-            f_gs = [torch.empty_like(rs[k][4].saved_tensors[0]) if gated[k] else None for k in range(K_)]
-            f_s = ptr_array([rs[k][4].saved_tensors[0] if gated[k] else None for k in range(K_)])
-            f_gate = ptr_array([rs[k][4].saved_tensors[3] if gated[k] else None for k in range(K_)])
+            f_gs = [torch.empty_like(rs[k][4].s) if gated[k] else None for k in range(K_)]
+            f_s = ptr_array([rs[k][4].s if gated[k] else None for k in range(K_)])
+            f_gate = ptr_array([rs[k][4].gate if gated[k] else None for k in range(K_)])
             for k in range(K_):
                 if gated[k]:
                     rs[k][4].gs_direct = f_gs[k]
@@ -1186,7 +1255,7 @@ class _MixedEpilogue(torch.autograd.Function):
         if rs is not None:
             for k in range(K_):                       # the consumer checks that THIS buffer is what reaches it (no second reader of y)
                 if rs[k] is not None and gys[k] is not None:
-                    rs[k][5].prescaled_ptr[rs[k][6]] = gys[k].data_ptr()
+                    rs[k][5].written[rs[k][6]] = gys[k].data_ptr()
         dgam = [red_local[k, 1] for k in range(K_)]
         dbet = [red_local[k, 0] for k in range(K_)]
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
@@ -1317,48 +1386,48 @@ class StatChain:
 
 
 def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales=False, identity=None):
-    """mixed_epilogue without running it: returns a PreparedEpilogue."""
+    """mixed_epilogue without running it: returns a PreparedEpilogue.  ys[k]: None (f_zero), a [rows, D] tensor (a stored
+    candidate), or a Candidate from an operator's for_epilogue path (stored with a foldable first backward pass / gate-only /
+    row factor)."""
+    cands = [y if isinstance(y, Candidate) else None for y in ys]
+    ys = [c.y if c is not None else y for c, y in zip(cands, ys)]
     present = [y is not None for y in ys]
     # a candidate whose backward starts with a row scale of its incoming gradient (f_comp: dz = g * c) and whose output feeds
-    # ONLY this epilogue gets that scale folded into the epilogue's gradient store; its backward node is told to skip the pass
+    # ONLY this epilogue gets that scale folded into the epilogue's gradient store; its producer's Link is claimed for it
     rowscale = [None] * len(ys)
     if fold_row_scales:
-        for k, y in enumerate(ys):
-            spec = getattr(y, "_mrg_rowscale", None) if y is not None else None
-            node = y.grad_fn if y is not None else None
-            if spec is not None and node is not None and isinstance(getattr(node, "prescaled", None), list) and node.prescaled[spec[5]] is False:
-                # [4] gated form: the node holds s / gate and receives gs; [5] the consumer's node; [6] which of its outputs y is
-                rowscale[k] = spec[:4] + (node if spec[4] else None, node, spec[5])
-                node.prescaled[spec[5]] = True
+        for k, c in enumerate(cands):
+            if c is not None and c.rowscale is not None and c.link is not None and c.link.claim(c.slot):
+                # (norm, b1, scale_edge, scale_self, the Link when the producer is a gated filter -- it holds s / gate and receives
+                #  the direct term --, the Link, the producer's output slot)
+                rowscale[k] = c.rowscale[:4] + (c.link if c.rowscale[4] else None, c.link, c.slot)
     gated = None
-    for k, y in enumerate(ys):
-        spec = getattr(y, "_mrg_gated", None) if y is not None else None
-        if spec is not None:
+    for k, c in enumerate(cands):
+        if c is not None and c.kind == "gate":
             if gated is not None:
                 raise _lib.MrgnasError("mixed epilogue: one recomputed (gate-only) candidate at most")
-            gated = dict(k=k, s=spec[0], c=spec[1])
+            gated = dict(k=k, s=c.s, c=c.c)
     # the row-factor candidate (f_sparse_comp as fvec [rows]): recomputed as s * fvec[r] by the kernels when the gated candidate of
     # the same rows s is there to receive its gradient w.r.t. s; multiplied out by plain tensor arithmetic otherwise
     ys = list(ys)
-    for k, y in enumerate(ys):
-        spec = getattr(y, "_mrg_rowfactor", None) if y is not None else None
-        if spec is None:
+    for k, c in enumerate(cands):
+        if c is None or c.kind != "rowfactor":
             continue
-        s_r, rb0, rb1 = spec
+        y, s_r, rb0, rb1 = c.y, c.s, c.b0, c.b1
         D_ = s_r.shape[1]
         wants_grad = torch.is_grad_enabled() and (y.requires_grad or s_r.requires_grad)
         # one float4 step per lane (KMAX == 1 in mrg_mix_bwd_apply's row dot) needs 16-byte aligned rows of EVERY tensor the kernels
         # touch: an offset view would pass here and fail in the middle of loss.backward() (advisor r3)
         aligned = all(t.data_ptr() % 16 == 0 for t in [s_r] + [t for t in ys if t is not None and t.dim() == 2])
-        ok = (gated is not None and "row_k" not in gated and gated["s"].data_ptr() == s_r.data_ptr() and gated["s"].shape == s_r.shape
+        ok = (gated is not None and "row_k" not in gated and _same_memory(gated["s"], s_r)
               and ((D_ % 4 == 0 and D_ <= 256 and aligned) or D_ <= 64))
         if ok and wants_grad:                              # the gated candidate's folded gradient store is where the gradient w.r.t. s goes
             rs_g = rowscale[gated["k"]]
-            ok = rs_g is not None and rs_g[4] is not None and y.grad_fn is not None
+            ok = rs_g is not None and rs_g[4] is not None and y.requires_grad and c.link is not None
         if ok:
-            gated.update(row_k=k, row_f=y, b0=rb0, b1=rb1, row_node=y.grad_fn)
+            gated.update(row_k=k, row_f=y, b0=rb0, b1=rb1, row_link=c.link if wants_grad else None)
         else:
-            ys[k] = s_r * y.unsqueeze(1)
+            ys[k] = c.materialize()
     cfg = _MixCfg(list(bns), present, group, total_rows, False, rowscale, identity, gated)
     return PreparedEpilogue(cfg, [y for y in ys if y is not None], list(bns))
 
@@ -1528,7 +1597,7 @@ class _DenseFilter(torch.autograd.Function):
     kind 0: sigmoid(W[s;s_in]+b) * s * c   kind 1: (W[s;s_in]) * c,  c = scale * norm on edge rows."""
 
     @staticmethod
-    def forward(ctx, kind, s, s_in, norm, b0, b1, scale_edge, scale_self, *params):
+    def forward(ctx, link, kind, s, s_in, norm, b0, b1, scale_edge, scale_self, *params):
         s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
         params = tuple(f32c(p) for p in params)
         require_hip(s, s_in, norm, *params)
@@ -1536,6 +1605,9 @@ class _DenseFilter(torch.autograd.Function):
         st = stream_of(s)
         out = torch.empty_like(s)
         gate = torch.empty_like(s) if kind == 0 else None
+        ctx.link = link
+        if link is not None:                            # what an epilogue that folds this node's first backward pass reads
+            link.s, link.gate = s, (gate.detach() if gate is not None else None)
         K_ = 2 * D if s_in is not None else D
         ws3 = int(_lib.load().mrg_dense_filter3_workspace_bytes(D, K_)) if (GROUPED_SEGMENTS and all(params[2 * i] is not None for i in range(3))) else 0
         if ws3 > 0:                                     # the three direction segments in one weight-split + one grouped GEMM launch
@@ -1570,13 +1642,11 @@ class _DenseFilter(torch.autograd.Function):
         g = f32c(g)
         M, D = s.shape
         st = stream_of(s)
-        prescaled = bool(getattr(ctx, "prescaled", [False])[0])   # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already
-        if prescaled and getattr(ctx, "prescaled_ptr", [None])[0] != g.data_ptr():
-            # y had a second consumer: autograd summed its (unscaled) gradient into the epilogue's pre-scaled one
-            raise _lib.MrgnasError("dense filter: the folded epilogue gradient was combined with another consumer's gradient; "
-                                   "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
+        # a MixedOp epilogue wrote dz (and, kind 0, the direct term of gs) already?  (raises when y had a second consumer whose
+        # unscaled gradient autograd summed into the epilogue's pre-scaled one)
+        prescaled = ctx.link is not None and ctx.link.arrived(0, g, "dense filter")
         if prescaled and kind == 0:
-            gs = ctx.gs_direct
+            gs = ctx.link.gs_direct
             gs.record_stream(torch.cuda.current_stream())   # allocated by the epilogue's backward on ITS stream
         else:
             gs = torch.empty_like(s)
@@ -1603,7 +1673,7 @@ class _DenseFilter(torch.autograd.Function):
                 call("mrg_linear_bwd_weight3", (ptr(dz), ptr(s), ptr(s_in), ptr_array(gWs), ptr_array(gbs), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st),
                      nbytes=4 * M * (D + K_), flops=2 * M * K_ * D)
                 grads = [t for pair in zip(gWs, gbs) for t in pair]
-                return (None, gs, gs_in, None, None, None, None, None, *grads)
+                return (None, None, gs, gs_in, None, None, None, None, None, *grads)
         grads = []
         segs = ((0, b0, scale_edge, True), (b0, b1, scale_edge, True), (b1, M, scale_self, False))
         work = []
@@ -1643,7 +1713,7 @@ class _DenseFilter(torch.autograd.Function):
                                                ptr(w["gb"]), ptr(w["ws"]), rows, D, D if s_in is not None else 0, D, st),
                      nbytes=4 * rows * (D + K_), flops=2 * rows * K_ * D)
         fork.join()
-        return (None, gs, gs_in, None, None, None, None, None, *grads)
+        return (None, None, gs, gs_in, None, None, None, None, None, *grads)
 
 
 class _FoldHalves(torch.autograd.Function):
@@ -1673,24 +1743,26 @@ class _FoldHalves(torch.autograd.Function):
         return tuple(gWs[:n])
 
 
-def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_self, b_self, self_scale):
+def dense_filter_comp(kind, s, s_in, norm, b0, b1, W_in, b_in, W_out, b_out, W_self, b_self, self_scale, for_epilogue=False):
     """f_dense_comp (kind 0, self_scale 1/3) / f_comp (kind 1, self_scale 1).  When `s` and `s_in` are the same rows
     the three GEMMs run on folded [D, D] weights (half the flops forward, one input-gradient GEMM and a
-    half-width weight-gradient GEMM backward)."""
+    half-width weight-gradient GEMM backward).  for_epilogue: the result goes to mixed_epilogue_prepare and nowhere else -- a
+    Candidate whose Link lets that epilogue's gradient store perform this node's first backward pass."""
     if s_in is not None and same_rows(s, s_in):
         W_in, W_out, W_self = _FoldHalves.apply(W_in, W_out, W_self)
         s_in = None
     norm = f32c(norm)        # ONE float32 contiguous [>= b1] vector for the forward, its backward and a folded epilogue gradient
     if norm is not None and norm.numel() < int(b1):
         raise _lib.MrgnasError(f"dense filter: edge norm has {norm.numel()} entries, the edge rows need {int(b1)}")
-    y = _DenseFilter.apply(kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
+    fold = for_epilogue and FOLD_ROW_SCALE and f32c(s).is_cuda and torch.is_grad_enabled()
+    link = Link() if fold else None
+    y = _DenseFilter.apply(link, kind, s, s_in, norm, int(b0), int(b1), 1.0 / 3.0, float(self_scale),
                            W_in, b_in, W_out, b_out, W_self, b_self)
-    if FOLD_ROW_SCALE and y.grad_fn is not None and y.is_cuda:
+    if fold and y.requires_grad:
         # the backward begins with an elementwise pass over the incoming gradient (f_comp: dz = g * c; f_dense_comp: dz = g c s gate
         # (1 - gate) and the direct term g c gate; c = norm / 3 on edge rows, self_scale on self rows): a MixedOp epilogue that is
-        # the only reader of y writes its gradient in that form (mixed_epilogue(fold_row_scales=True)) and flips `prescaled`
-        y.grad_fn.prescaled, y.grad_fn.prescaled_ptr = [False], [None]
-        y._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, float(self_scale), kind == 0, 0)
+        # the only reader of y writes its gradient in that form (Candidate.rowscale + the Link it claims)
+        return Candidate("stored", y, link=link, slot=0, rowscale=(norm, int(b1), 1.0 / 3.0, float(self_scale), kind == 0))
     return y
 
 
@@ -1706,7 +1778,7 @@ class _DensePair(torch.autograd.Function):
     params: W_in, b_in, W_out, b_out, W_self, b_self of f_dense_comp, then W_in, W_out, W_self of f_comp (no biases)."""
 
     @staticmethod
-    def forward(ctx, s, s_in, norm, b0, b1, gate_only, *params):
+    def forward(ctx, link, s, s_in, norm, b0, b1, gate_only, *params):
         s, s_in, norm = f32c(s), f32c(s_in), f32c(norm)
         params = tuple(f32c(p) for p in params)
         require_hip(s, s_in, norm, *params)
@@ -1727,6 +1799,11 @@ class _DensePair(torch.autograd.Function):
                                        ptr(_ws(ws3, s)), b0, b1, M, D, st), nbytes=4 * M * (K_ + D), **work)
         ctx.cfg = (b0, b1)
         ctx.save_for_backward(s, s_in, norm, gate, *params)
+        ctx.link = link
+        if link is not None:
+            # detached: with gate_only the gate IS the node's first output -- a plain reference would close the cycle
+            # node -> link -> output -> grad_fn = node and keep every tensor of the step alive until the cyclic collector runs
+            link.s, link.gate = s, gate.detach()
         return out_d, out_c
 
     @staticmethod
@@ -1736,17 +1813,12 @@ class _DensePair(torch.autograd.Function):
         M, D = s.shape
         st = stream_of(s)
         g_d, g_c = f32c(g_d), f32c(g_c)
-        pres = list(getattr(ctx, "prescaled", [False, False]))
-        ptrs = getattr(ctx, "prescaled_ptr", [None, None])
-        for i, g in enumerate((g_d, g_c)):
-            if pres[i] and ptrs[i] != g.data_ptr():
-                raise _lib.MrgnasError("dense filter pair: the folded epilogue gradient was combined with another consumer's gradient; "
-                                       "call mixed_epilogue(fold_row_scales=False) when a candidate's output is read elsewhere")
+        pres = [ctx.link is not None and ctx.link.arrived(i, g, "dense filter pair") for i, g in enumerate((g_d, g_c))]
         K_ = 2 * D if s_in is not None else D
         dW, cW = [params[0], params[2], params[4]], list(params[6:9])
         # 1. dz of both candidates (+ the direct term of f_dense_comp's gs), unless the MixedOp epilogue's gradient store did it
         if pres[0]:
-            dz_d, gs = g_d, ctx.gs_direct
+            dz_d, gs = g_d, ctx.link.gs_direct
             gs.record_stream(torch.cuda.current_stream())
         else:
             dz_d, gs = torch.empty_like(s), torch.empty_like(s)
@@ -1778,7 +1850,7 @@ class _DensePair(torch.autograd.Function):
         call("mrg_linear_bwd_weight3", (ptr(dz_c), ptr(s), ptr(s_in), ptr_array(g_cW), ptr_array([None, None, None]), ptr(_ws(wsw, s)), b0, b1, M, D, K_ - D, D, st),
              **wwork)
         grads_d = [t for pair in zip(g_dW, g_dB) for t in pair]
-        return (gs, gs_in, None, None, None, None, *grads_d, *g_cW)
+        return (None, gs, gs_in, None, None, None, None, *grads_d, *g_cW)
 
 
 def dense_pair_available(D, tied):
@@ -1819,10 +1891,11 @@ def _gated_rowscale(norm, b1, M, scale_edge, scale_self, device):
 GATED_RECOMPUTE = os.environ.get("MRG_GATED_RECOMPUTE", "1") == "1"     # lab switch: 0 = f_dense_comp's output is stored for the epilogue
 
 
-def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights, gate_only=False):
+def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights, gate_only=False, for_epilogue=False):
     """(f_dense_comp(s, s_in), f_comp(s, s_in)) as one autograd node; dense_params = (W_in, b_in, W_out, b_out, W_self, b_self),
     comp_weights = (W_in, W_out, W_self).  Operands that are the same rows use the folded [D, D] weights.
-    gate_only: the first result is f_dense_comp's GATE, tagged `_mrg_gated` -- ONLY for mixed_epilogue, which recomputes the
+    for_epilogue: both results go to mixed_epilogue_prepare and nowhere else: two Candidates sharing the node's Link.
+    gate_only (with for_epilogue): the first is Candidate("gate") around f_dense_comp's GATE -- the epilogue recomputes the
     candidate's value gate * s * c wherever it reads it (the [rows, D] output is never written or re-read)."""
     dW, dB = list(dense_params[0::2]), list(dense_params[1::2])
     cW = list(comp_weights)
@@ -1834,16 +1907,20 @@ def dense_filter_pair(s, s_in, norm, b0, b1, dense_params, comp_weights, gate_on
     if norm is not None and norm.numel() < int(b1):
         raise _lib.MrgnasError(f"dense filter: edge norm has {norm.numel()} entries, the edge rows need {int(b1)}")
     s = f32c(s)
-    gate_only = bool(gate_only and s.is_cuda)
-    y_d, y_c = _DensePair.apply(s, s_in, norm, int(b0), int(b1), gate_only, dW[0], dB[0], dW[1], dB[1], dW[2], dB[2], *cW)
+    gate_only = bool(gate_only and for_epilogue and s.is_cuda)
+    fold = for_epilogue and FOLD_ROW_SCALE and s.is_cuda and torch.is_grad_enabled()
+    link = Link(2) if fold else None
+    y_d, y_c = _DensePair.apply(link, s, s_in, norm, int(b0), int(b1), gate_only, dW[0], dB[0], dW[1], dB[1], dW[2], dB[2], *cW)
+    if not for_epilogue:
+        return y_d, y_c
+    fold = fold and y_d.requires_grad
+    rs_d = (norm, int(b1), 1.0 / 3.0, 1.0 / 3.0, True) if fold else None
+    rs_c = (norm, int(b1), 1.0 / 3.0, 1.0, False) if fold else None
     if gate_only:
-        y_d._mrg_gated = (s, _gated_rowscale(norm, int(b1), s.shape[0], 1.0 / 3.0, 1.0 / 3.0, s.device))
-    if FOLD_ROW_SCALE and y_d.grad_fn is not None and y_d.is_cuda:
-        node = y_d.grad_fn
-        node.prescaled, node.prescaled_ptr = [False, False], [None, None]
-        y_d._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, 1.0 / 3.0, True, 0)
-        y_c._mrg_rowscale = (norm, int(b1), 1.0 / 3.0, 1.0, False, 1)
-    return y_d, y_c
+        c_d = Candidate("gate", y_d, link=link, slot=0, s=s, c=_gated_rowscale(norm, int(b1), s.shape[0], 1.0 / 3.0, 1.0 / 3.0, s.device), rowscale=rs_d)
+    else:
+        c_d = Candidate("stored", y_d, link=link, slot=0, rowscale=rs_d)
+    return c_d, Candidate("stored", y_c, link=link, slot=1, rowscale=rs_c)
 
 
 def dense_filter_single(s, s_in, W, b):
@@ -1851,7 +1928,7 @@ def dense_filter_single(s, s_in, W, b):
     if s_in is not None and same_rows(s, s_in):
         (W,) = _FoldHalves.apply(W)
         s_in = None
-    return _DenseFilter.apply(0, s, s_in, None, 0, 0, 1.0, 1.0, None, None, None, None, W, b)
+    return _DenseFilter.apply(None, 0, s, s_in, None, 0, 0, 1.0, 1.0, None, None, None, None, W, b)
 
 
 
@@ -1970,17 +2047,18 @@ class _Fanout(torch.autograd.Function):
     pairwise adds.  Aliases nobody reads cost nothing (their gradient stays None)."""
 
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, box):
         ctx.set_materialize_grads(False)
+        ctx.box = box                                       # mailbox of this batch of aliases (Fan.take / _AggRows.backward)
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = [g for g in grads if g is not None]
-        gathered = getattr(ctx, "gathered", None)
+        gathered = ctx.box.gathered
         if gathered is not None:                            # a reader (a_sum) left its gradient as a gather of an [N, D] tensor
             gh, gself, graph, ev = gathered
-            ctx.gathered = None
+            ctx.box.gathered = None
             cur = torch.cuda.current_stream(gh.device)
             cur.wait_event(ev)                                # the producer's stream may not be this one
             for t in (gh, gself):
@@ -1992,7 +2070,7 @@ class _Fanout(torch.autograd.Function):
                 out = torch.empty(E + N, D, dtype=torch.float32, device=gh.device)
                 call("mrg_sum_rows_gather", (ptr_array(gs), len(gs), ptr(f32c(gh)), ptr(f32c(gself)), ptr(graph.i32("dst")), E, E + N, D, ptr(out),
                                              stream_of(out)), nbytes=4 * D * (E + N) * (len(gs) + 1))
-                return out, None
+                return out, None, None
             gx = torch.empty(E + N, D, dtype=torch.float32, device=gh.device)      # shapes the kernel does not take: materialise
             if gself is not None:
                 gx[E:] = gself
@@ -2001,15 +2079,24 @@ class _Fanout(torch.autograd.Function):
             _seg_bwd(0, gh, graph, None, gx, None)
             gs.append(gx)
         if not gs:
-            return None, None
+            return None, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         if not gs[0].is_cuda or any(g.shape != gs[0].shape for g in gs):
             tot = gs[0]
             for g in gs[1:]:
                 tot = tot + g
-            return tot, None
-        return sum_buffers(gs), None
+            return tot, None, None
+        return sum_buffers(gs), None, None
+
+
+class _FanBox:
+    """Mailbox of one batch of Fan aliases: a reader whose gradient w.r.t. the alias is a gather of a small tensor (a_sum) leaves the
+    small tensor here instead of materialising [rows, D]; the batch's fan-in sum (_Fanout.backward) reads it."""
+    __slots__ = ("gathered",)
+
+    def __init__(self):
+        self.gathered = None
 
 
 class Fan:
@@ -2034,9 +2121,25 @@ class Fan:
             raise RuntimeError("Fan: more readers than announced")
         self.left -= 1
         if not self._views:
-            views = list(_Fanout.apply(self._root, self.BATCH))
+            self._box = _FanBox()
+            views = list(_Fanout.apply(self._root, self.BATCH, self._box))
             self._root = views.pop()                    # source of the next batch, if one is ever needed
             self._views = views
         v = self._views.pop()
-        v._mrg_fan_node = v.grad_fn                     # lets a reader leave its gradient with the fan-in sum (_AggRows.backward)
+        Fan._remember(v, self._box)                     # lets a reader leave its gradient with the fan-in sum (_AggRows.backward)
         return v
+
+    # alias tensor -> the mailbox of the fan-out batch it came from.  A side table keyed by the alias OBJECT's id (tensors compare
+    # elementwise, so they cannot key a dict themselves) holding a weak reference that removes the entry when the alias dies: a reader
+    # handed anything else -- a copy, a cast that allocates -- simply is not found and materialises its gradient as usual.
+    _NODE = {}
+
+    @staticmethod
+    def _remember(v, box):
+        key = id(v)
+        Fan._NODE[key] = (weakref.ref(v, lambda _r, key=key: Fan._NODE.pop(key, None)), box)
+
+    @staticmethod
+    def node_of(x):
+        hit = Fan._NODE.get(id(x))
+        return hit[1] if hit is not None and hit[0]() is x else None

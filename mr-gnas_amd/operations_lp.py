@@ -126,10 +126,13 @@ class f_dense_op_comp(nn.Module):
         self.W_out = nn.Linear(2 * D, D, bias=True)
         self.W_self = nn.Linear(2 * D, D, bias=True)
 
-    def forward(self, g, src_emb, src_emb_in):
+    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+        """for_epilogue: the result goes to functional.mixed_epilogue and nowhere else -- a functional.Candidate whose Link lets the
+        epilogue's gradient store perform this operator's first backward pass (cell_lp.MixedOp asks for it)."""
         b0, b1 = _bounds(g)
         return K.dense_filter_comp(0, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, self.W_in.bias,
-                                   self.W_out.weight, self.W_out.bias, self.W_self.weight, self.W_self.bias, 1.0 / 3.0)
+                                   self.W_out.weight, self.W_out.bias, self.W_self.weight, self.W_self.bias, 1.0 / 3.0,
+                                   for_epilogue=for_epilogue and src_emb.is_cuda)
 
 
 class f_comp_op(nn.Module):
@@ -140,25 +143,26 @@ class f_comp_op(nn.Module):
         self.W_out = nn.Linear(2 * D, D, bias=False)
         self.W_self = nn.Linear(2 * D, D, bias=False)
 
-    def forward(self, g, src_emb, src_emb_in):
+    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
         b0, b1 = _bounds(g)       # self rows are NOT scaled (reference :285-287)
         return K.dense_filter_comp(1, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, None,
-                                   self.W_out.weight, None, self.W_self.weight, None, 1.0)
+                                   self.W_out.weight, None, self.W_self.weight, None, 1.0, for_epilogue=for_epilogue and src_emb.is_cuda)
 
 
 def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=False):
     """(f_dense_comp(g, src_emb, src_emb_in), f_comp(g, src_emb, src_emb_in)) of one MixedOp as one autograd node when the
     shapes allow (functional.dense_filter_pair), else the two operators on their own.  for_epilogue: both results go to
-    functional.mixed_epilogue and nowhere else -- f_dense_comp's may then be its gate, tagged for the epilogue to recompute the
-    output from (functional.GATED_RECOMPUTE)."""
+    functional.mixed_epilogue and nowhere else -- two functional.Candidate values; f_dense_comp's may then be its GATE, which the
+    epilogue recomputes the output from (functional.GATED_RECOMPUTE)."""
     D = src_emb.shape[1]
     tied = src_emb_in is not None and K.same_rows(src_emb, src_emb_in)
     if not (src_emb.is_cuda and K.dense_pair_available(D, tied)):
-        return op_dense(g, src_emb, src_emb_in), op_comp(g, src_emb, src_emb_in)
+        return op_dense(g, src_emb, src_emb_in, for_epilogue=for_epilogue), op_comp(g, src_emb, src_emb_in, for_epilogue=for_epilogue)
     b0, b1 = _bounds(g)
     dp = (op_dense.W_in.weight, op_dense.W_in.bias, op_dense.W_out.weight, op_dense.W_out.bias, op_dense.W_self.weight, op_dense.W_self.bias)
     cw = (op_comp.W_in.weight, op_comp.W_out.weight, op_comp.W_self.weight)
-    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw, gate_only=for_epilogue and K.GATED_RECOMPUTE)
+    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw, gate_only=for_epilogue and K.GATED_RECOMPUTE,
+                               for_epilogue=for_epilogue)
 
 
 class f_dense_op(nn.Module):
