@@ -737,8 +737,12 @@ __global__ __launch_bounds__(MRG_BLOCK, 2) void rowgemm_dma_k(GemmArgs a) {
   gemm_epilogue<NT, EPI>(a, acc, row0 + wave * 32, col0, li, lh, row0 + GBM <= a.rows);
 }
 
+#ifndef MRG_FORCE_NT4
+#define MRG_FORCE_NT4 0     // lab: column blocks of four tiles whatever the width (N = 200: 2 blocks, 8 tiles, A read twice)
+#endif
 inline int gemm_pick_nt(int ncols) {
   int t = (ncols + 31) / 32;
+  if (MRG_FORCE_NT4 && t > 4) return 4;
   if (t <= 1) return 1;
   if (t <= 2) return 2;
   if (t <= 4) return 4;

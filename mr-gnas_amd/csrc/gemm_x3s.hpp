@@ -58,8 +58,11 @@ __device__ unsigned long long* mrg_x3s_trace;
 // tile -- a lane then holds ONE row's columns 8g + 4 lh + {0..3} in registers 4g..4g+3 -- so that the epilogue loads and stores
 // 16 bytes per lane (gemm_epilogue_tr below): 4 * NT store instructions per strip instead of 16 * NT.  Same products, same
 // order of accumulation: bit-identical results.
+#ifndef MRG_X3S_WPS4
+#define MRG_X3S_WPS4 2      // lab: waves per SIMD the NT <= 4 instances are compiled for (3 = at most 168 registers)
+#endif
 template <int NT, int EPI, bool DUAL, bool TR>
-__global__ __launch_bounds__(256, 2) void rowgemm_x3s_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
+__global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
   constexpr int GBM = 128;
   constexpr int NCH = NT * 3;                   // 1 KB chunks (64 lanes x 16 B) of one pre-split B slab of this column block
   constexpr int BSLAB = NCH * 1024;
