@@ -190,7 +190,7 @@ ALPHA_RTOL = 5e-4      # architecture-parameter gradients: measured <= 1.2e-4
 OUT_RTOL = 1e-5        # outputs and loss: measured <= 1.8e-6 (north_star asks for 1e-4)
 
 
-REPLAY_RTOL = 1e-3     # gradients against the float64 run that takes the HIP run's ReLU decisions: per tensor, NO outlier clause
+REPLAY_RTOL = 5e-4     # gradients against the float64 run that takes the HIP run's ReLU decisions: per tensor, NO outlier clause
 
 
 def check_replay(hip, replay, what):
