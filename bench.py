@@ -533,8 +533,31 @@ def main():
             from mr_gnas_amd import rccl
             if rehearse is None:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
-                comm = rccl.Comm(rank, world, device)
                 barrier = dist.barrier
+                # The directly bound communicator has only ever run with ONE rank (no multi-GPU node was available to the build):
+                # bring it up, push one all-reduce through it, and let the ranks AGREE (over gloo) that it works everywhere; if any rank
+                # failed, every rank falls back to torch.distributed's nccl backend for the data path (eager, no capture).
+                ok = 1
+                try:
+                    comm = rccl.Comm(rank, world, device)
+                    probe = torch.ones(8, device=device)
+                    comm.all_reduce(probe, "sum")
+                    torch.cuda.synchronize()
+                    ok = int(bool((probe == world).all()))
+                except Exception as e:
+                    log(f"direct RCCL communicator failed on rank {rank} ({type(e).__name__}: {str(e)[:160]})")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    log("falling back to --comm c10d on every rank")
+                    if comm is not None:
+                        try:
+                            comm.destroy()
+                        except Exception:
+                            pass
+                    comm = dist.new_group(backend="nccl")          # the data-path group; the gloo default group keeps the control plane
+                    direct = False
             else:
                 comm = rccl.VirtualWorld(rehearse[0], rehearse[1], device)
                 barrier = lambda: None
@@ -647,7 +670,7 @@ def main():
     log(f"timed {args.steps} steps in {dt:.3f} s")
     if sharded and world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=("cpu" if direct else device))
+        t = torch.tensor([dt], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -776,7 +799,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, state, step.model.arch_parameters())
     if rank == 0:
         print(json.dumps(out))
-    if comm is not None:
+    if comm is not None and getattr(comm, "is_direct_rccl", False):
         comm.destroy()
     if sharded and world > 1 or (sharded and not direct):
         import torch.distributed as dist

@@ -321,3 +321,18 @@ def test_sync_batch_norm_eval_uses_running_statistics():
     bn.eval()
     x = torch.randn(7, 5)
     torch.testing.assert_close(MD.sync_batch_norm(x, bn, 7, None), bn(x))
+
+
+def test_rccl_binding_loads_and_matches_the_header():
+    """mr_gnas_amd/rccl.py binds the librccl.so PyTorch ships (no GPU needed to load it): every entry point the sharded step launches
+    is there, the unique id is the header's 128 opaque bytes, the dtype / op codes are the header's enum values
+    (/opt/rocm/include/rccl/rccl.h: ncclFloat32 = 7, ncclFloat64 = 8, ncclInt32 = 2, ncclSum = 0, ncclMax = 2)."""
+    import ctypes
+    from mr_gnas_amd import rccl
+    lib = rccl.load()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather", "ncclGetErrorString"):
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(rccl._UniqueId) == 128
+    assert rccl._DTYPE[torch.float32] == 7 and rccl._DTYPE[torch.float64] == 8 and rccl._DTYPE[torch.int32] == 2
+    assert rccl._OP == {"sum": 0, "max": 2, "min": 3}
+    assert lib.ncclGetErrorString(0).decode().lower().startswith("no error")
