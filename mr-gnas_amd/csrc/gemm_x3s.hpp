@@ -20,7 +20,8 @@
 #include "gemm_x3.hpp"
 
 // lab switches (tools/x3s_dbg_lab.hip, timing only -- wrong results): 1 no epilogue, 2 no A loads after the prologue,
-// 4 no B DMA after the prologue, 8 no barriers, 16 phase stamps, 64 no split arithmetic, 128 no fragment reads after the first slab.  (A "no splits" switch left asynchronous register fills unconsumed and
+// 4 no B DMA after the prologue, 8 no barriers, 16 phase stamps, 64 no split arithmetic, 128 no fragment reads after the first slab,
+// 256 nothing but the epilogue, 512 the tile's stores paced through the k-loop (use with 1).  (A "no splits" switch left asynchronous register fills unconsumed and
 // faulted: every asm load's registers must be read after its wait -- see gemm_x3.hpp.)
 #ifndef MRG_X3S_DBG
 #define MRG_X3S_DBG 0
@@ -117,6 +118,9 @@ __global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s
   else gemm_epilogue<NT, EPI>(a, acc, roww, col0, li, lh, row0 + GBM <= a.rows);
   return;
 #endif
+#if MRG_X3S_DBG & 512
+  float* paced_c = (roww + 32 <= a.rows && col0 + NT * 32 <= a.ldc + 31) ? a.C + (roww + 4 * lh) * a.ldc + (col0 + li < a.N ? col0 + li : a.N - 1) : nullptr;
+#endif
   // ---- A: this lane's fragment of a slab = row li, k = slab * 16 + lh * 8 + {0..3, 4..7}: two 16-byte loads
   int64_t rc = roww + li < a.rows ? roww + li : a.rows - 1;
   if (rc < 0) rc = 0;
@@ -179,6 +183,20 @@ __global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s
     H[q] = h; M[q] = m; L[q] = l;
   };
   auto nb_issued = [&](int j) { return (j >= -2 && j + 2 < nslab) ? NBW : 0; };   // B DMAs issued at the top of slab j (j < 0: prologue)
+  // lab switch 512: stores a wave issues inside slab j (they count in vmcnt like the loads); 0 in the product
+  auto paced_in = [&](int j) -> int {
+#if MRG_X3S_DBG & 512
+    if (paced_c == nullptr || j < 0 || j >= nslab) return 0;
+    const int np = (NT + 1) / 2, per = (16 * NT + nslab * np - 1) / (nslab * np);
+    int n = 0;
+    for (int pp = 0; pp < np; ++pp)
+      for (int q = 0; q < 3; ++q) n += (q < per && (j * np + pp) * per + q < 16 * NT) ? 1 : 0;
+    return n;
+#else
+    (void)j;
+    return 0;
+#endif
+  };
   constexpr int NP = (NT + 1) / 2;                          // column-tile pairs per slab
   constexpr bool PIPE = MRG_X3S_PIPE && (NP % 2 == 0);      // the pair buffers alternate across slabs: their parity must not depend on s
   auto nbw = [&](int j) { return (j >= 1 && j < nslab) ? NBW : 0; };              // PIPE: DMAs of B(j) that stand BEHIND older A loads (B(0) leads)
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s
     read_b(0, R, bq2[0][0]);
     if (NT > 1) read_b(1, R, bq2[0][1]);
     if constexpr (ST && !(MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBW + 4) : "memory");
-    else if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2);
+    else if (has_next && !(MRG_X3S_DBG & 6)) wait_vmcnt(nb_issued(s - 1) + 2 + nb_issued(s) + 2 + paced_in(s - 2) + paced_in(s - 1));
     if (has_next && (MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #pragma unroll
@@ -319,6 +337,22 @@ __global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // ... then up to three VALU
       }
       __builtin_amdgcn_sched_barrier(0);
+#if MRG_X3S_DBG & 512
+      // lab (timing only, wrong results): the tile's 16 * NT dword stores PACED through the k-loop -- two or three behind every tile
+      // pair, every (tile, register) address of the strip written once per tile -- instead of the burst behind it (switch 1 drops that)
+      if (paced_c != nullptr) {
+        const int slot = s * NP + pp;                       // 0 .. nslab * NP - 1
+        const int per = (16 * NT + nslab * NP - 1) / (nslab * NP);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int idx = slot * per + j;                   // which (tile, register) of the strip: run-time, only the address depends on it
+          if (j < per && idx < 16 * NT) {
+            const int tn = idx >> 4, tr = idx & 15;
+            paced_c[(int64_t)((tr & 3) + 8 * (tr >> 2)) * a.ldc + tn * 32] = acc[(pp * 2 + (j & 1)) % NT][(R * 4 + j) & 15];
+          }
+        }
+      }
+#endif
     }
     if (NT < 4 && has_next) {
 #pragma unroll
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? MRG_X3S_WPS4 : 2)) void rowgemm_x3s
       ch = nh; cm = nm; cl = nl;
       if constexpr (!PIPE) {
       if constexpr (ST && !(MRG_X3S_DBG & 6)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 4) : "memory");
-      else if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2);                       // this wave's share of B(s+1) is in LDS
+      else if (!(MRG_X3S_DBG & 6)) wait_vmcnt(2 + nb_issued(s) + 2 + paced_in(s - 1) + paced_in(s));     // this wave's share of B(s+1) is in LDS
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(MRG_X3S_DBG & 8)) __builtin_amdgcn_s_barrier();   // ... and everybody's; all reads of this slab's buffer are done
       }
