@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # the guide's measured float4 copy rate: what an H
 # eight entry-point names, so "the entry point with the largest time" (rounds 1-2) named the wrong kernel.  `roofline` is the
 # family with the largest summed time: its summed algorithmic work / its summed time.
 KERNEL_FAMILIES = {
-    "row_gemm [rowgemm_x3s_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
+    "row_gemm [rowgemm_x3s_k rowgemm_x3s8_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
                                  "mrg_dense_filter_fwd3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd"],
     "weight_gradient [wgrad_x3v_k]": ["mrg_linear_bwd_weight", "mrg_linear_bwd_weight3"],
     "mixedop_epilogue [mix_colstats_k mix_fwd_k mix_bwd_reduce_k mix_bwd_apply_k]": [

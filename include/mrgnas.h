@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 10   /* 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 11   /* 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -381,6 +381,10 @@ int mrg_gemm_set_mode(int mode);
  * measured slower for the plain epilogue and in the whole step, kept as a tested comparison point.
  * Process-wide. */
 int mrg_gemm_set_epilogue(int mode);
+/* 1 (default): a split-core row GEMM whose output is eight 32-column tiles wide (225 .. 256 columns: D = 256) and that has no
+ * direction groups, a single source and no gate epilogue runs as ONE column block (128 accumulator registers per lane, a weight ring of
+ * two slabs): the activation operand is read once.  0: two four-tile column blocks (rounds 1-3).  Bit-identical.  Process-wide. */
+int mrg_gemm_set_wide8(int on);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
  * (wgrad_x3_k, rounds 1-2).  Same operands and products in the same order: bit-identical gradients for any shape. */

@@ -4,6 +4,7 @@
 #pragma once
 #include "gemm_x3.hpp"
 #include "gemm_x3s.hpp"
+#include "gemm_x3s8.hpp"
 
 namespace mrg {
 
@@ -20,7 +21,13 @@ inline int& gemm_mode() { static int m = 0; return m; }
 // the split-core row GEMM of the current mode for launches that prepared their own weight split (grouped launches, fused aggregators)
 template <int EPI>
 inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
-  if (gemm_mode() != 2 && x3s_eligible(a)) return launch_rowgemm_x3s<EPI>(a, Bp, st);
+  if (gemm_mode() != 2 && x3s_eligible(a)) {
+    // eight column tiles (D = 256) as ONE block where the epilogue fits (gemm_x3s8.hpp): the activation operand is read once
+    if constexpr (EPI != EPI_GATE) {
+      if (x3s8_eligible<EPI>(a)) return launch_rowgemm_x3s8<EPI>(a, Bp, st);
+    }
+    return launch_rowgemm_x3s<EPI>(a, Bp, st);
+  }
   return launch_rowgemm_x3<EPI>(a, Bp, st);
 }
 

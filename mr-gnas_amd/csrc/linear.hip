@@ -943,6 +943,12 @@ extern "C" int mrg_wgrad_set_variant(int variant) {
   return MRG_OK;
 }
 
+extern "C" int mrg_gemm_set_wide8(int on) {
+  if (on != 0 && on != 1) return MRG_E_ENUM;
+  gemm_wide8() = on;
+  return MRG_OK;
+}
+
 extern "C" int mrg_gemm_set_epilogue(int mode) {
   if (mode < 0 || mode > 2) return MRG_E_ENUM;
   gemm_epi_lds() = mode == 1 ? 1 : 0;

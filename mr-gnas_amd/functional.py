@@ -724,6 +724,9 @@ def sum_partial(x, graph):
 # ---------------------------------------------------------------------------
 # dense linear on rows (fp32 MFMA)
 # ---------------------------------------------------------------------------
+WIDE_BWD_INPUT = os.environ.get("MRG_WIDE_BWD_INPUT", "1") == "1"     # lab switch: 0 = the [B, N] scorer's input gradient on the row GEMM
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act):
@@ -754,18 +757,30 @@ class _Linear(torch.autograd.Function):
         st = stream_of(x)
         gx = gW = gb = None
         work = dict(nbytes=4 * rows * (K + Nout) + 4 * K * Nout, flops=2 * rows * K * Nout)
+        # a wide, short product ([B, N] scores against the whole entity table: Nout = N >> rows): both gradients reduce over
+        # or stream along the N entity rows, so both run on the transposed score gradient g^T [N, B]
+        wide = Nout > 1024
+        need_w = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
+        wide_in = wide and WIDE_BWD_INPUT and ctx.needs_input_grad[0] and rows <= 1024 and (rows <= 128 or (rows % 4 == 0 and K % 4 == 0))
+        gT = g.t().contiguous() if (wide_in or (wide and need_w)) else None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", K, Nout), x)
-            call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), ptr(wt), rows, K, Nout, K, 0, st), **work)
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            if wide_in:
+                # gx = g W = (g^T)^T W is a reduction over N into a [B, K] block: the shape of a weight gradient (rows := N,
+                # gY := g^T, X := W).  The row GEMM would give the whole N-long reduction to ceil(B / 128) workgroups
+                # (36 ms at B = 256, N = 1 M, K = 256); the split-over-rows kernel spreads it over the chip.
+                ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", Nout, K, rows), x)
+                call("mrg_linear_bwd_weight", (ptr(gT), ptr(W), None, ptr(gx), None, ptr(ws), Nout, K, 0, rows, st), **work)
+            else:
+                wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", K, Nout), x)
+                call("mrg_linear_bwd_input", (ptr(g), ptr(W), ptr(gx), ptr(wt), rows, K, Nout, K, 0, st), **work)
+        if need_w:
             gW = torch.empty_like(W)
             gb = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-            if Nout > 1024:
-                # a wide, short product ([B, N] scores against the whole entity table: Nout = N >> rows): the split-over-rows
-                # weight-gradient kernel keeps all of gW's row tiles in registers and does not cover this shape; here
-                # gW = g^T x is itself a tall-skinny row GEMM over the transposed operands
-                gT, xT = g.t().contiguous(), x.t().contiguous()
+            if wide:
+                # the split-over-rows weight-gradient kernel keeps all of gW's row tiles in registers and does not cover this
+                # shape; here gW = g^T x is itself a tall-skinny row GEMM over the transposed operands
+                xT = x.t().contiguous()
                 gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", rows, K), x)
                 call("mrg_linear_fwd", (ptr(gT), ptr(xT), None, ptr(gW), ptr(gws), Nout, rows, K, 0, st), **work)
                 if gb is not None:

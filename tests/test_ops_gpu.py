@@ -177,6 +177,32 @@ def test_linear_mfma_shapes():
             close(bd.grad, br.grad, "linear gb", rtol=5e-5, atol=5e-5)
 
 
+def test_linear_wide_short_gradients():
+    """[B, N] scores against an entity table (Nout = N >> rows): the input gradient is a reduction over the N entity rows and
+    runs on the split-over-rows weight-gradient kernel (functional._Linear.backward), the row GEMM where that kernel does
+    not take the shape; both against float64 and against each other."""
+    gen = torch.Generator().manual_seed(11)
+    for rows, Kd, Nout in ((90, 200, 3000), (256, 200, 5001), (1000, 64, 2048), (1001, 64, 2048), (256, 50, 3000), (4, 256, 20000)):
+        x = torch.randn(rows, Kd, generator=gen) * 0.3
+        W = torch.randn(Nout, Kd, generator=gen) * 0.3
+        gy = torch.randn(rows, Nout, generator=gen)
+        xr, Wr = x.double().requires_grad_(True), W.double().requires_grad_(True)
+        torch.sigmoid(xr @ Wr.t()).backward(gy.double())
+        got = {}
+        for sw in (True, False):
+            old, K.WIDE_BWD_INPUT = K.WIDE_BWD_INPUT, sw
+            try:
+                xd, Wd = x.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True)
+                K.linear(xd, Wd, None, "sigmoid").backward(gy.to(DEV))
+            finally:
+                K.WIDE_BWD_INPUT = old
+            got[sw] = xd.grad
+            for g_, r_, what in ((xd.grad, xr.grad, "gx"), (Wd.grad, Wr.grad, "gW")):
+                err = float((g_.double().cpu() - r_).abs().max())
+                assert err <= 1e-4 * max(1.0, float(r_.abs().max())), f"wide linear {rows}x{Kd}x{Nout} split={sw} {what}: {err:.3e}"
+        assert float((got[True] - got[False]).abs().max()) <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
+
+
 @pytest.mark.parametrize("rows,D,present", [(3000, 200, [0, 1, 1, 1, 1]), (777, 64, [1, 1, 1]), (100, 10, [1, 0, 1, 1]),
                                             (5000, 256, [1, 1, 1, 1, 1, 1, 1, 1]), (64, 512, [1, 1])])
 def test_mixed_epilogue_matches_bn_relu_sum(rows, D, present):
@@ -625,7 +651,8 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
     accumulators with 16-byte epilogue accesses (mrg_gemm_set_epilogue(2), round 4's comparison point), the wave-autonomous kernel
     (mode 2) with accumulator-order stores and with row-order 16-byte stores through LDS (mrg_gemm_set_epilogue(1)).  Bias / ReLU / sigmoid, gate (+ stored
     gate), row scale, accumulate -- bit-identical outputs; ragged last strips, partial last column tiles, two column blocks,
-    both row-tile shapes, dual-source K."""
+    both row-tile shapes, dual-source K.  Third switch: the eight-tile column block of a 256-wide output (gemm_x3s8.hpp, the
+    default for 224 < N <= 256) against the 2 x 4-tile kernel (mrg_gemm_set_wide8(0))."""
     from mr_gnas_amd._lib import call, ptr, stream_of
     lib = mr_gnas_amd._lib.load()
     gen = torch.Generator().manual_seed(rows + Nout + K2)
@@ -639,8 +666,8 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
     base = torch.randn(rows, K1, generator=gen).to(DEV)
     res = {}
     try:
-        for order in ((0, 0), (0, 2), (2, 0), (2, 1)):
-            assert lib.mrg_gemm_set_mode(order[0]) == 0 and lib.mrg_gemm_set_epilogue(order[1]) == 0
+        for order in ((0, 0, 1), (0, 0, 0), (0, 2, 0), (2, 0, 1), (2, 1, 1)):
+            assert lib.mrg_gemm_set_mode(order[0]) == 0 and lib.mrg_gemm_set_epilogue(order[1]) == 0 and lib.mrg_gemm_set_wide8(order[2]) == 0
             outs = []
             if K2 == 0:
                 for act in (None, "relu", "sigmoid"):
@@ -663,21 +690,23 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
     finally:
         lib.mrg_gemm_set_epilogue(0)
         lib.mrg_gemm_set_mode(0)
-    assert len(res[(0, 0)]) > 0
-    for other in ((0, 2), (2, 0), (2, 1)):
-        assert len(res[other]) == len(res[(0, 0)])
-        for i, (x, y) in enumerate(zip(res[(0, 0)], res[other])):
+        lib.mrg_gemm_set_wide8(1)
+    assert len(res[(0, 0, 1)]) > 0
+    for other in ((0, 0, 0), (0, 2, 0), (2, 0, 1), (2, 1, 1)):
+        assert len(res[other]) == len(res[(0, 0, 1)])
+        for i, (x, y) in enumerate(zip(res[(0, 0, 1)], res[other])):
             assert torch.equal(x, y), (other, i, float((x - y).abs().max()))
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [200, 256])
 @pytest.mark.parametrize("kind", ["max", "mean"])
-def test_fused_aggregators_are_bit_exact_across_split_core_kernels(kind):
+def test_fused_aggregators_are_bit_exact_across_split_core_kernels(kind, D):
     """Fused a_max / a_mean (GEMM over gathered, destination-ordered edge rows with the segmented epilogue) on the default
     LDS-weight kernel (gathered rows read straight into registers) against the wave-autonomous kernel (mode 2, gathered rows by
-    LDS-DMA): outputs and every gradient bit-identical."""
+    LDS-DMA): outputs and every gradient bit-identical.  D = 256 runs the eight-tile column block (gemm_x3s8.hpp) in mode 0."""
     lib = mr_gnas_amd._lib.load()
-    N, E, R, D = 2500, 120000, 9, 200
+    N, E, R = 2500, 120000, 9
     gen = torch.Generator().manual_seed(77)
     src = torch.randint(0, N, (E,), generator=gen)
     dst = torch.randint(0, N - 10, (E,), generator=gen)

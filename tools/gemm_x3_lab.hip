@@ -97,6 +97,24 @@ int main(int argc, char** argv) {
     }
     launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
   }
+  if (x3s8_eligible<EPI_BIAS_ACT>(a)) {   // round 4: eight column tiles as ONE block (gemm_x3s8.hpp) against two four-tile blocks
+    gemm_epi_mode() = 0;
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
+    std::vector<float> cref(rows * N), cs(rows * N);
+    hipMemcpy(cref.data(), C, cref.size() * 4, hipMemcpyDeviceToHost);
+    hipMemset(C, 0, rows * N * 4);
+    timeit("x3s, 2 x 4 tiles (gemm only)", [&] { launch_rowgemm_x3s<EPI_BIAS_ACT>(a, Bp, 0); });
+    hipMemset(C, 0, rows * N * 4);
+    timeit("x3s8, ONE 8-tile block (gemm only)", [&] { launch_rowgemm_x3s8<EPI_BIAS_ACT>(a, Bp, 0); });
+    hipMemcpy(cs.data(), C, cs.size() * 4, hipMemcpyDeviceToHost);
+    int64_t bad = 0;
+    for (size_t i = 0; i < cs.size(); ++i) bad += (cs[i] != cref[i]);
+    printf("x3s8 vs x3: %lld of %lld outputs differ\n", (long long)bad, (long long)cs.size());
+    GemmArgs g = a; g.Cin = C2; g.ld_cin = N; g.bias = nullptr;
+    timeit("x3s accumulate, 2 x 4 tiles", [&] { launch_rowgemm_x3s<EPI_ACCUM>(g, Bp, 0); });
+    timeit("x3s8 accumulate", [&] { launch_rowgemm_x3s8<EPI_ACCUM>(g, Bp, 0); });
+    launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
+  }
   {   // round 4: transposed accumulators (16-byte epilogue accesses) against accumulator-order stores, every epilogue, bit for bit
     std::vector<float> r0(rows * N), r1(rows * N), x0(rows * N), x1(rows * N);
     float* AUX; hipMalloc(&AUX, rows * N * 4);
