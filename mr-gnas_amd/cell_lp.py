@@ -279,7 +279,8 @@ class Cell(nn.Module):
         states = self.cell_middle(g, states, h_in, weights_middle, self._fan)
         states = self.cell_last(g, states, h_in, weights_last, self._fan)
         states = [s.take() if isinstance(s, K.Fan) else s for s in states]
-        return self.concat_weights(torch.cat(states, dim=1))
+        cat = torch.cat(states, dim=1)
+        return self.concat_weights(cat) if CALLER == "reference" else K.module_linear(self.concat_weights, cat)
 
 
 class Cell_SF(nn.Module):

@@ -19,14 +19,14 @@
 
 namespace mrg {
 
-template <int EPI>
+template <int NT, int EPI>
 __global__ __launch_bounds__(256, 2) void rowgemm_x3s8_k(GemmArgs a, const char* __restrict__ Bp, int ntile) {
-  constexpr int NT = 8, GBM = 128;
+  constexpr int GBM = 128;
   constexpr int NCH = NT * 3;                   // 1 KB chunks of one pre-split B slab
   constexpr int BSLAB = NCH * 1024;
-  constexpr int NBW = NCH / 4;                  // DMA instructions per wave and slab (24 chunks over 4 waves: exact)
-  constexpr int NP = NT / 2;
-  extern __shared__ __align__(16) char smem_b8[];    // [2][BSLAB] = 48 KB
+  constexpr int NBW = (NCH + 3) / 4;            // DMA instructions per wave and slab (the last wave repeats the last chunk: same bytes, same place)
+  constexpr int NP = (NT + 1) / 2;
+  extern __shared__ __align__(16) char smem_b8[];    // [2][BSLAB] = 48 KB at eight tiles
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s8_k(GemmArgs a, const char*
     const char* src = Bp + (int64_t)slab * ntile * 3072;
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-      const int c = wave * NBW + i;
+      int c = wave * NBW + i;
+      c = c < NCH ? c : NCH - 1;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 1024 + lane * 16), (lds_ptr_t)(smem_b8 + buf * BSLAB + c * 1024), 16, 0, 0);
     }
   };
@@ -95,20 +96,20 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s8_k(GemmArgs a, const char*
     if (has_next) fetch_b(s + 1, R ^ 1);                     // into the buffer slab s - 1 was read from: every wave is past that barrier
     load_a(s + 2, xr[R]);                                    // into the raw registers slab s - 1 split from
     read_b(0, R, bq2[0][0]);
-    read_b(1, R, bq2[0][1]);
+    if (NT > 1) read_b(1, R, bq2[0][1]);
     if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 2) : "memory");    // A(s+1): younger = B(s+1) A(s+2)
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
-      const int n0 = 2 * pp, n1 = 2 * pp + 1;
-      if (pp + 1 < NP) {
-        read_b(n0 + 2, R, bq2[(pp + 1) & 1][0]);
-        read_b(n1 + 2, R, bq2[(pp + 1) & 1][1]);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // the reads just issued may still be in flight
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+      const int n0 = 2 * pp, n1 = 2 * pp + 1 < NT ? 2 * pp + 1 : n0;
+      const bool two = 2 * pp + 1 < NT;                      // an odd NT ends on a single tile
+      if (n0 + 2 < NT) read_b(n0 + 2, R, bq2[(pp + 1) & 1][0]);
+      if (n0 + 3 < NT) read_b(n0 + 3, R, bq2[(pp + 1) & 1][1]);
+      // the reads just issued may still be in flight
+      if (n0 + 3 < NT) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      else if (n0 + 2 < NT) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (has_next) split_pair_of(xr[R ^ 1], pp, nh, nm, nl);          // one float pair of A(s+1) in the shadow of each tile pair
+      if (has_next && pp < 4) split_pair_of(xr[R ^ 1], pp, nh, nm, nl);   // one float pair of A(s+1) in the shadow of each tile pair
       const bf16x8 Ah = __builtin_bit_cast(bf16x8, ch), Am = __builtin_bit_cast(bf16x8, cm), Al = __builtin_bit_cast(bf16x8, cl);
       const bf16x8 Bh0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][0]), Bm0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][1]),
                    Bl0 = __builtin_bit_cast(bf16x8, bq2[pp & 1][0][2]);
@@ -116,25 +117,27 @@ __global__ __launch_bounds__(256, 2) void rowgemm_x3s8_k(GemmArgs a, const char*
                    Bl1 = __builtin_bit_cast(bf16x8, bq2[pp & 1][1][2]);
       // small terms first, the leading term last (the order of every split-core kernel)
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm1, acc[n1], 0, 0, 0);
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh1, acc[n1], 0, 0, 0);
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl1, acc[n1], 0, 0, 0);
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh1, acc[n1], 0, 0, 0);
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm1, acc[n1], 0, 0, 0);
       acc[n0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh0, acc[n0], 0, 0, 0);
-      acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[n1], 0, 0, 0);
+      if (two) acc[n1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh1, acc[n1], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < (two ? 12 : 6); ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // ... then up to three VALU
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (has_next) {
+#pragma unroll
+      for (int q = NP; q < 4; ++q) split_pair_of(xr[R ^ 1], q, nh, nm, nl);   // fewer than four tile pairs: the rest of A(s+1) here
       ch = nh; cm = nm; cl = nl;
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // this wave's share of B(s+1) is in LDS (younger: A(s+2))
       __builtin_amdgcn_s_barrier();                            // ... and everybody's; all reads of this slab's buffer are done
@@ -160,7 +163,8 @@ inline int& gemm_wide8() { static int m = 1; return m; }
 template <int EPI>
 inline bool x3s8_eligible(const GemmArgs& a) {
   if (EPI == EPI_GATE) return false;                       // 55 register spills at eight tiles: keeps the two-block form
-  return gemm_wide8() && a.grp.n == 0 && (a.K2 == 0 || !a.A2) && a.N > 224 && a.N <= 256 && a.K1 >= 32 && x3s_eligible(a);
+  if (!(gemm_wide8() && a.grp.n == 0 && (a.K2 == 0 || !a.A2) && a.K1 >= 32 && x3s_eligible(a))) return false;
+  return (a.N > 224 && a.N <= 256) || (gemm_wide8() == 2 && a.N > 192 && a.N <= 224);   // 2 (lab): seven-tile outputs on the ring of two as well
 }
 
 // Bp: the split of B prepared by launch_bsplit(..., nt = gemm_pick_nt(a.N) = 4, ...): [slab][8 tiles][plane][lane], the layout of one
@@ -169,11 +173,18 @@ template <int EPI>
 inline int launch_rowgemm_x3s8(GemmArgs a, const void* Bp, hipStream_t st) {
   if (a.rows <= 0) return MRG_OK;
   a.A2 = a.A1; a.K2 = 0;
-  const int ntile = x3_tiles(a.N, gemm_pick_nt(a.N));      // 8
+  const int ntile = x3_tiles(a.N, gemm_pick_nt(a.N));      // 8 (7: the lab's seven-tile form)
   dim3 grid((unsigned)((a.rows + 127) / 128), 1);
-  const size_t lds = (size_t)2 * 8 * 3 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s8_k<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rowgemm_x3s8_k<EPI>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);
+  const size_t lds = (size_t)2 * ntile * 3 * 1024;
+  if (ntile == 8) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s8_k<8, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((rowgemm_x3s8_k<8, EPI>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);
+  } else if (ntile == 7) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_x3s8_k<7, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((rowgemm_x3s8_k<7, EPI>), grid, dim3(256), lds, st, a, (const char*)Bp, ntile);
+  } else {
+    return MRG_E_SHAPE;
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MRG_OK : (int)e;
 }

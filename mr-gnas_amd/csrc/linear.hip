@@ -944,7 +944,7 @@ extern "C" int mrg_wgrad_set_variant(int variant) {
 }
 
 extern "C" int mrg_gemm_set_wide8(int on) {
-  if (on != 0 && on != 1) return MRG_E_ENUM;
+  if (on < 0 || on > 2) return MRG_E_ENUM;          // 2 (lab): seven-tile plain launches on the ring-of-two kernel as well
   gemm_wide8() = on;
   return MRG_OK;
 }

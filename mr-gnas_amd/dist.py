@@ -518,13 +518,13 @@ class ShardedSupernet:
             off += n
             states.append(fan(sN))
         states = [t.take() if isinstance(t, K.Fan) else t for t in states]
-        return cell.concat_weights(torch.cat(states, dim=1))
+        return K.module_linear(cell.concat_weights, torch.cat(states, dim=1))
 
     # -- the step ---------------------------------------------------------------------------
     def forward(self):
         """Returns (ent [N, D] gathered on every rank, rel [R', D])."""
         m, s = self.m, self.s
-        ent_all = m.linear_e(m.embedding_h.weight)
+        ent_all = K.module_linear(m.linear_e, m.embedding_h.weight)
         rel = torch.mm(m.rel_wt, m.embedding_e.weight)
         N = s.number_of_nodes()
         ent = None

@@ -796,6 +796,18 @@ def linear(x, W, b=None, act=None):
     return _Linear.apply(x, W, b, ACT[act])
 
 
+NODE_LINEAR = os.environ.get("MRG_NODE_LINEAR", "1") == "1"      # lab switch: 0 = the node-level nn.Linear modules stay on torch (Tensile)
+
+
+def module_linear(mod, x):
+    """An nn.Linear module applied to HIP rows on the library's row GEMM (forward, input and weight gradient) instead of the
+    vendor GEMM torch would pick: the entity projection and the cells' concat Linear (reference models/model_search_lp.py:131,
+    models/cell_lp.py:186-188) are [N, .] x [., D] products whose Tensile kernels cost 60-120 us each at N = 14 541."""
+    if NODE_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+        return linear(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 # ---------------------------------------------------------------------------
 # G: row gather with a deterministic (atomic-free) backward
 # ---------------------------------------------------------------------------

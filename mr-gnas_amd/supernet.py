@@ -124,7 +124,8 @@ class SearchNetwork(nn.Module):
     _plans = prepare
 
     def forward(self, g_train, node_id, src_in, edge_type):
-        ent_all = self.linear_e(self.embedding_h.weight)
+        ent_all = (self.linear_e(self.embedding_h.weight) if _cell_lp.CALLER == "reference"
+                   else K.module_linear(self.linear_e, self.embedding_h.weight))
         rel = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel, p_in = self._plans(g_train, node_id, src_in, edge_type)
         ent = None
@@ -255,7 +256,7 @@ class FixedCell(nn.Module):
         states = [src_emb, zero_out]
         for n in range(1, self._nb):
             states.append(_tsum(self._ops[n][i][0](g, states[i], zero_out) for i in range(n + 1) if len(self._ops[n][i])))
-        h = self.concat(torch.cat([states[i] for i in self._concat_node], dim=1))
+        h = K.module_linear(self.concat, torch.cat([states[i] for i in self._concat_node], dim=1))
         return F.relu(self.batchnorm_h(h))
 
 
@@ -287,7 +288,7 @@ class FixedNetwork(nn.Module):
         return cached_on(g, "_mrg_fixed_plans", (src, etype), (self._num_rel, g.number_of_nodes()), build)
 
     def forward(self, g, subj, rel):
-        ent = self.linear_e(self.embedding_h.weight)
+        ent = K.module_linear(self.linear_e, self.embedding_h.weight)
         rel_emb = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel = self._plans(g)
         for cell in self.cells:

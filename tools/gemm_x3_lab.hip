@@ -97,15 +97,16 @@ int main(int argc, char** argv) {
     }
     launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
   }
+  if (getenv("MRG_LAB_RING2")) gemm_wide8() = 2;   // seven-tile outputs on the ring-of-two kernel as well
   if (x3s8_eligible<EPI_BIAS_ACT>(a)) {   // round 4: eight column tiles as ONE block (gemm_x3s8.hpp) against two four-tile blocks
     gemm_epi_mode() = 0;
     launch_rowgemm_x3<EPI_BIAS_ACT>(a, Bp, 0);
     std::vector<float> cref(rows * N), cs(rows * N);
     hipMemcpy(cref.data(), C, cref.size() * 4, hipMemcpyDeviceToHost);
     hipMemset(C, 0, rows * N * 4);
-    timeit("x3s, 2 x 4 tiles (gemm only)", [&] { launch_rowgemm_x3s<EPI_BIAS_ACT>(a, Bp, 0); });
+    timeit("x3s (N = 256: 2 x 4 tiles) (gemm only)", [&] { launch_rowgemm_x3s<EPI_BIAS_ACT>(a, Bp, 0); });
     hipMemset(C, 0, rows * N * 4);
-    timeit("x3s8, ONE 8-tile block (gemm only)", [&] { launch_rowgemm_x3s8<EPI_BIAS_ACT>(a, Bp, 0); });
+    timeit("x3s8, ring of two, ONE block (gemm only)", [&] { launch_rowgemm_x3s8<EPI_BIAS_ACT>(a, Bp, 0); });
     hipMemcpy(cs.data(), C, cs.size() * 4, hipMemcpyDeviceToHost);
     int64_t bad = 0;
     for (size_t i = 0; i < cs.size(); ++i) bad += (cs[i] != cref[i]);
