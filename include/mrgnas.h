@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 11   /* 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 12   /* 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -581,6 +581,11 @@ int mrg_transe_score_fwd(const float *ent, const float *sub, const float *rel, f
                          int64_t B, int64_t N, int D, void *stream);
 int mrg_transe_score_bwd(const float *ent, const float *sub, const float *rel, const float *gscore, const float *score,
                          float *gent, float *gobj, int64_t B, int64_t N, int D, void *stream);
+/* gT[n][b] = g[b][n] * act'(y[b][n]): the output gradient of a wide, short Linear (the [B, N] scorers: N = all entities) with the
+ * activation's derivative folded in, transposed to [N][B] rows -- the layout both of its gradient products stream
+ * (functional._Linear.backward; replaces torch's mul / rsub / mul / strided copy).  act: MRG_ACT_NONE (y may be NULL) / _RELU /
+ * _SIGMOID, y = the forward's output.  B <= 64 * 65535. */
+int mrg_act_grad_transpose(const float *g, const float *y, float *gT, int64_t B, int64_t N, int act, void *stream);
 
 #ifdef __cplusplus
 }

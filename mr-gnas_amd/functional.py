@@ -748,10 +748,6 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x, W, y = ctx.saved_tensors
         g = f32c(g)
-        if ctx.act == 1:
-            g = g * (y > 0)           # ReLU mask (elementwise; folded into the fused kernel later)
-        elif ctx.act == 2:
-            g = g * y * (1 - y)       # sigmoid
         rows, K = x.shape
         Nout = W.shape[0]
         st = stream_of(x)
@@ -762,7 +758,20 @@ class _Linear(torch.autograd.Function):
         wide = Nout > 1024
         need_w = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
         wide_in = wide and WIDE_BWD_INPUT and ctx.needs_input_grad[0] and rows <= 1024 and (rows <= 128 or (rows % 4 == 0 and K % 4 == 0))
-        gT = g.t().contiguous() if (wide_in or (wide and need_w)) else None
+        gT = None
+        if wide and WIDE_BWD_INPUT and (wide_in or not ctx.needs_input_grad[0]) and (wide_in or need_w):
+            # the activation's derivative and the transposition in one pass over g and y (mrg_act_grad_transpose); g itself is not needed
+            require_hip(g)
+            gT = torch.empty(Nout, rows, dtype=torch.float32, device=x.device)
+            call("mrg_act_grad_transpose", (ptr(g), ptr(y), ptr(gT), rows, Nout, ctx.act, st), nbytes=4 * rows * Nout * (3 if ctx.act else 2))
+            g = None
+        else:
+            if ctx.act == 1:
+                g = g * (y > 0)           # ReLU mask (elementwise; folded into the fused kernel later)
+            elif ctx.act == 2:
+                g = g * y * (1 - y)       # sigmoid
+            if wide_in or (wide and need_w):
+                gT = g.t().contiguous()
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             if wide_in:
@@ -784,7 +793,7 @@ class _Linear(torch.autograd.Function):
                 gws = _ws(_ws_bytes("mrg_gemm_workspace_bytes", rows, K), x)
                 call("mrg_linear_fwd", (ptr(gT), ptr(xT), None, ptr(gW), ptr(gws), Nout, rows, K, 0, st), **work)
                 if gb is not None:
-                    gb = g.sum(0)
+                    gb = gT.sum(1)
             else:
                 ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K, Nout), x)
                 call("mrg_linear_bwd_weight", (ptr(g), ptr(x), None, ptr(gW), ptr(gb), ptr(ws), rows, K, 0, Nout, st), **work)

@@ -177,6 +177,25 @@ def test_linear_mfma_shapes():
             close(bd.grad, br.grad, "linear gb", rtol=5e-5, atol=5e-5)
 
 
+def test_act_grad_transpose_kernel():
+    """mrg_act_grad_transpose: gT[n][b] = g[b][n] * act'(y[b][n]) for the three activation codes, ragged tile edges, bit for bit
+    against the torch expressions it replaces (same products in the same order)."""
+    from mr_gnas_amd._lib import call, ptr, stream_of
+    gen = torch.Generator().manual_seed(21)
+    for B, N in ((1, 1), (70, 1000), (64, 64), (256, 5001), (3, 200000)):
+        g = torch.randn(B, N, generator=gen).to(DEV)
+        y = torch.sigmoid(torch.randn(B, N, generator=gen)).to(DEV)
+        y[0, ::7] = 0.0
+        for act, want in ((0, g), (1, g * (y > 0)), (2, g * y * (1 - y))):
+            out = torch.full((N, B), float("nan"), device=DEV)
+            call("mrg_act_grad_transpose", (ptr(g), ptr(y) if act else None, ptr(out), B, N, act, stream_of(g)))
+            assert torch.equal(out, want.t().contiguous()), (B, N, act)
+    lib = mr_gnas_amd._lib.load()
+    assert lib.mrg_act_grad_transpose(None, None, None, 4, 4, 0, None) == -1           # MRG_E_NULLPTR
+    assert lib.mrg_act_grad_transpose(None, None, None, 4, 4, 7, None) == -3           # MRG_E_ENUM
+    assert lib.mrg_act_grad_transpose(None, None, None, 0, 4, 0, None) == 0
+
+
 def test_linear_wide_short_gradients():
     """[B, N] scores against an entity table (Nout = N >> rows): the input gradient is a reduction over the N entity rows and
     runs on the split-over-rows weight-gradient kernel (functional._Linear.backward), the row GEMM where that kernel does

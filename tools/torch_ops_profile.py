@@ -15,7 +15,13 @@ import bench  # noqa: E402
 
 args = bench.parse()
 torch.cuda.set_device(0)
-step = bench.Step(args, torch.device("cuda", 0), bench.build_step_inputs(args.workload, args.negative, args.seed))
+dev = torch.device("cuda", 0)
+if args.workload == "c5_fixed_cell":
+    step = bench.FixedStep(args, dev, shape="synthetic10m", dim=256, init_dim=64, nbase=64)
+elif args.workload == "fb15k237_fixed_d64":
+    step = bench.FixedStep(args, dev)
+else:
+    step = bench.Step(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
