@@ -520,7 +520,7 @@ def main():
         os.environ["MRG_SEGMENT_STREAMS"] = "1"
         CL.MIXED_STREAMS = 1
         from mr_gnas_amd import functional as _KF
-        _KF.SEGMENT_STREAMS = 1
+        _KF.switches.SEGMENT_STREAMS = 1
     if sharded:
         import torch.distributed as dist
         from mr_gnas_amd import dist as MD
@@ -598,8 +598,8 @@ def main():
     # It runs on ONE stream: in the timed steps the candidates of a MixedOp share the GPU from four streams, and
     # an event pair around a kernel then also spans the time it waits for CUs held by the other streams.
     from mr_gnas_amd import functional as KF
-    fork_rows = KF.FORK_MIN_ROWS
-    KF.FORK_MIN_ROWS = 1 << 62
+    fork_rows = KF.switches.FORK_MIN_ROWS
+    KF.switches.FORK_MIN_ROWS = 1 << 62
     _lib.meter.start()
     torch.cuda.synchronize()
     t_inst = time.perf_counter()
@@ -607,7 +607,7 @@ def main():
     raw_stats = _lib.meter.stop()                 # synchronises
     inst_ms = (time.perf_counter() - t_inst) * 1e3
     table = kernel_table(raw_stats)
-    KF.FORK_MIN_ROWS = fork_rows
+    KF.switches.FORK_MIN_ROWS = fork_rows
     families = family_table(raw_stats, inst_ms)
     dom_family = max(families, key=lambda k: families[k]["ms_total"]) if families else None
     dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
@@ -654,7 +654,7 @@ def main():
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides --------------------
     rows_local = int(getattr(step, "E_global", step.E)) // world + int(step.g.number_of_nodes())
-    multi_stream = KF.FORK_MIN_ROWS <= rows_local
+    multi_stream = KF.switches.FORK_MIN_ROWS <= rows_local
     live = bool(dominant) and launch_mode == "eager" and not multi_stream
     if live:
         _lib.meter.start([dominant])

@@ -86,7 +86,7 @@ class MixedOp(nn.Module):
             total = sum(w * self.op_forward(op, g, h, h_in) for w, op in zip(weights, self._ops))
             return total if addend is None else addend + total
         if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
-            if (K.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(self._ops) <= 3
+            if (K.switches.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(self._ops) <= 3
                     and all(isinstance(op, OPS._PreOp) for op, _, _ in self._ops)):
                 # ... and are never stored: statistics, combine and gradients recompute them from the two tables
                 return K.cell_zero_mixed([op.kind for op, _, _ in self._ops], h, h_in, [bn for _, bn, _ in self._ops], weights,
@@ -102,12 +102,12 @@ class MixedOp(nn.Module):
         pair = self._dense_pair(fh.x)
         paired = {}
         # f_sparse_comp as a row factor: only next to the gate-only f_dense_comp, whose folded gradient store receives its gradient
-        row_ok = pair is not None and K.GATED_RECOMPUTE and K.FOLD_ROW_SCALE
+        row_ok = pair is not None and K.switches.GATED_RECOMPUTE and K.switches.FOLD_ROW_SCALE
         # The candidates are independent: they may run round-robin on a few HIP streams so that the tail of one
         # kernel is filled by another candidate's kernels.  Autograd replays each candidate's backward on the stream its
         # forward ran on.  (Launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows.)
         dev = fh.x.device
-        nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.FORK_MIN_ROWS else 1
+        nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.switches.FORK_MIN_ROWS else 1
         if nstreams <= 1:
             ys = []
             for k, (op, _, _) in enumerate(self._ops):

@@ -86,7 +86,7 @@ class f_sparse_op_comp(nn.Module):
         for x in ("in", "out", "self"):
             W, a = getattr(self, "W_" + x), getattr(self, "a_" + x)
             p += [W.weight, W.bias, a.weight]
-        if for_epilogue and K.ROW_FACTOR and src_emb.is_cuda:
+        if for_epilogue and K.switches.ROW_FACTOR and src_emb.is_cuda:
             return K.gate_comp_row_factor(src_emb, src_emb_in, g.norm_flat(), b0, b1, *p)
         return K.gate_comp(src_emb, src_emb_in, g.norm_flat(), b0, b1, *p)
 
@@ -153,7 +153,7 @@ def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=F
     """(f_dense_comp(g, src_emb, src_emb_in), f_comp(g, src_emb, src_emb_in)) of one MixedOp as one autograd node when the
     shapes allow (functional.dense_filter_pair), else the two operators on their own.  for_epilogue: both results go to
     functional.mixed_epilogue and nowhere else -- two functional.Candidate values; f_dense_comp's may then be its GATE, which the
-    epilogue recomputes the output from (functional.GATED_RECOMPUTE)."""
+    epilogue recomputes the output from (functional.switches.GATED_RECOMPUTE)."""
     D = src_emb.shape[1]
     tied = src_emb_in is not None and K.same_rows(src_emb, src_emb_in)
     if not (src_emb.is_cuda and K.dense_pair_available(D, tied)):
@@ -161,7 +161,7 @@ def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=F
     b0, b1 = _bounds(g)
     dp = (op_dense.W_in.weight, op_dense.W_in.bias, op_dense.W_out.weight, op_dense.W_out.bias, op_dense.W_self.weight, op_dense.W_self.bias)
     cw = (op_comp.W_in.weight, op_comp.W_out.weight, op_comp.W_self.weight)
-    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw, gate_only=for_epilogue and K.GATED_RECOMPUTE,
+    return K.dense_filter_pair(src_emb, src_emb_in, g.norm_flat(), b0, b1, dp, cw, gate_only=for_epilogue and K.switches.GATED_RECOMPUTE,
                                for_epilogue=for_epilogue)
 
 

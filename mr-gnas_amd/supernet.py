@@ -141,8 +141,8 @@ class SearchNetwork(nn.Module):
                 x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
                 ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
             if l > 0 or self._layers == 1:
-                if K.MASK_TAP is not None and ent.is_cuda:           # test instrumentation (functional.MASK_TAP)
-                    K.MASK_TAP(("net", l), [ent > 0])
+                if K.switches.MASK_TAP is not None and ent.is_cuda:           # test instrumentation (functional.switches.MASK_TAP)
+                    K.switches.MASK_TAP(("net", l), [ent > 0])
                 ent = F.relu(ent)
             ent = F.dropout(ent, self._dropout, training=self.training)
             rel = torch.matmul(rel, self.w_rel)

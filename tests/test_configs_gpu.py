@@ -61,7 +61,7 @@ def step_inputs(ds, negative, seed=0):
 
 def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels, imposed=None):
     """The oracle restatement of one supernet step in float64 on the device; returns ent, rel, loss and
-    {name: grad}, [alpha grads].  `imposed` ({site: bool mask}, the HIP run's ReLU decisions from functional.MASK_TAP): the run takes
+    {name: grad}, [alpha grads].  `imposed` ({site: bool mask}, the HIP run's ReLU decisions from functional.switches.MASK_TAP): the run takes
     THOSE decisions instead of its own (z * mask in place of relu(z)) and counts where its own would have differed -- "mask replay":
     both runs then evaluate the same piecewise-linear function, so what is left between their gradients is rounding alone."""
     src, dst, _ = g.edges(form="all")
@@ -139,7 +139,7 @@ def supernet_case(ds, D, negative):
             if p.dim() == 1:
                 p.add_(0.05 * torch.randn_like(p))
     model.train()
-    # the HIP run's own ReLU decisions, site by site (functional.MASK_TAP): site = the BatchNorm's state_dict prefix / ("net", layer)
+    # the HIP run's own ReLU decisions, site by site (functional.switches.MASK_TAP): site = the BatchNorm's state_dict prefix / ("net", layer)
     names = {id(m): n + "." for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm1d)}
     masks = {}
 
@@ -154,11 +154,11 @@ def supernet_case(ds, D, negative):
             for b, m in zip(bns, ms):
                 masks[names[id(b)]] = m
 
-    K.MASK_TAP = tap
+    K.switches.MASK_TAP = tap
     try:
         ent, rel = model(g, node_id, src, edge_type)
     finally:
-        K.MASK_TAP = None
+        K.switches.MASK_TAP = None
     loss = model.get_loss(g, ent, rel, samples_t, labels_t)
     loss.backward()
     torch.cuda.synchronize()
@@ -486,7 +486,7 @@ def test_c5_fused_amax(c5):
     keep = {}
     try:
         for fused in (True, False):
-            K.FUSED_AMAX = fused
+            K.switches.FUSED_AMAX = fused
             x = x0.clone().requires_grad_(True)
             out = K.linear_relu_aggregate("max", x, W0, b0, g)
             out.backward(gout)
@@ -497,7 +497,7 @@ def test_c5_fused_amax(c5):
             del x, out
             free()
     finally:
-        K.FUSED_AMAX = True
+        K.switches.FUSED_AMAX = True
     cols = slice(64, 128)
     y = torch.relu(x0[:E].double() @ W0[cols].double().t() + b0[cols].double()).float()
     ref = torch.zeros(N, 64, device=DEV).scatter_reduce(0, dst.view(-1, 1).expand(E, 64), y, "amax", include_self=False) + x0[E:, cols]
@@ -522,7 +522,7 @@ def test_c5_fused_amean(c5):
     keep = {}
     try:
         for fused in (True, False):
-            K.FUSED_AMEAN = fused
+            K.switches.FUSED_AMEAN = fused
             x = x0.clone().requires_grad_(True)
             out = K.linear_relu_aggregate("mean", x, W0, b0, g)
             out.backward(gout)
@@ -530,7 +530,7 @@ def test_c5_fused_amean(c5):
             del x, out
             free()
     finally:
-        K.FUSED_AMEAN = True
+        K.switches.FUSED_AMEAN = True
     for a, b, what in zip(keep[True], keep[False], ("out", "gx sample", "gx self rows")):
         err = float((a - b).abs().max())
         assert err <= 2e-5 * max(1.0, float(b.abs().max())), f"C5 fused a_mean {what}: {err:.3e}"

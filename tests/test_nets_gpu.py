@@ -55,7 +55,7 @@ def streams(request, monkeypatch):
     a missing stream dependency shows up as a flaky mismatch)."""
     if request.param == "side streams":
         from mr_gnas_amd import functional as K
-        monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+        monkeypatch.setattr(K.switches, "FORK_MIN_ROWS", 0)
     return request.param
 
 
@@ -217,7 +217,7 @@ def test_lazy_asum_gradient_is_ordered_across_candidate_streams(monkeypatch):
     -> _Fanout); with the candidates on side HIP streams the consumer must wait for the producer's stream.  Side streams forced on
     a small graph with dropout inside a_sum, lazy hand-over against the materialised gradient (MRG_LAZY_ASUM=0), several times."""
     from mr_gnas_amd import cell_lp as CL, functional as K
-    monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+    monkeypatch.setattr(K.switches, "FORK_MIN_ROWS", 0)
     monkeypatch.setattr(CL, "MIXED_STREAMS", 4)
     z = load_golden("supernet_d24")
     n = z["node_id"].numel()
@@ -230,7 +230,7 @@ def test_lazy_asum_gradient_is_ordered_across_candidate_streams(monkeypatch):
     data, labels = z["data"].to(DEV), z["labels"].to(DEV)
 
     def grads(lazy):
-        monkeypatch.setattr(K, "LAZY_ASUM", lazy)
+        monkeypatch.setattr(K.switches, "LAZY_ASUM", lazy)
         torch.manual_seed(11)                       # the same dropout masks
         for p in list(net.parameters()) + net.arch_parameters():
             p.grad = None
@@ -256,7 +256,7 @@ def test_cold_first_step_with_side_streams_matches_reference(monkeypatch):
     with int32 ones of many sizes first, so a plan read before it is written yields in-bounds but wrong indices
     and the comparison with the reference fails instead of the GPU faulting."""
     from mr_gnas_amd import functional as K
-    monkeypatch.setattr(K, "FORK_MIN_ROWS", 0)
+    monkeypatch.setattr(K.switches, "FORK_MIN_ROWS", 0)
     for rep in range(4):
         junk = [torch.ones(n, dtype=torch.int32, device=DEV) for n in (37, 120, 208, 480, 832, 1024, 4096, 20000, 70000) for _ in range(6)]
         torch.cuda.synchronize()

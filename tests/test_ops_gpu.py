@@ -209,12 +209,12 @@ def test_linear_wide_short_gradients():
         torch.sigmoid(xr @ Wr.t()).backward(gy.double())
         got = {}
         for sw in (True, False):
-            old, K.WIDE_BWD_INPUT = K.WIDE_BWD_INPUT, sw
+            old, K.switches.WIDE_BWD_INPUT = K.switches.WIDE_BWD_INPUT, sw
             try:
                 xd, Wd = x.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True)
                 K.linear(xd, Wd, None, "sigmoid").backward(gy.to(DEV))
             finally:
-                K.WIDE_BWD_INPUT = old
+                K.switches.WIDE_BWD_INPUT = old
             got[sw] = xd.grad
             for g_, r_, what in ((xd.grad, xr.grad, "gx"), (Wd.grad, Wr.grad, "gW")):
                 err = float((g_.double().cpu() - r_).abs().max())
@@ -407,7 +407,7 @@ def test_weight_gradient_split_once_is_bit_exact_with_split_per_wave(rows, K1, K
                                               (77, 900, 260, 1, True)])
 def test_fan_in_sum_with_a_gathered_term(N, E, D, K_, self_rows):
     """mrg_sum_rows_gather: sum of K [M, D] tensors plus a gather of [N, D] rows (edge row e <- dst[e], self row n <- n) against
-    torch; then a_sum's input gradient left to the fan-in sum (functional.LAZY_ASUM) against the materialised form through a Fan."""
+    torch; then a_sum's input gradient left to the fan-in sum (functional.switches.LAZY_ASUM) against the materialised form through a Fan."""
     from mr_gnas_amd._lib import call, ptr, ptr_array, stream_of
     gen = torch.Generator().manual_seed(N + E + D + K_)
     dst = torch.randint(0, N, (E,), generator=gen)
@@ -428,14 +428,14 @@ def test_fan_in_sum_with_a_gathered_term(N, E, D, K_, self_rows):
     res = {}
     try:
         for lazy in (True, False):
-            K.LAZY_ASUM = lazy
+            K.switches.LAZY_ASUM = lazy
             x = x0.clone().to(DEV).requires_grad_(True)
             fan = K.Fan(x, 3)
             y = K.aggregate_rows("sum", fan.take(), g) + K.aggregate_rows("mean", fan.take(), g)
             (y * gout).sum().backward()
             res[lazy] = x.grad.clone()
     finally:
-        K.LAZY_ASUM = True
+        K.switches.LAZY_ASUM = True
     close(res[True], res[False].cpu(), "a_sum gradient through the fan-in gather", rtol=2e-6, atol=2e-6)
 
 
@@ -534,17 +534,17 @@ def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
     b0 = torch.randn(D, generator=gen) * 0.1
     gout = torch.randn(N, D, generator=gen).to(DEV)
     res = {}
-    min_rows = K.FUSED_AMAX_MIN_ROWS
+    min_rows = K.switches.FUSED_AMAX_MIN_ROWS
     try:
-        K.FUSED_AMAX_MIN_ROWS = 0
+        K.switches.FUSED_AMAX_MIN_ROWS = 0
         for fused in (True, False):
-            K.FUSED_AMAX = fused
+            K.switches.FUSED_AMAX = fused
             x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
             out = K.linear_relu_aggregate("max", x, W, b, g)
             out.backward(gout)
             res[fused] = (out.detach(), x.grad, W.grad, b.grad)
     finally:
-        K.FUSED_AMAX, K.FUSED_AMAX_MIN_ROWS = True, min_rows
+        K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS = True, min_rows
     assert int(mr_gnas_amd._lib.load().mrg_linear_relu_segmax_workspace_bytes(N, D, D)) > 0
     for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
         assert torch.equal(a, b_), what
@@ -570,7 +570,7 @@ def test_grouped_direction_segments_are_bit_exact(kind, tied, N, E, R, D):
     res = {}
     try:
         for grouped in (True, False):
-            K.GROUPED_SEGMENTS = grouped
+            K.switches.GROUPED_SEGMENTS = grouped
             a = a0.clone().to(DEV).requires_grad_(True)
             b = a if tied else b0.clone().to(DEV).requires_grad_(True)
             op.zero_grad()
@@ -578,7 +578,7 @@ def test_grouped_direction_segments_are_bit_exact(kind, tied, N, E, R, D):
             out.backward(gout)
             res[grouped] = [out.detach(), a.grad] + ([] if tied else [b.grad]) + [p.grad.clone() for p in op.parameters()]
     finally:
-        K.GROUPED_SEGMENTS = True
+        K.switches.GROUPED_SEGMENTS = True
     for x, y in zip(res[True], res[False]):
         assert torch.equal(x, y)
 
@@ -635,11 +635,11 @@ def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
     b0 = torch.randn(D, generator=gen) * 0.1
     gout = torch.randn(N, D, generator=gen).to(DEV)
     res = {}
-    min_rows = K.FUSED_AMAX_MIN_ROWS
+    min_rows = K.switches.FUSED_AMAX_MIN_ROWS
     try:
-        K.FUSED_AMAX_MIN_ROWS = 0
+        K.switches.FUSED_AMAX_MIN_ROWS = 0
         for fused in (True, True, False):
-            K.FUSED_AMEAN = fused
+            K.switches.FUSED_AMEAN = fused
             x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
             out = K.linear_relu_aggregate("mean", x, W, b, g)
             out.backward(gout)
@@ -648,7 +648,7 @@ def test_fused_amean_matches_the_two_launch_form(N, E, R, D, hub):
                 assert all(torch.equal(p, q) for p, q in zip(cur, res[True])), "fused a_mean is not reproducible"
             res[fused] = cur
     finally:
-        K.FUSED_AMEAN, K.FUSED_AMAX_MIN_ROWS = True, min_rows
+        K.switches.FUSED_AMEAN, K.switches.FUSED_AMAX_MIN_ROWS = True, min_rows
     for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
         close(a, b_.cpu(), "fused a_mean " + what, rtol=2e-5, atol=1e-6)
     # exact mask: rows whose message is dead in every column get a zero input gradient in both forms, and vice versa
@@ -768,7 +768,7 @@ def test_cell_zero_recompute_matches_the_stored_candidates(N, E, R, D, train):
     res = {}
     try:
         for fused in (True, False):
-            K.CELL_ZERO_FUSED = fused
+            K.switches.CELL_ZERO_FUSED = fused
             torch.manual_seed(5)
             mixed = S.MixedOp(D, 0.0, O.PRE_OPS).to(DEV)
             with torch.no_grad():
@@ -786,7 +786,7 @@ def test_cell_zero_recompute_matches_the_stored_candidates(N, E, R, D, train):
             if fused:
                 model = mixed
     finally:
-        K.CELL_ZERO_FUSED = True
+        K.switches.CELL_ZERO_FUSED = True
     a, b = res[True], res[False]
     # same values; the recomputing statistics / gradient reductions sum over more blocks than the stored form's (order of the
     # float64 / float32 partial sums): equal to rounding, not bit for bit
@@ -843,8 +843,8 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
     res = {}
     try:
         for pair in (True, False, "no identity fold", "neither"):
-            K.DENSE_PAIR = pair in (True, "no identity fold")
-            K.FOLD_IDENTITY = pair in (True, False)          # f_identity's gradient added into f_dense_comp's direct term / a tensor of its own
+            K.switches.DENSE_PAIR = pair in (True, "no identity fold")
+            K.switches.FOLD_IDENTITY = pair in (True, False)          # f_identity's gradient added into f_dense_comp's direct term / a tensor of its own
             mixed.zero_grad(set_to_none=True)
             h = h0.clone().to(DEV).requires_grad_(True)
             hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
@@ -854,7 +854,7 @@ def test_dense_pair_node_matches_the_two_operators(N, E, R, D, tied):
             torch.cuda.synchronize()
             res[pair] = [out.detach(), h.grad] + ([] if tied else [hin.grad]) + [w.grad] + [p.grad.clone() for p in mixed.parameters()]
     finally:
-        K.DENSE_PAIR, K.FOLD_IDENTITY = True, True
+        K.switches.DENSE_PAIR, K.switches.FOLD_IDENTITY = True, True
     for other in (False, "no identity fold", "neither"):
         assert torch.equal(res[True][0], res[other][0])
         for i, (a, b) in enumerate(zip(res[True][1:], res[other][1:])):
@@ -923,7 +923,13 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
             p.data.add_(0.1 * torch.randn(p.shape, generator=gen).to(DEV))
     state0 = {k: v.clone() for k, v in mixed.state_dict().items()}
     calls = []
-    real_call = K.call
+    import types
+    real_call = mr_gnas_amd._lib.call
+    launchers = [m for m in vars(K).values() if isinstance(m, types.ModuleType) and getattr(m, "call", None) is real_call]
+
+    def set_call(fn):                                     # every kernel-family module of the package binds `call` by name
+        for m in launchers:
+            m.call = fn
 
     def spy(name, args, **kw):
         calls.append((name, args))
@@ -934,8 +940,8 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
             for training in (True, False):
                 res = {}
                 for mode in ("stored", "gate", "gate+row"):
-                    K.GATED_RECOMPUTE, K.ROW_FACTOR = mode != "stored", mode == "gate+row"
-                    K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = folds, folds
+                    K.switches.GATED_RECOMPUTE, K.switches.ROW_FACTOR = mode != "stored", mode == "gate+row"
+                    K.switches.FOLD_ROW_SCALE, K.switches.FOLD_IDENTITY = folds, folds
                     mixed.load_state_dict(state0)
                     mixed.train(training)
                     mixed.zero_grad(set_to_none=True)
@@ -943,10 +949,10 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
                     hin = h if tied else hin0.clone().to(DEV).requires_grad_(True)
                     w = w0.clone().to(DEV).requires_grad_(True)
                     del calls[:]
-                    K.call = spy
+                    set_call(spy)
                     out = mixed(w, g, h, hin, addend=add0)
                     out.backward(gout)
-                    K.call = real_call
+                    set_call(real_call)
                     torch.cuda.synchronize()
                     fwd3 = [a for n, a in calls if n == "mrg_dense_filter_fwd3" and a[0] == 0]
                     assert len(fwd3) == 1 and (fwd3[0][8] is None) == (mode != "stored"), "the gated row GEMM stores its output exactly when the candidate is stored"
@@ -966,5 +972,5 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
                     close(a, b.cpu(), f"row-factor f_sparse_comp: gradient {i} (folds {folds}, training {training})", rtol=2e-5,
                           atol=2e-5 * max(1e-3, float(b.abs().max())))
     finally:
-        K.call = real_call
-        K.GATED_RECOMPUTE, K.ROW_FACTOR, K.FOLD_ROW_SCALE, K.FOLD_IDENTITY = True, True, True, True
+        set_call(real_call)
+        K.switches.GATED_RECOMPUTE, K.switches.ROW_FACTOR, K.switches.FOLD_ROW_SCALE, K.switches.FOLD_IDENTITY = True, True, True, True

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lab: randomized comparison of a first-stage MixedOp with its candidates recomputed (gate-only f_dense_comp, row-factor
-f_sparse_comp: functional.GATED_RECOMPUTE / ROW_FACTOR) against the stored form.  Random D (multiples of 4 from 52 to 320 -- above 256
+f_sparse_comp: functional.switches.GATED_RECOMPUTE / ROW_FACTOR) against the stored form.  Random D (multiples of 4 from 52 to 320 -- above 256
 the row factor is multiplied out), edge counts, direction splits incl. empty segments, tied / distinct operands, training / eval.
 Output and running statistics must be bit-identical; gradients bit-identical for the gate-only form, within float32 rounding with the
 row factor.   usage: python tools/fuzz_mixed.py [cases] [seed]"""
@@ -48,7 +48,7 @@ for case in range(cases):
     gout = torch.randn(E + N, D, generator=gen).to(DEV)
     res = {}
     for mode in ("stored", "gate", "gate+row"):
-        K.GATED_RECOMPUTE, K.ROW_FACTOR = mode != "stored", mode == "gate+row"
+        K.switches.GATED_RECOMPUTE, K.switches.ROW_FACTOR = mode != "stored", mode == "gate+row"
         mixed.load_state_dict(state0)
         mixed.train(training)
         mixed.zero_grad(set_to_none=True)
@@ -70,6 +70,6 @@ for case in range(cases):
     ok = ok and worst <= 5e-5
     print(f"case {case:3d} D={D:3d} N={N:3d} E={E:5d} b0={b0:5d} tied={int(tied)} train={int(training)}  {'ok' if ok else 'MISMATCH'}  row-factor gradient rel err {worst:.1e}", flush=True)
     bad += not ok
-K.GATED_RECOMPUTE, K.ROW_FACTOR = True, True
+K.switches.GATED_RECOMPUTE, K.switches.ROW_FACTOR = True, True
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -49,14 +49,14 @@ for c in range(cases):
         b0_ = torch.randn(E + N, D, generator=gen).to(DEV)
         gout = torch.randn(N if kind.startswith("a_") else E + N, D, generator=gen).to(DEV)
         res = {}
-        keep = (K.GROUPED_SEGMENTS, K.FUSED_AMAX, K.FUSED_AMAX_MIN_ROWS, K.FUSED_AMEAN)
+        keep = (K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN)
         try:
-            K.FUSED_AMAX_MIN_ROWS = 0
+            K.switches.FUSED_AMAX_MIN_ROWS = 0
             for fast in (True, False):
-                K.GROUPED_SEGMENTS = K.FUSED_AMAX = K.FUSED_AMEAN = fast
+                K.switches.GROUPED_SEGMENTS = K.switches.FUSED_AMAX = K.switches.FUSED_AMEAN = fast
                 res[fast] = run(op, g, a0, b0_, gout, tied)
         finally:
-            K.GROUPED_SEGMENTS, K.FUSED_AMAX, K.FUSED_AMAX_MIN_ROWS, K.FUSED_AMEAN = keep
+            K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN = keep
         def same(x, y):
             if x is None or y is None:
                 return x is None and y is None
