@@ -703,9 +703,13 @@ def main():
         # algorithmic work / summed HIP-event time of its launches; `traffic` = counter bytes of its largest entry point
         f = families[dom_family]
         big = max(f["entry_points"], key=lambda n: table[n]["ms_total"] if n in table else 0.0)
+        # per-launch counter bytes exist for the launches of the default workload only (tools/profile_r4.sh profiles that command)
+        counted = args.workload == "fb15k237_supernet_full" and args.dim == 200 and not sharded and args.caller == "fused"
         out["roofline"] = {"kernel": dom_family, "bound": f["bound"], "achieved": f["achieved"], "peak": f["peak"], "unit": f["unit"],
-                           "frac": f["frac"], "traffic": load_traffic(big), "traffic_entry_point": big,
-                           "traffic_source": traffic_source(big), "launches": f["launches"],
+                           "frac": f["frac"], "traffic": load_traffic(big) if counted else None, "traffic_entry_point": big,
+                           "traffic_source": traffic_source(big) if counted else
+                           "none: the counter passes under profiles/ are of the default workload (fb15k237_supernet_full, D = 200), whose launches have other sizes",
+                           "launches": f["launches"],
                            "us_per_launch": round(f["ms_total"] * 1e3 / f["launches"], 2), "ms_per_step": f["ms_total"],
                            "entry_points": f["entry_points"],
                            "timed_in": "the instrumented single-stream step before the timed steps (HIP events on the launch stream)",

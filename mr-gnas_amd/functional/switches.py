@@ -18,7 +18,7 @@ NODE_LINEAR = os.environ.get("MRG_NODE_LINEAR", "1") == "1"      # lab switch: 0
 MASK_TAP = None
 FOLD_IDENTITY = os.environ.get("MRG_FOLD_IDENTITY", "1") == "1"     # lab switch: 0 = f_identity's gradient stays a tensor of its own
 CELL_ZERO_FUSED = os.environ.get("MRG_CELL_ZERO_FUSED", "1") == "1"     # lab switch: 0 = three gather-compose launches + the generic epilogue
-FORK_MIN_ROWS = 1 << 17      # below this many rows an operator is launch-bound: no side streams
+FORK_MIN_ROWS = int(os.environ.get("MRG_FORK_MIN_ROWS", str(1 << 17)))      # below this many rows an operator is launch-bound: no side streams
 SEGMENT_STREAMS = int(os.environ.get("MRG_SEGMENT_STREAMS", "3"))   # streams the direction segments of one operator use
 FOLD_ROW_SCALE = os.environ.get("MRG_FOLD_ROW_SCALE", "1") == "1"          # lab switch: 0 = f_comp's dz pass stays a launch of its own
 GROUPED_SEGMENTS = os.environ.get("MRG_GROUPED_SEGMENTS", "1") == "1"    # lab switch: 0 = one launch per direction segment

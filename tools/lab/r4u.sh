@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, call u: the same probe at 1 / 2 / 3 segment streams (the 36 ms launch is not a concurrency effect)
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r4u
 mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, call v: the [B, N] scorer input gradient on the split-over-rows kernel: tests, C5 probe, fixed d64 probe
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r4v
 mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, call w: full GPU suite and the C5 / headline bench lines after the reroute
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r4w
 mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, call y: torch (non-library) kernels left in the headline step, by aten op (tools/torch_ops_profile.py)
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r4y
 mkdir -p $O

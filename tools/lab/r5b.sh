@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, call 5b: torch (non-library) kernels left in the c5_fixed_cell step
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r5b
 mkdir -p $O
