@@ -16,7 +16,14 @@ import bench  # noqa: E402
 args = bench.parse()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-if args.workload == "c5_fixed_cell":
+if args.rehearse_shard:                               # one rank of a W-way sharded step on one GPU (timing only, bench.py --rehearse-shard)
+    from mr_gnas_amd import cell_lp as CL, dist as MD, functional as K, rccl
+    r_, w_ = (int(v) for v in args.rehearse_shard.split("/"))
+    CL.MIXED_STREAMS = 1
+    K.switches.SEGMENT_STREAMS = 1
+    step = MD.ShardedStep(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed), r_, w_,
+                          group=rccl.VirtualWorld(r_, w_, dev))
+elif args.workload == "c5_fixed_cell":
     step = bench.FixedStep(args, dev, shape="synthetic10m", dim=256, init_dim=64, nbase=64)
 elif args.workload == "fb15k237_fixed_d64":
     step = bench.FixedStep(args, dev)
