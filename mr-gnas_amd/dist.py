@@ -523,6 +523,10 @@ class ShardedSupernet:
     # -- the step ---------------------------------------------------------------------------
     def forward(self):
         """Returns (ent [N, D] gathered on every rank, rel [R', D])."""
+        with K.deferred_counters():                        # the BatchNorm step counters of all MixedOps: one launch at the end
+            return self._forward()
+
+    def _forward(self):
         m, s = self.m, self.s
         ent_all = K.module_linear(m.linear_e, m.embedding_h.weight)
         rel = torch.mm(m.rel_wt, m.embedding_e.weight)

@@ -22,6 +22,7 @@ This package re-exports every name of its modules, so callers keep writing ``fro
 """
 from . import switches                                   # noqa: F401
 from ._base import (  # noqa: F401
+    bump_counters, deferred_counters,
     COMPOSE, REDUCE, ACT, gate_ld, same_rows, _same_memory, _cnt, _ws, _WS_BYTES, _ws_bytes, _SIDE_STREAMS, Fork,
 )
 from .candidates import (  # noqa: F401

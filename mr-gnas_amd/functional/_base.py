@@ -97,3 +97,39 @@ class Fork:
     def join(self):
         for st in self.side:
             self.main.wait_stream(st)
+
+
+# ---- BatchNorm step counters -------------------------------------------------------------------------------------------------
+# nn.BatchNorm1d counts its training forwards in `num_batches_tracked` (a device scalar per module).  The fused epilogues update the
+# running statistics inside their kernels; the counters are left to torch -- one multi-tensor launch per MixedOp, 22 per supernet
+# step.  Inside `deferred_counters()` (the networks' forward) they are collected and bumped by ONE launch at the end.
+_PENDING_COUNTERS = None
+
+
+def bump_counters(bns):
+    """num_batches_tracked += 1 for the BatchNorm modules of one fused epilogue (now, or at the end of the enclosing deferred_counters())."""
+    counters = [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
+    if not counters:
+        return
+    if _PENDING_COUNTERS is not None:
+        _PENDING_COUNTERS.extend(counters)
+    else:
+        torch._foreach_add_(counters, 1)
+
+
+@contextlib.contextmanager
+def deferred_counters():
+    """Collect the BatchNorm step counters of every fused epilogue inside the block and add 1 to all of them in one launch at its end
+    (re-entrant: an inner block leaves the flush to the outermost one)."""
+    global _PENDING_COUNTERS
+    if _PENDING_COUNTERS is not None:
+        yield
+        return
+    _PENDING_COUNTERS = []
+    try:
+        yield
+    finally:
+        pending, _PENDING_COUNTERS = _PENDING_COUNTERS, None
+        if pending:
+            torch._foreach_add_(pending, 1)
+

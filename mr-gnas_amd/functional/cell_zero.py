@@ -7,7 +7,7 @@ import torch
 from .. import _lib
 from .._lib import ptr_array, call, f32c, ptr, require_hip, stream_of
 from . import switches as SW
-from ._base import COMPOSE, _ws, _ws_bytes
+from ._base import COMPOSE, _ws, _ws_bytes, bump_counters
 from .gcs import span_gcs
 from .mixed import _all_reduce_sum
 
@@ -53,7 +53,7 @@ class _CellZeroMixed(torch.autograd.Function):
                 _all_reduce_sum(sums, group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:
-                torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+                bump_counters(bns)
         else:
             for k, b in enumerate(bns):
                 invstd = torch.rsqrt(b.running_var + b.eps)

@@ -7,7 +7,7 @@ import torch
 from .. import _lib
 from .._lib import ptr_array, call, f32c, ptr, require_hip, stream_of
 from . import switches as SW
-from ._base import _same_memory, _ws, _ws_bytes
+from ._base import _same_memory, _ws, _ws_bytes, bump_counters
 from .candidates import Candidate
 from .dense import _gated_rowscale
 
@@ -80,7 +80,7 @@ class _MixedEpilogue(torch.autograd.Function):
                     _all_reduce_sum(sums, cfg.group)
                 call("mrg_mix_finalize_fwd", (ptr(sums), ptr_array(gam), ptr_array(bet), rm, rv, K_, total, D, bn0.eps, mom, ptr(coef), st))
             if track:                                      # one multi-tensor launch instead of one per BatchNorm
-                torch._foreach_add_([b.num_batches_tracked for b in cfg.bns], 1)
+                bump_counters(cfg.bns)
         else:   # eval: fixed statistics
             for k, b in enumerate(cfg.bns):
                 invstd = torch.rsqrt(b.running_var + b.eps)

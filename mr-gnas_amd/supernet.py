@@ -124,6 +124,10 @@ class SearchNetwork(nn.Module):
     _plans = prepare
 
     def forward(self, g_train, node_id, src_in, edge_type):
+        with K.deferred_counters():                        # the BatchNorm step counters of all MixedOps: one launch at the end
+            return self._forward(g_train, node_id, src_in, edge_type)
+
+    def _forward(self, g_train, node_id, src_in, edge_type):
         ent_all = (self.linear_e(self.embedding_h.weight) if _cell_lp.CALLER == "reference"
                    else K.module_linear(self.linear_e, self.embedding_h.weight))
         rel = torch.mm(self.rel_wt, self.embedding_e.weight)
@@ -318,6 +322,10 @@ class FixedNetwork(nn.Module):
         return cached_on(g, "_mrg_fixed_plans", (src, etype), (self._num_rel, g.number_of_nodes()), build)
 
     def forward(self, g, subj, rel):
+        with K.deferred_counters():
+            return self._forward(g, subj, rel)
+
+    def _forward(self, g, subj, rel):
         ent = K.module_linear(self.linear_e, self.embedding_h.weight)
         rel_emb = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel = self._plans(g)

@@ -41,7 +41,15 @@ class Sites(TorchDispatchMode):
 args = bench.parse()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-step = bench.Step(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed))
+if args.rehearse_shard:                               # one rank of a W-way sharded step on one GPU (bench.py --rehearse-shard)
+    from mr_gnas_amd import cell_lp as CL, dist as MD, functional as K, rccl
+    r_, w_ = (int(v) for v in args.rehearse_shard.split("/"))
+    CL.MIXED_STREAMS = 1
+    K.switches.SEGMENT_STREAMS = 1
+    step = MD.ShardedStep(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed), r_, w_,
+                          group=rccl.VirtualWorld(r_, w_, dev))
+else:
+    step = bench.Step(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed))
 for _ in range(2):
     step()
 torch.cuda.synchronize()
