@@ -177,6 +177,51 @@ def test_linear_mfma_shapes():
             close(bd.grad, br.grad, "linear gb", rtol=5e-5, atol=5e-5)
 
 
+def test_module_linear_matches_nn_linear():
+    """functional.module_linear: an nn.Linear module on the library's row GEMM (entity projection, concat Linear) against the module
+    itself in float64: output and the three gradients; anything but float32 HIP rows falls through to the module."""
+    gen = torch.Generator().manual_seed(5)
+    for rows, K_, Nout in ((14541, 100, 200), (3000, 1000, 200), (257, 64, 64)):
+        mod = torch.nn.Linear(K_, Nout).to(DEV)
+        x = torch.randn(rows, K_, generator=gen).to(DEV).requires_grad_(True)
+        gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+        out = K.module_linear(mod, x)
+        out.backward(gy)
+        got = (out.detach(), x.grad.clone(), mod.weight.grad.clone(), mod.bias.grad.clone())
+        mod.zero_grad()
+        ref_mod = torch.nn.Linear(K_, Nout).double()
+        ref_mod.load_state_dict({k: v.double().cpu() for k, v in mod.state_dict().items()})
+        xr = x.detach().double().cpu().requires_grad_(True)
+        ref = ref_mod(xr)
+        ref.backward(gy.double().cpu())
+        for g_, r_, what in zip(got, (ref.detach(), xr.grad, ref_mod.weight.grad, ref_mod.bias.grad), ("out", "gx", "gW", "gb")):
+            err = float((g_.double().cpu() - r_).abs().max())
+            assert err <= 1e-4 * max(1.0, float(r_.abs().max())), f"module_linear {rows}x{K_}x{Nout} {what}: {err:.3e}"
+    mod = torch.nn.Linear(8, 4)
+    assert torch.equal(K.module_linear(mod, torch.ones(3, 8)), mod(torch.ones(3, 8)))          # CPU rows: the module itself
+
+
+def test_deferred_batchnorm_counters():
+    """functional.deferred_counters: the BatchNorm step counters of the fused epilogues inside the block are bumped by ONE launch at
+    its end (re-entrant), outside a block at once -- nn.BatchNorm1d's num_batches_tracked semantics either way."""
+    rows, D = 500, 64
+    bns = [torch.nn.BatchNorm1d(D).to(DEV) for _ in range(3)]
+    ys = [torch.randn(rows, D, device=DEV) for _ in range(3)]
+    w = torch.softmax(torch.randn(3, device=DEV), 0)
+    K.mixed_epilogue(ys, bns, w)
+    assert [int(b.num_batches_tracked) for b in bns] == [1, 1, 1]
+    with K.deferred_counters():
+        K.mixed_epilogue(ys, bns, w)
+        with K.deferred_counters():
+            K.mixed_epilogue(ys[:2], bns[:2], w[:2].contiguous())
+        assert [int(b.num_batches_tracked) for b in bns] == [1, 1, 1]          # nothing yet: the outermost block flushes
+    assert [int(b.num_batches_tracked) for b in bns] == [3, 3, 2]
+    for b in bns:
+        b.eval()
+    K.mixed_epilogue(ys, bns, w)
+    assert [int(b.num_batches_tracked) for b in bns] == [3, 3, 2]              # eval: no statistics, no count
+
+
 def test_act_grad_transpose_kernel():
     """mrg_act_grad_transpose: gT[n][b] = g[b][n] * act'(y[b][n]) for the three activation codes, ragged tile edges, bit for bit
     against the torch expressions it replaces (same products in the same order)."""
