@@ -477,6 +477,20 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3_k(WgradArgs a) {
 // ds_read_b128 per fragment.  Per workgroup and tile: 15 splits instead of 48 (TM = 7, KT = 8).  Two LDS buffers, one barrier per
 // tile; the loads of tile t + 2 are issued before the barrier of tile t and consumed (split) during the MFMAs of tile t + 1.
 // Same operands, same products, same accumulation order per output element as wgrad_x3_k: bit-identical partial tiles.
+// lab (tools/wgrad_trace_lab.hip, -DMRG_WGRAD_TRACE=1): shader-clock stamps of workgroup (0, 0, 0), per wave and 16-row tile:
+// mrg_wgrad_trace[(wave * 64 + tile) * 6 + i]: 0 top of the tile, 1 MFMAs issued, 2 fragments split and written, 3 next loads issued,
+// 4 past the barrier, 5 the 100 MHz clock at the top
+#ifndef MRG_WGRAD_TRACE
+#define MRG_WGRAD_TRACE 0
+#endif
+#if MRG_WGRAD_TRACE
+__device__ unsigned long long* mrg_wgrad_trace;
+#define MRG_WG_STAMP(i) do { if (traced && lane == 0 && t < 64) mrg_wgrad_trace[(wave * 64 + (int)t) * 6 + (i)] = \
+    (i) == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MRG_WG_STAMP(i) do { } while (0)
+#endif
+
 template <int NG>
 __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
   constexpr int KP = 8 / NG, KT = 2 * KP;
@@ -630,13 +644,21 @@ __global__ __launch_bounds__(WX_THREADS, 1) void wgrad_x3v_k(WgradArgs a) {
     fetch(nfull > 1 ? 1 : 0);
     __syncthreads();
     int cur = 0;
+#if MRG_WGRAD_TRACE
+    const bool traced = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+#endif
     for (int64_t t = 0; t < nfull; ++t) {
+      MRG_WG_STAMP(5); MRG_WG_STAMP(0);
       consume(cur);
+      MRG_WG_STAMP(1);
       // tile t + 1 (its loads were issued one tile ago) is split under this tile's MFMAs; then the loads of tile t + 2 (clamped:
       // past the end the last full tile is simply loaded again and never used)
       if (t + 1 < nfull) produce(cur ^ 1, std::false_type{});
+      MRG_WG_STAMP(2);
       fetch(t + 2 < nfull ? t + 2 : nfull - 1);
+      MRG_WG_STAMP(3);
       __syncthreads();
+      MRG_WG_STAMP(4);
       cur ^= 1;
     }
   }
