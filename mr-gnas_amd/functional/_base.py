@@ -112,7 +112,9 @@ def bump_counters(bns):
     if not counters:
         return
     if _PENDING_COUNTERS is not None:
-        _PENDING_COUNTERS.extend(counters)
+        for c in counters:                       # a module applied twice inside the block counts twice -- as ONE entry of the flush
+            slot = _PENDING_COUNTERS.setdefault(id(c), [c, 0])       # (a multi-tensor add must not see the same tensor twice)
+            slot[1] += 1
     else:
         torch._foreach_add_(counters, 1)
 
@@ -125,11 +127,14 @@ def deferred_counters():
     if _PENDING_COUNTERS is not None:
         yield
         return
-    _PENDING_COUNTERS = []
+    _PENDING_COUNTERS = {}
     try:
         yield
     finally:
         pending, _PENDING_COUNTERS = _PENDING_COUNTERS, None
-        if pending:
-            torch._foreach_add_(pending, 1)
+        by_count = {}
+        for c, n in pending.values():
+            by_count.setdefault(n, []).append(c)
+        for n, cs in by_count.items():           # one launch in the usual case (every module applied once)
+            torch._foreach_add_(cs, n)
 
