@@ -77,14 +77,17 @@ __global__ void hist_lds_k(const int32_t* __restrict__ key, int64_t n, int32_t* 
   for (int b = threadIdx.x; b < nbins; b += blockDim.x) hist_sm[b] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist_sm[key[i]], 1);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const int32_t k = key[i];
+    if ((unsigned)k < (unsigned)nbins) atomicAdd(&hist_sm[k], 1);          // -1 padding / out-of-range ids are skipped, not counted into a neighbour's bin
+  }
   __syncthreads();
   for (int b = threadIdx.x; b < nbins; b += blockDim.x) {
     const int32_t v = hist_sm[b];
     if (v) atomicAdd(&cnt[b], v);
   }
 }
-__global__ void hist_run_k(const int32_t* __restrict__ key, int64_t n, int32_t* __restrict__ cnt) {
+__global__ void hist_run_k(const int32_t* __restrict__ key, int64_t n, int32_t* __restrict__ cnt, int64_t nbins) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t i = t * HIST_RUN;
   if (i >= n) return;
@@ -93,10 +96,10 @@ __global__ void hist_run_k(const int32_t* __restrict__ key, int64_t n, int32_t* 
   for (++i; i < hi; ++i) {
     const int32_t k = key[i];
     if (k == cur) { ++c; continue; }
-    atomicAdd(&cnt[cur], c);
+    if ((uint64_t)cur < (uint64_t)nbins) atomicAdd(&cnt[cur], c);           // -1 padding / out-of-range ids are skipped (advisor r4)
     cur = k; c = 1;
   }
-  atomicAdd(&cnt[cur], c);
+  if ((uint64_t)cur < (uint64_t)nbins) atomicAdd(&cnt[cur], c);
 }
 static inline void launch_hist(const int32_t* key, int64_t n, int32_t* cnt, int64_t nbins, hipStream_t st) {
   if (n <= 0) return;
@@ -107,7 +110,7 @@ static inline void launch_hist(const int32_t* key, int64_t n, int32_t* cnt, int6
     hipLaunchKernelGGL(hist_lds_k, dim3((unsigned)blocks), dim3(256), (size_t)nbins * 4, st, key, n, cnt, (int)nbins, per_block);
   } else {
     const int64_t threads = (n + HIST_RUN - 1) / HIST_RUN;
-    hipLaunchKernelGGL(hist_run_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, key, n, cnt);
+    hipLaunchKernelGGL(hist_run_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, key, n, cnt, nbins > 0 ? nbins : ((int64_t)1 << 62));
   }
 }
 __global__ void iota_k(int32_t* __restrict__ out, int64_t n) {

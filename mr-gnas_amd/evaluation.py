@@ -24,23 +24,31 @@ def filtered_ranks(pred, labels, obj):
     return ranks
 
 
+_HITS = (1, 3, 10)
+
+
 def predict(val_test_loader, g, model, device):
-    """Reference train/mr_lp_train.py:269-314: returns (results, summed loss) with results['count'|'mr'|'mrr'|'hits@k']."""
+    """The evaluation pass of the fixed-genotype driver (reference train/mr_lp_train.py:269-314) with its bookkeeping on the device:
+    the per-batch rank statistics (number of predictions, sum of ranks, sum of reciprocal ranks, hits at 1 / 3 / 10) and the summed
+    BCE loss are accumulated in ONE float64 device vector and read back by ONE copy when the loader is exhausted -- the reference
+    synchronises three times per batch (`.item()`).  Returns (results, summed loss), results keyed 'count', 'mr', 'mrr', 'hits@k'
+    like the reference's, counts as int."""
+    ks = torch.tensor(_HITS, dtype=torch.float64, device=device)
+    acc = torch.zeros(4 + len(_HITS), dtype=torch.float64, device=device)       # [count, mr, mrr, loss, hits@k ...]
     with torch.no_grad():
-        results, test_loss = {}, []
         model.eval()
         for triplets, labels in val_test_loader:
             triplets, labels = triplets.to(device), labels.to(device)
-            subj, rel, obj = triplets[:, 0], triplets[:, 1], triplets[:, 2]
-            pred = model(g, subj, rel)
-            test_loss.append(F.binary_cross_entropy(pred, labels).item())
-            ranks = filtered_ranks(pred, labels, obj).float()
-            results['count'] = torch.numel(ranks) + results.get('count', 0)
-            results['mr'] = torch.sum(ranks).item() + results.get('mr', 0)
-            results['mrr'] = torch.sum(1.0 / ranks).item() + results.get('mrr', 0)
-            for k in [1, 3, 10]:
-                results[f'hits@{k}'] = torch.numel(ranks[ranks <= k]) + results.get(f'hits@{k}', 0)
-        return results, float(sum(test_loss))
+            pred = model(g, triplets[:, 0], triplets[:, 1])
+            ranks = filtered_ranks(pred, labels, triplets[:, 2]).double()
+            batch = torch.cat((torch.stack((ranks.new_tensor(float(ranks.numel())), ranks.sum(), ranks.reciprocal().sum(),
+                                            F.binary_cross_entropy(pred, labels).double())),
+                               (ranks.unsqueeze(0) <= ks.unsqueeze(1)).sum(dim=1).double()))
+            acc += batch
+    tot = acc.tolist()                                                          # the pass's only device -> host copy
+    results = {'count': int(tot[0]), 'mr': tot[1], 'mrr': tot[2]}
+    results.update({f'hits@{k}': int(tot[4 + i]) for i, k in enumerate(_HITS)})
+    return results, tot[3]
 
 
 def combine_results(left, right):

@@ -92,6 +92,11 @@ def module_linear(mod, x):
     """An nn.Linear module applied to HIP rows on the library's row GEMM (forward, input and weight gradient) instead of the
     vendor GEMM torch would pick: the entity projection and the cells' concat Linear (reference models/model_search_lp.py:131,
     models/cell_lp.py:186-188) are [N, .] x [., D] products whose Tensile kernels cost 60-120 us each at N = 14 541."""
-    if SW.NODE_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+    # The library path bypasses nn.Module.__call__: a module that carries forward (pre-)hooks, or a call under autocast, goes
+    # through torch so that the hooks fire and the cast happens (advisor r4; INTEGRATION.md section 1)
+    hooked = bool(mod._forward_hooks or mod._forward_pre_hooks or getattr(mod, "_forward_hooks_with_kwargs", None)
+                  or getattr(mod, "_forward_pre_hooks_with_kwargs", None))
+    if (SW.NODE_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not hooked
+            and not torch.is_autocast_enabled()):
         return linear(x, mod.weight, mod.bias)
     return mod(x)

@@ -50,6 +50,7 @@ def load():
     lib.ncclGetUniqueId.restype, lib.ncclGetUniqueId.argtypes = ci, [ctypes.POINTER(_UniqueId)]
     lib.ncclCommInitRank.restype, lib.ncclCommInitRank.argtypes = ci, [ctypes.POINTER(vp), ci, _UniqueId, ci]
     lib.ncclCommDestroy.restype, lib.ncclCommDestroy.argtypes = ci, [vp]
+    lib.ncclCommAbort.restype, lib.ncclCommAbort.argtypes = ci, [vp]
     lib.ncclGetErrorString.restype, lib.ncclGetErrorString.argtypes = ctypes.c_char_p, [ci]
     lib.ncclAllReduce.restype, lib.ncclAllReduce.argtypes = ci, [vp, vp, sz, ci, ci, vp, vp]
     lib.ncclReduceScatter.restype, lib.ncclReduceScatter.argtypes = ci, [vp, vp, sz, ci, ci, vp, vp]
@@ -69,18 +70,24 @@ class Comm:
 
     is_direct_rccl = True
 
-    def __init__(self, rank, world, device, bootstrap=None):
+    def __init__(self, rank, world, device, bootstrap=None, unique_id=None):
+        """`unique_id`: the 128 bytes rank 0 drew (bring_up() below distributes them in a step every rank takes part in whatever
+        happened before); None = draw / broadcast here (one-rank communicators, tests)."""
         lib = load()
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        if self.world > 1:
-            import torch.distributed as dist
-            box = [bytes(uid.internal) if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(bootstrap, 0) if bootstrap is not None else 0, group=bootstrap)
-            ctypes.memmove(ctypes.byref(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
         self._comm = ctypes.c_void_p()
+        self.launches = 0
+        uid = _UniqueId()
+        if unique_id is not None:
+            ctypes.memmove(ctypes.byref(uid), unique_id, _NCCL_UNIQUE_ID_BYTES)
+        else:
+            if self.rank == 0:
+                _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+            if self.world > 1:
+                import torch.distributed as dist
+                box = [bytes(uid.internal) if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(bootstrap, 0) if bootstrap is not None else 0, group=bootstrap)
+                ctypes.memmove(ctypes.byref(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
         # RCCL prints a version banner on the process's stdout when it initialises: keep stdout clean (bench.py prints ONE JSON line there)
         import sys
         sys.stdout.flush()
@@ -92,7 +99,24 @@ class Comm:
         finally:
             os.dup2(saved, 1)
             os.close(saved)
-        self.launches = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        # an exception between ncclCommInitRank and destroy() (a failed step, a failed capture) must not leak the communicator, and
+        # must not wait on a stream that a hung collective may never drain: abort instead of synchronise + destroy
+        if exc_type is None:
+            self.destroy()
+        else:
+            self.abort()
+        return False
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
 
     def size(self):
         return self.world
@@ -100,10 +124,11 @@ class Comm:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    @staticmethod
-    def _prep(t):
+    def _prep(self, t):
         if not t.is_cuda or not t.is_contiguous():
             raise RcclError("direct RCCL collectives take contiguous device tensors")
+        if t.device != self.device and not (t.device.index is None and self.device.index == torch.cuda.current_device()):
+            raise RcclError(f"tensor on {t.device}, communicator on {self.device}")
         if t.dtype not in _DTYPE:
             raise RcclError(f"dtype {t.dtype} has no RCCL counterpart")
         return ctypes.c_void_p(t.data_ptr()), _DTYPE[t.dtype]
@@ -132,10 +157,114 @@ class Comm:
         self.launches += 1
 
     def destroy(self):
+        """Orderly end: waits for the device, then frees the communicator.  After an error use abort()."""
         if self._comm:
             torch.cuda.synchronize(self.device)
             load().ncclCommDestroy(self._comm)
             self._comm = ctypes.c_void_p()
+
+    def abort(self):
+        """Error path: frees the communicator WITHOUT synchronising (a hung collective never drains its stream)."""
+        if self._comm:
+            comm, self._comm = self._comm, ctypes.c_void_p()
+            load().ncclCommAbort(comm)
+
+
+def _run_bounded(fn, timeout_s):
+    """fn() on a helper thread: (finished, result-or-exception).  A call that has not returned after timeout_s stays stuck on its
+    thread (a daemon: it cannot keep the process alive) and is reported as not finished."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["value"] = fn()
+        except BaseException as e:      # noqa: BLE001  (reported to the caller, never swallowed)
+            box["error"] = e
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return False, None
+    return True, box.get("error", box.get("value"))
+
+
+def bring_up(rank, world, device, control=None, timeout_s=120.0, log=None):
+    """A direct communicator over `world` ranks, brought up in STAGES that every rank leaves together (advisor r4: the one-try-block
+    bring-up of round 4 could leave peers in different collectives when one rank failed early).  `control`: the torch.distributed
+    group of the control plane (gloo); None = the default group.  Returns the Comm on every rank, or None on every rank (then the
+    caller falls back to torch.distributed's nccl backend).  A rank whose ncclCommInitRank or probe all-reduce has not RETURNED
+    after `timeout_s` cannot be recovered in-process (the call is stuck inside RCCL): after the ranks have agreed on it, every rank
+    logs and exits with status 3 -- the launcher then starts fresh processes; nothing is re-executed from a process that has
+    touched the GPU.
+
+      stage 1  load librccl.so                      -> agree (MIN over ranks)
+      stage 2  rank 0 draws the unique id           -> broadcast (every rank takes part; a failure travels as None)
+      stage 3  ncclCommInitRank, bounded            -> agree
+      stage 4  one probe all-reduce, bounded        -> agree
+    """
+    import torch.distributed as dist
+    say = log if log is not None else (lambda m: None)
+
+    def agree(ok):
+        flag = torch.tensor([int(bool(ok))], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=control)
+        return bool(int(flag.item()))
+
+    try:
+        load()
+        ok = True
+    except Exception as e:          # noqa: BLE001
+        say(f"rank {rank}: librccl.so did not load ({type(e).__name__}: {str(e)[:120]})")
+        ok = False
+    if not agree(ok):
+        return None
+    box = [None]
+    if rank == 0:
+        try:
+            uid = _UniqueId()
+            _check(load().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+            box = [bytes(uid.internal)]
+        except Exception as e:      # noqa: BLE001
+            say(f"rank 0: ncclGetUniqueId failed ({type(e).__name__}: {str(e)[:120]})")
+    dist.broadcast_object_list(box, src=(dist.get_global_rank(control, 0) if control is not None else 0), group=control)
+    if box[0] is None:
+        return None
+    done, comm = _run_bounded(lambda: Comm(rank, world, device, unique_id=box[0]), timeout_s)
+    stuck = not done
+    failed = stuck or isinstance(comm, BaseException)
+    if failed and not stuck:
+        say(f"rank {rank}: ncclCommInitRank failed ({type(comm).__name__}: {str(comm)[:120]})")
+    all_ok = agree(not failed)
+    any_stuck = not agree(not stuck)
+    if any_stuck:
+        say(f"rank {rank}: a rank's ncclCommInitRank did not return within {timeout_s:.0f} s; exiting (status 3) for a fresh launch")
+        os._exit(3)
+    if not all_ok:
+        if isinstance(comm, Comm):
+            comm.abort()
+        return None
+
+    def probe():
+        t = torch.ones(8, device=device)
+        comm.all_reduce(t, "sum")
+        torch.cuda.synchronize(device)
+        return bool((t == world).all())
+
+    done, good = _run_bounded(probe, timeout_s)
+    stuck = not done
+    failed = stuck or good is not True
+    all_ok = agree(not failed)
+    any_stuck = not agree(not stuck)
+    if any_stuck:
+        say(f"rank {rank}: the probe all-reduce did not complete within {timeout_s:.0f} s on some rank; exiting (status 3) for a fresh launch")
+        os._exit(3)
+    if not all_ok:
+        say(f"rank {rank}: the probe all-reduce gave a wrong sum or raised on some rank")
+        comm.abort()
+        return None
+    return comm
 
 
 class VirtualWorld:

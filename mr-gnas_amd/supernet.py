@@ -228,6 +228,7 @@ class OpModule(nn.Module):
         self.op = registry[name]({'feature_dim': feature_dim, 'drop_aggr': drop_aggr})
         self.op_name = name
         self.batchnorm_h = nn.BatchNorm1d(feature_dim)
+        self.register_buffer("_one", torch.ones(1), persistent=False)      # the one-branch epilogue's weight (not in state_dict; moves with .to())
 
     def forward(self, g, h, h_in):
         h = self.op(g, h, h_in)
@@ -236,9 +237,7 @@ class OpModule(nn.Module):
         if h.is_cuda:
             # BN + ReLU through the MixedOp epilogue kernels with one branch of weight 1 (statistics pass + combine pass; the
             # backward one reduction + one apply pass): torch's BatchNorm1d over [11 M, 256] rows took 9/10 of the C5 cell step
-            one = getattr(self, "_one", None)
-            if one is None or one.device != h.device:
-                one = self._one = torch.ones(1, dtype=torch.float32, device=h.device)
+            one = self._one if self._one.device == h.device else self._one.to(h.device)
             return K.mixed_epilogue([h], [self.batchnorm_h], one)
         return F.relu(self.batchnorm_h(h))
 
@@ -254,6 +253,7 @@ class FixedCell(nn.Module):
             self._ops[center - 1][pre].append(OpModule(feature_dim, drop_aggr, name, registry))
         self.concat = nn.Linear(len(self._concat_node) * feature_dim, feature_dim)
         self.batchnorm_h = nn.BatchNorm1d(feature_dim)
+        self.register_buffer("_one", torch.ones(1), persistent=False)
 
     def _caps(self):
         """Readers per state (state 0 = src_emb, 1 = the zero node's output, ...): the ops that take it as their first operand, the
@@ -287,9 +287,7 @@ class FixedCell(nn.Module):
             fans.append(fan(states[-1], n + 1))
         h = K.module_linear(self.concat, torch.cat([take(i) for i in self._concat_node], dim=1))
         if h.is_cuda:                                   # BN + ReLU on the MixedOp epilogue kernels with one branch of weight 1 (OpModule.forward)
-            one = getattr(self, "_one", None)
-            if one is None or one.device != h.device:
-                one = self._one = torch.ones(1, dtype=torch.float32, device=h.device)
+            one = self._one if self._one.device == h.device else self._one.to(h.device)
             return K.mixed_epilogue([h], [self.batchnorm_h], one)
         return F.relu(self.batchnorm_h(h))
 

@@ -59,15 +59,16 @@ def step_inputs(ds, negative, seed=0):
     return N, R, tri, samples, labels
 
 
-def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels, imposed=None):
-    """The oracle restatement of one supernet step in float64 on the device; returns ent, rel, loss and
+def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels, imposed=None, dtype=torch.float64):
+    """The oracle restatement of one supernet step in float64 (or, as the float32 CONTROL of VERDICT r4 #6, in `dtype` = float32: the
+    reference's own arithmetic -- plain torch ops in the reference's operator order -- at the reference's own precision) on the device; returns ent, rel, loss and
     {name: grad}, [alpha grads].  `imposed` ({site: bool mask}, the HIP run's ReLU decisions from functional.switches.MASK_TAP): the run takes
     THOSE decisions instead of its own (z * mask in place of relu(z)) and counts where its own would have differed -- "mask replay":
     both runs then evaluate the same piecewise-linear function, so what is left between their gradients is rounding alone."""
     src, dst, _ = g.edges(form="all")
-    og = OGraph(g.number_of_nodes(), src.cpu(), dst.cpu(), edge_type.cpu(), g.edata["norm"].cpu()).to(DEV, torch.float64)
-    P = {k: v.detach().double().requires_grad_(True) for k, v in model.named_parameters()}
-    al = [a.detach().double().requires_grad_(True) for a in model.arch_parameters()]
+    og = OGraph(g.number_of_nodes(), src.cpu(), dst.cpu(), edge_type.cpu(), g.edata["norm"].cpu()).to(DEV, dtype)
+    P = {k: v.detach().to(dtype).requires_grad_(True) for k, v in model.named_parameters()}
+    al = [a.detach().to(dtype).requires_grad_(True) for a in model.arch_parameters()]
     flips, near = {}, {}
 
     def hook(site, z):
@@ -111,7 +112,7 @@ def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels
     _OO.AGG_HOOK = agg_hook
     try:
         ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
-        loss = ON.distmult_bce(ent, rel, samples.long(), labels.double())
+        loss = ON.distmult_bce(ent, rel, samples.long(), labels.to(dtype))
         loss.backward()
     finally:
         ON.RELU_HOOK = None
@@ -173,12 +174,14 @@ def supernet_case(ds, D, negative):
     ref = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t)
     replay = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t, imposed=masks)
     replay["sites"] = len(masks)
+    # the float32 control: the same restatement at the reference's own precision (torch f32 kernels on this device)
+    f32 = oracle_supernet_f64(model, g, node_id, src, edge_type, R, samples_t, labels_t, dtype=torch.float32)
     replay["entries"] = int(sum((m[0].numel() * (32 if m[0].dtype == torch.int32 and len(m) == 1 else 1)) if isinstance(m, tuple) else m.numel()
                                 for m in masks.values()))
     masks.clear()
     free()
     return dict(model=model, g=g, node_id=node_id, src=src, edge_type=edge_type, R=R, N=N, samples=samples_t, labels=labels_t,
-                samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref, replay=replay)
+                samples_np=samples, labels_np=labels, tri=tri, hip=hip, ref=ref, replay=replay, f32=f32)
 
 
 # full-size gradient bound relative to a tensor's largest entry (f32 step against the float64 oracle over 5.6e5 rows).  The
@@ -222,6 +225,50 @@ def check_replay(hip, replay, what):
         assert err <= ALPHA_RTOL * max(scale, 1e-8) + 1e-7, f"{what}: alpha grad {i} under mask replay: {err:.3e}"
     print(f"{what}: mask replay: {total} flipped ReLU decisions in {replay['entries']} entries; gradients off beyond {REPLAY_RTOL:g}: {len(bad)}")
     assert not bad, f"{what}: with the ReLU decisions replayed, {len(bad)} gradients still differ: " + " | ".join(bad[:12])
+
+
+CONTROL_RATIO = 2.0    # HIP-vs-float64 error / torch-float32-vs-float64 error, per tensor (rms) and for the outputs
+
+
+def check_against_f32_control(hip, ctrl, ref, what):
+    """"within float32 rounding" as a MEASUREMENT.  `ctrl` is the oracle restatement run in float32 with plain torch
+    kernels on the same inputs -- what the reference's own arithmetic scores against float64.  Per tensor the HIP step's error
+    against float64 is set against the control's: rms error (one flipped ReLU bit moves one entry of a hub row's gradient in EITHER
+    run -- each run has its own handful of flips -- so the maximum is recorded but the bound is on the rms) must be <= CONTROL_RATIO x
+    the control's, with the control's error floored at float32's unit roundoff of the tensor's rms.  The table goes to
+    gpurun_out/parity_margins.json (kept: profiles/r5_parity_margins.json, records `... [f32 control]`)."""
+    from conftest import record_margin
+    rows, bad = [], []
+
+    def rms(t):
+        return float(t.double().square().mean().sqrt()) if t.numel() else 0.0
+
+    def one(name, h, c, r):
+        r = r.double()
+        e_h, e_c, base = rms(h.double() - r), rms(c.double() - r), rms(r)
+        m_h, m_c = float((h.double() - r).abs().max()), float((c.double() - r).abs().max())
+        floor = 6e-8 * max(base, 1e-30)
+        ratio = e_h / max(e_c, floor)
+        rows.append((ratio, name, e_h, e_c, m_h, m_c, base))
+        record_margin(what + " [f32 control]", f"{name}: rms err HIP {e_h:.3e} / torch-f32 {e_c:.3e} (max {m_h:.3e} / {m_c:.3e}; ref rms {base:.3e})",
+                      ratio, 1.0, CONTROL_RATIO)
+        if ratio > CONTROL_RATIO and e_h > 1e-6 * max(base, 1e-30):
+            bad.append(f"{name}: HIP {e_h:.3e} vs control {e_c:.3e} (x{ratio:.2f})")
+
+    one("output ent", hip["ent"], ctrl["ent"], ref["ent"])
+    one("output rel", hip["rel"], ctrl["rel"], ref["rel"])
+    for k, r in ref["g"].items():
+        one(k, hip["g"][k], ctrl["g"][k], r)
+    for i, r in enumerate(ref["ga"]):
+        one(f"alpha grad {i}", hip["ga"][i], ctrl["ga"][i], r)
+    l_h, l_c = abs(hip["loss"] - ref["loss"]), abs(ctrl["loss"] - ref["loss"])
+    record_margin(what + " [f32 control]", f"loss: |err| HIP {l_h:.3e} / torch-f32 {l_c:.3e}", l_h / max(l_c, 6e-8 * abs(ref["loss"])), 1.0, float("inf"))
+    ratios = sorted(r[0] for r in rows)
+    med = ratios[len(ratios) // 2]
+    record_margin(what + " [f32 control]", "median over tensors of (HIP rms err / torch-f32 rms err)", med, 1.0, CONTROL_RATIO)
+    rows.sort(reverse=True)
+    print(f"{what}: f32 control: median ratio {med:.2f}, worst " + "; ".join(f"{n} x{r:.2f}" for r, n, *_ in rows[:6]))
+    assert not bad, f"{what}: {len(bad)} tensors are further from float64 than {CONTROL_RATIO} x the float32 torch run: " + " | ".join(bad[:10])
 
 
 def check_step(hip, ref, what):
@@ -287,6 +334,10 @@ def test_c2_gradients_under_mask_replay(fb_case):
     check_replay(fb_case["hip"], fb_case["replay"], "C2 FB15k-237 supernet D=200")
 
 
+def test_c2_error_against_the_float32_control(fb_case):
+    check_against_f32_control(fb_case["hip"], fb_case["f32"], fb_case["ref"], "C2 FB15k-237 supernet D=200")
+
+
 def test_c4_sharded_step_world1_rccl_full_size(fb_case):
     """mr-gnas_amd/dist.py at FB15k-237 size: relation-block shard (world = 1: the whole graph, re-ordered by
     (relation, dst)), collectives through RCCL, SyncBN epilogues, flat gradient all-reduce -- against the plain
@@ -332,6 +383,7 @@ def test_c3_wn18rr_supernet_step_matches_float64_oracle():
         assert float(rel_hist.sort(descending=True).values[:4].sum()) / c["g"].num_edges() > 0.45  # 4 of 22 directed relations hold half the edges
         check_step(c["hip"], c["ref"], "C3 WN18RR supernet D=200")
         check_replay(c["hip"], c["replay"], "C3 WN18RR supernet D=200")
+        check_against_f32_control(c["hip"], c["f32"], c["ref"], "C3 WN18RR supernet D=200")
     finally:
         c.clear()
         free()

@@ -125,3 +125,50 @@ def test_sharded_supernet_matches_reference(tmp_path, world, case):
         got = res["g/" + k]
         scale = max(float(v.abs().max()), 1e-6)
         assert float((got - v).abs().max()) <= 2e-3 * scale + 5e-6, k
+
+
+def _bring_up_worker(rank, world, port, fault, out):
+    """rccl.bring_up with a fault injected on ONE rank: every rank must leave it together with None (advisor r4)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mr_gnas_amd import rccl
+
+        class FakeLib:
+            def ncclGetUniqueId(self, ref):
+                return 1 if fault == "unique_id" else 0
+
+            def ncclGetErrorString(self, code):
+                return b"injected"
+
+        def load():
+            if fault == "load" and rank == 1:
+                raise rccl.RcclError("injected: no librccl.so on this rank")
+            return FakeLib()
+
+        class FakeComm:
+            def __init__(self, r, w, d, unique_id=None):
+                if fault == "init" and r == 1:
+                    raise rccl.RcclError("injected: ncclCommInitRank failed on this rank")
+                self.aborted = False
+
+            def all_reduce(self, t, op):
+                pass
+
+            def abort(self):
+                self.aborted = True
+
+        rccl.load, rccl.Comm = load, FakeComm
+        got = rccl.bring_up(rank, world, "cpu", timeout_s=20.0)
+        torch.save({"none": got is None}, f"{out}.{rank}")
+        dist.barrier()                          # the ranks are still in step: a mismatched collective would hang or raise here
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fault", ["load", "unique_id", "init"])
+def test_direct_rccl_bring_up_fails_on_every_rank_together(tmp_path, fault):
+    out = str(tmp_path / "bring")
+    port = 31500 + (os.getpid() % 2000) + len(fault)
+    mp.spawn(_bring_up_worker, args=(2, port, fault, out), nprocs=2, join=True)
+    assert all(torch.load(f"{out}.{r}")["none"] for r in range(2))

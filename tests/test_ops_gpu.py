@@ -16,11 +16,18 @@ DEV = "cuda"
 OPS_CASES = ["ops_tiny_train", "ops_small_search", "ops_mid_train", "ops_d100_search", "ops_odd_train", "ops_r300_d64_search"]
 
 
-def close(a, b, what, rtol=1e-4, atol=2e-5):
+def close(a, b, what, rtol=1e-4, atol=2e-5, rms_rtol=1e-4):
+    """Two bounds: the largest error against the tensor's largest entry -- floored at 1.0, so for a tensor whose
+    entries are << 1 this bound alone is an ABSOLUTE 1.2e-4 -- and the rms error against the tensor's rms, which scales with the
+    tensor whatever its magnitude (a tensor of 1e-3-sized entries must agree to 1e-7, not to 1e-4)."""
     a = a.detach().cpu()
     scale = float(b.abs().max()) if b.numel() else 1.0
     err = float((a - b).abs().max()) if b.numel() else 0.0
     assert err <= atol + rtol * max(scale, 1.0), f"{what}: max err {err:.3e} (scale {scale:.3e})"
+    if b.numel() and rms_rtol is not None:
+        rms_b = float(b.double().square().mean().sqrt())
+        rms_e = float((a.double() - b.double()).square().mean().sqrt())
+        assert rms_e <= rms_rtol * rms_b + 1e-9, f"{what}: rms err {rms_e:.3e} against rms {rms_b:.3e} (ratio {rms_e / max(rms_b, 1e-300):.2e} > {rms_rtol:g})"
 
 
 def dev_graph(z):
