@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -75,6 +75,7 @@ SIGNATURES = {
     "mrg_gemm_set_mode": (_I, [_I]),
     "mrg_gemm_set_epilogue": (_I, [_I]),
     "mrg_gemm_set_wide8": (_I, [_I]),
+    "mrg_gemm_set_q": (_I, [_I]),
     "mrg_act_grad_transpose": (_I, [_P, _P, _P, _L, _L, _I, _P]),
     "mrg_wgrad_set_variant": (_I, [_I]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

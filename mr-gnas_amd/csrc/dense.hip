@@ -79,7 +79,7 @@ static bool dense3_shape_ok(int D, int K) { return D > 0 && (K == D || K == 2 * 
 
 extern "C" int64_t mrg_dense_filter3_workspace_bytes(int D, int K) {
   if (!dense3_shape_ok(D, K) || gemm_mode() == 1) return 0;  // 0: not available for this shape / split core switched off (use the per-segment entry points)
-  return 3 * (int64_t)(((int64_t)x3_bsplit_bytes(D, K, gemm_pick_nt(D)) + 255) / 256 * 256);
+  return 3 * (int64_t)(((int64_t)bsplit_bytes_any(D, K) + 255) / 256 * 256);
 }
 
 extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in, const float* const* W_host, const float* const* bias_host,
@@ -96,7 +96,7 @@ extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in
   if (!ws) return MRG_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t lo[3] = {0, b0, b1}, hi[3] = {b0, b1, M};
-  const size_t each = (size_t)(((int64_t)x3_bsplit_bytes(D, K, gemm_pick_nt(D)) + 255) / 256 * 256);
+  const size_t each = (size_t)(((int64_t)bsplit_bytes_any(D, K) + 255) / 256 * 256);
   GemmArgs a{};
   a.A1 = s; a.K1 = D; a.A2 = s_in; a.K2 = s_in ? D : 0;
   a.C = out; a.ldc = D; a.N = D; a.rows = M; a.rowscale = norm;
@@ -115,7 +115,7 @@ extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in
     a.grp.scale[i] = i < 2 ? scale_edge : scale_self;
     a.grp.use_rowscale[i] = (i < 2 && norm) ? 1 : 0;
   }
-  launch_bsplit3(Bs, K, 1, D, K, gemm_pick_nt(D), outs, st);
+  launch_bsplit3_any(kind == 0 ? EPI_GATE : EPI_SCALE, Bs, K, 1, D, K, outs, st);
   MRG_LAUNCH_CHECK();
   if (kind == 0) return launch_rowgemm_x3_mode<EPI_GATE>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_SCALE>(a, outs[0], st);

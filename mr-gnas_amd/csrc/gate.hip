@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
   const float* u = uvc + (int64_t)seg * ld;
   const float cc = u[HAS_IN ? 2 * D : D];
   Vec<VEC> uk[KMAX], vk[KMAX], du[KMAX], dvv[KMAX];
-  float dc = 0.f;
+  double dc = 0.0;                                        // the sum of mixed-sign dz_r cancels heavily: double (round-5 f32 control)
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     int c = sl + k * LPR;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
     float t = scale * (use_norm ? norm[r] : 1.0f);
     float dz = q * t * gt * (1.0f - gt);
     float f = gt * t;
-    dc += dz;
+    dc += (double)dz;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       int c = sl + k * LPR;
@@ -172,17 +172,17 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
       mine[WIDTH + c * VEC + j] = dvv[k][j];
     }
   }
-  if (sl == 0) mine[2 * WIDTH] = dc;
+  if (sl == 0) mine[2 * WIDTH] = (float)dc;
   __syncthreads();
   float* dst = ws + (int64_t)b * ld;
   for (int t = threadIdx.x; t < ld; t += MRG_BLOCK) {
     int srcidx = t < D ? t : ((HAS_IN && t < 2 * D) ? WIDTH + (t - D) : (t == cidx ? 2 * WIDTH : -1));
-    float acc = 0.f;
+    double acc = 0.0;
     if (srcidx >= 0) {
 #pragma unroll
-      for (int q = 0; q < RPB; ++q) acc += red[q * (2 * WIDTH + 1) + srcidx];
+      for (int q = 0; q < RPB; ++q) acc += (double)red[q * (2 * WIDTH + 1) + srcidx];
     }
-    dst[t] = acc;
+    dst[t] = (float)acc;
   }
 }
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_row_bwd_k(const float* __restr
   const int cidx = HAS_IN ? 2 * D : D;
   const float* u = uvc + (int64_t)seg * ld;
   Vec<VEC> vk[KMAX], du[KMAX], dvv[KMAX];
-  float dc = 0.f;
+  double dc = 0.0;                                        // the sum of mixed-sign dz_r cancels heavily: double (round-5 f32 control)
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     int c = sl + k * LPR;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_row_bwd_k(const float* __restr
   }
   for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
     const float dz = qv[r] * hv[r];
-    dc += dz;
+    dc += (double)dz;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       int c = sl + k * LPR;
@@ -299,17 +299,17 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_row_bwd_k(const float* __restr
       mine[WIDTH + c * VEC + j] = dvv[k][j];
     }
   }
-  if (sl == 0) mine[2 * WIDTH] = dc;
+  if (sl == 0) mine[2 * WIDTH] = (float)dc;
   __syncthreads();
   float* dst = ws + (int64_t)b * ld;
   for (int t = threadIdx.x; t < ld; t += MRG_BLOCK) {
     int srcidx = t < D ? t : ((HAS_IN && t < 2 * D) ? WIDTH + (t - D) : (t == cidx ? 2 * WIDTH : -1));
-    float acc = 0.f;
+    double acc = 0.0;
     if (srcidx >= 0) {
 #pragma unroll
-      for (int q = 0; q < RPB; ++q) acc += red[q * (2 * WIDTH + 1) + srcidx];
+      for (int q = 0; q < RPB; ++q) acc += (double)red[q * (2 * WIDTH + 1) + srcidx];
     }
-    dst[t] = acc;
+    dst[t] = (float)acc;
   }
 }
 
@@ -318,9 +318,9 @@ __global__ void gate_reduce_k(const float* __restrict__ ws, float* __restrict__ 
   int seg = blockIdx.y;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ld) return;
-  float acc = 0.f;
-  for (int b = p.blk[seg]; b < p.blk[seg + 1]; ++b) acc += ws[(int64_t)b * ld + t];
-  d_uvc[seg * ld + t] = acc;
+  double acc = 0.0;                                      // hundreds of block partials of mixed sign, in block order: double
+  for (int b = p.blk[seg]; b < p.blk[seg + 1]; ++b) acc += (double)ws[(int64_t)b * ld + t];
+  d_uvc[seg * ld + t] = (float)acc;
 }
 
 // uvc[k] = sum_j W[j,k] a[j]  (k < in_dim);  uvc[in_dim] = sum_j a[j] b[j].

@@ -5,6 +5,7 @@
 #include "gemm_x3.hpp"
 #include "gemm_x3s.hpp"
 #include "gemm_x3s8.hpp"
+#include "gemm_x3q.hpp"
 
 namespace mrg {
 
@@ -18,9 +19,51 @@ namespace mrg {
 // dense-filter forward 6.5 -> 5.9; 68.2 -> 65.5 ms / step, profiles/r3_rowgemm_lds_weight.txt).
 inline int& gemm_mode() { static int m = 0; return m; }
 
+// Which launches take the 16 x 16 x 32 kernel of gemm_x3q.hpp (round 5): a pure function of the epilogue kind and of the product's
+// shape, so that the code that prepares the weight split and the code that launches the GEMM agree without talking.  Its column
+// block is 14 tiles of 16 (129..224 columns: narrower products keep the four-tile blocks of rowgemm_x3s_k, wider ones its eight-tile
+// sibling); the fused aggregators' epilogues (EPI_SEGMAX / EPI_SEGSUM: run structure tied to the 32-row strip) stay on rowgemm_x3s_k.
+// Measured (profiles/r5_rowgemm_q.txt, rows 558 771, interleaved rounds in one process): at K = 400 (the dense filters' forward on
+// two operands, the paired input gradient) 0.552 vs 0.584 ms (-5 %), gate-only forward -7..-12 %; at K = 200 equal (0.986-1.017): the
+// reduction dimension has to be long enough for the smaller tile's doubled weight traffic (L2 -> LDS 2.6 GB instead of 1.2 GB per
+// launch) to be paid back, so gemm_q() == 1 (default) takes only K > X3Q_MIN_K; 2 (lab) takes every K > 48.
+constexpr int X3Q_MIN_K = 224;
+inline bool x3q_shape(int epi, int N, int K) {
+  return gemm_mode() == 0 && gemm_q() != 0 && epi != EPI_SEGMAX && epi != EPI_SEGSUM && N > 128 && N <= X3Q_NT * 16
+         && K > (gemm_q() == 2 ? 48 : X3Q_MIN_K);
+}
+
+// bytes of ONE pre-split weight in whichever layout a launch of this shape may use
+inline size_t bsplit_bytes_any(int N, int K) {
+  const size_t a = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
+  const size_t q = (N > 128 && N <= X3Q_NT * 16) ? x3q_bsplit_bytes(K) : 0;
+  return a > q ? a : q;
+}
+
+// the weight split of a launch with epilogue `epi`: B(n, k) = B[n * sn + k * sk]
+inline void launch_bsplit_any(int epi, const float* B, int64_t sn, int64_t sk, int N, int K, void* Bp, hipStream_t st) {
+  if (x3q_shape(epi, N, K)) {
+    const float* Bs[1] = {B};
+    void* outs[1] = {Bp};
+    launch_bsplitq3(Bs, sn, sk, N, K, outs, 1, st);
+  } else {
+    launch_bsplit(B, sn, sk, N, K, gemm_pick_nt(N), Bp, st);
+  }
+}
+inline void launch_bsplit3_any(int epi, const float* const* B, int64_t sn, int64_t sk, int N, int K, void* const* out, hipStream_t st,
+                               const float* const* B2 = nullptr, int ksplit = 0) {
+  if (x3q_shape(epi, N, K)) launch_bsplitq3(B, sn, sk, N, K, out, 3, st, B2, ksplit);
+  else launch_bsplit3(B, sn, sk, N, K, gemm_pick_nt(N), out, st, B2, ksplit);
+}
+
 // the split-core row GEMM of the current mode for launches that prepared their own weight split (grouped launches, fused aggregators)
+// with launch_bsplit_any / launch_bsplit3_any
 template <int EPI>
 inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
+  if (x3q_shape(EPI, a.N, a.K1 + a.K2)) {
+    if (!x3q_eligible(a)) return MRG_E_SHAPE;              // the split was prepared in this kernel's layout: no other kernel can read it
+    return launch_rowgemm_x3q<EPI>(a, Bp, st);
+  }
   if (gemm_mode() != 2 && x3s_eligible(a)) {
     // eight column tiles (D = 256) as ONE block where the epilogue fits (gemm_x3s8.hpp): the activation operand is read once
     if constexpr (EPI != EPI_GATE) {
@@ -32,7 +75,7 @@ inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
 }
 
 inline size_t gemm_workspace_bytes(int K, int N) {
-  const size_t split = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
+  const size_t split = bsplit_bytes_any(N, K);
   const size_t transp = (size_t)K * N * sizeof(float);
   return split > transp ? split : transp;
 }
@@ -45,7 +88,7 @@ inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStre
   if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
   const int K = a.K1 + a.K2;
   if (ws && gemm_mode() != 1 && x3_eligible(a)) {
-    launch_bsplit(a.B, b_sn, b_sk, a.N, K, gemm_pick_nt(a.N), ws, st);
+    launch_bsplit_any(EPI, a.B, b_sn, b_sk, a.N, K, ws, st);
     return launch_rowgemm_x3_mode<EPI>(a, ws, st);
   }
   if (b_sk != 1) {                                   // present B^T row-major to the f32 core

@@ -895,7 +895,7 @@ static bool segmax_shape_ok(int K, int Nout) { return K > 48 && K % 4 == 0 && No
 
 extern "C" int64_t mrg_linear_relu_segmax_workspace_bytes(int64_t N, int K, int Nout) {
   if (N < 0 || !segmax_shape_ok(K, Nout) || gemm_mode() == 1) return 0;   // 0: the split core cannot take the shape or is switched off (use the unfused entry points)
-  return ((N * (int64_t)Nout * 8 + 255) / 256) * 256 + (int64_t)x3_bsplit_bytes(Nout, K, gemm_pick_nt(Nout)) + 256;
+  return ((N * (int64_t)Nout * 8 + 255) / 256) * 256 + (int64_t)bsplit_bytes_any(Nout, K) + 256;
 }
 
 extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const float* bias, const int32_t* eid, const int32_t* dst,
@@ -918,7 +918,7 @@ extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const 
     a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
     a.row_index = eid; a.row_seg = dst; a.seg_out = keys;
     if (!x3_eligible(a)) return MRG_E_SHAPE;
-    launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), bsplit, st);
+    launch_bsplit_any(EPI_SEGMAX, W, K, 1, Nout, K, bsplit, st);
     const int rc = launch_rowgemm_x3_mode<EPI_SEGMAX>(a, bsplit, st);
     if (rc != MRG_OK) return rc;
   }
@@ -944,7 +944,7 @@ extern "C" int mrg_linear_relu_segsum_fwd(const float* X, const float* W, const 
   a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
   a.row_index = eid; a.row_seg = dst; a.seg_part = part; a.relu_bits = relu_bits; a.bits_ld = (Nout + 31) / 32;
   if (!x3_eligible(a)) return MRG_E_SHAPE;
-  launch_bsplit(W, K, 1, Nout, K, gemm_pick_nt(Nout), ws, st);
+  launch_bsplit_any(EPI_SEGSUM, W, K, 1, Nout, K, ws, st);
   return launch_rowgemm_x3_mode<EPI_SEGSUM>(a, ws, st);
 }
 
@@ -968,6 +968,12 @@ extern "C" int mrg_wgrad_set_variant(int variant) {
 extern "C" int mrg_gemm_set_wide8(int on) {
   if (on < 0 || on > 2) return MRG_E_ENUM;          // 2 (lab): seven-tile plain launches on the ring-of-two kernel as well
   gemm_wide8() = on;
+  return MRG_OK;
+}
+
+extern "C" int mrg_gemm_set_q(int on) {
+  if (on < 0 || on > 2) return MRG_E_ENUM;          // 2 (lab, tests): every eligible K, not only K > 224
+  gemm_q() = on;
   return MRG_OK;
 }
 
@@ -1016,7 +1022,7 @@ extern "C" int mrg_linear_bwd_input(const float* gY, const float* W, float* gX, 
 // ---- the three direction segments of a dense filter in one launch each (split core only) -----------------------------------
 // gX rows [0, b0) (+)= gY W[0][:, 0:K], rows [b0, b1) with W[1], rows [b1, M) with W[2]; W: HOST array of three device
 // pointers to [Nout][ldw] weights (a column block when offset by the caller).
-static size_t bwd_input3_each(int K, int Nout) { return (size_t)(((int64_t)x3_bsplit_bytes(K, Nout, gemm_pick_nt(K)) + 255) / 256 * 256); }
+static size_t bwd_input3_each(int K, int Nout) { return (size_t)(((int64_t)bsplit_bytes_any(K, Nout) + 255) / 256 * 256); }
 
 extern "C" int64_t mrg_linear_bwd_input3_workspace_bytes(int K, int Nout) {
   if (K <= 0 || Nout <= 48 || Nout % 4 != 0 || gemm_mode() == 1) return 0;      // 0: the split core cannot take the shape / is switched off
@@ -1048,7 +1054,7 @@ extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host
     a.grp.lo[i] = lo[i]; a.grp.hi[i] = live ? hi[i] : lo[i];
     a.grp.scale[i] = 1.0f;
   }
-  launch_bsplit3(Bs, 1, ldw, K, Nout, gemm_pick_nt(K), outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
+  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, Bs, 1, ldw, K, Nout, outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
   MRG_LAUNCH_CHECK();
   if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);
@@ -1058,7 +1064,7 @@ extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host
 // dimension, [gY1 | gY2] [W1 ; W2]: the input gradient of two candidates that read the same rows (f_dense_comp and f_comp of
 // one MixedOp, reference models/cell_lp.py:95-113, models/operations_lp.py:266-288,356-390) written once instead of two
 // gradients that a fan-in pass adds.
-static size_t bwd_input3_pair_each(int K, int Nout) { return (size_t)(((int64_t)x3_bsplit_bytes(K, 2 * Nout, gemm_pick_nt(K)) + 255) / 256 * 256); }
+static size_t bwd_input3_pair_each(int K, int Nout) { return (size_t)(((int64_t)bsplit_bytes_any(K, 2 * Nout) + 255) / 256 * 256); }
 
 extern "C" int64_t mrg_linear_bwd_input3_pair_workspace_bytes(int K, int Nout) {
   if (K <= 0 || Nout <= 24 || Nout % 4 != 0 || gemm_mode() == 1) return 0;
@@ -1091,7 +1097,7 @@ extern "C" int mrg_linear_bwd_input3_pair(const float* gY1, const float* gY2, co
     a.grp.scale[i] = 1.0f;
   }
   // B(n = k_in, k) = k < Nout ? W1[k * ldw + k_in] : W2[(k - Nout) * ldw + k_in]
-  launch_bsplit3(Bs, 1, ldw, K, 2 * Nout, gemm_pick_nt(K), outs, st, Bs2, Nout);
+  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, Bs, 1, ldw, K, 2 * Nout, outs, st, Bs2, Nout);
   MRG_LAUNCH_CHECK();
   if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);

@@ -121,13 +121,18 @@ class Comm:
     def size(self):
         return self.world
 
+    @staticmethod
+    def _index(device):
+        """cuda and cuda:<current> are the same device."""
+        return device.index if device.index is not None else torch.cuda.current_device()
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _prep(self, t):
         if not t.is_cuda or not t.is_contiguous():
             raise RcclError("direct RCCL collectives take contiguous device tensors")
-        if t.device != self.device and not (t.device.index is None and self.device.index == torch.cuda.current_device()):
+        if self._index(t.device) != self._index(self.device):
             raise RcclError(f"tensor on {t.device}, communicator on {self.device}")
         if t.dtype not in _DTYPE:
             raise RcclError(f"dtype {t.dtype} has no RCCL counterpart")

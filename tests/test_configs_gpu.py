@@ -228,46 +228,62 @@ def check_replay(hip, replay, what):
 
 
 CONTROL_RATIO = 2.0    # HIP-vs-float64 error / torch-float32-vs-float64 error, per tensor (rms) and for the outputs
+CONTROL_MEDIAN = 0.5   # over the tensors of a step: measured 0.08-0.10 (the HIP step is ~10x CLOSER to float64 than torch's float32 kernels)
+CONTROL_P90 = 1.0      # measured 0.47-0.63
 
 
-def check_against_f32_control(hip, ctrl, ref, what):
+def check_against_f32_control(hip, ctrl, ref, replay, what):
     """"within float32 rounding" as a MEASUREMENT.  `ctrl` is the oracle restatement run in float32 with plain torch
     kernels on the same inputs -- what the reference's own arithmetic scores against float64.  Per tensor the HIP step's error
-    against float64 is set against the control's: rms error (one flipped ReLU bit moves one entry of a hub row's gradient in EITHER
-    run -- each run has its own handful of flips -- so the maximum is recorded but the bound is on the rms) must be <= CONTROL_RATIO x
-    the control's, with the control's error floored at float32's unit roundoff of the tensor's rms.  The table goes to
-    gpurun_out/parity_margins.json (kept: profiles/r5_parity_margins.json, records `... [f32 control]`)."""
+    against float64 is set against the control's (rms over the tensor; the control's error floored at float32's unit roundoff of the
+    tensor's rms and at 1e-8 absolute: a gradient that is identically zero has no relative scale).  Bounds: the median ratio over
+    the tensors of a step <= CONTROL_MEDIAN, the 90th percentile <= CONTROL_P90, and every tensor <= CONTROL_RATIO -- except
+    tensors whose error is a flipped ReLU decision (each float32 run has its own handful of pre-activations within rounding of zero
+    that land on the other side; one flip moves every parameter gradient of its candidate): those must be back within
+    CONTROL_RATIO x the control once the comparison is against the float64 run that TAKES the HIP run's decisions (`replay`).
+    The table goes to gpurun_out/parity_margins.json (kept: profiles/r5_parity_margins.json, records `... [f32 control]`)."""
     from conftest import record_margin
-    rows, bad = [], []
+    rows, bad, flipped = [], [], []
 
     def rms(t):
         return float(t.double().square().mean().sqrt()) if t.numel() else 0.0
 
-    def one(name, h, c, r):
+    def one(name, h, c, r, rp):
         r = r.double()
         e_h, e_c, base = rms(h.double() - r), rms(c.double() - r), rms(r)
         m_h, m_c = float((h.double() - r).abs().max()), float((c.double() - r).abs().max())
-        floor = 6e-8 * max(base, 1e-30)
+        floor = max(6e-8 * base, 1e-8)
         ratio = e_h / max(e_c, floor)
-        rows.append((ratio, name, e_h, e_c, m_h, m_c, base))
-        record_margin(what + " [f32 control]", f"{name}: rms err HIP {e_h:.3e} / torch-f32 {e_c:.3e} (max {m_h:.3e} / {m_c:.3e}; ref rms {base:.3e})",
+        rows.append((ratio, name))
+        note = ""
+        if ratio > CONTROL_RATIO:
+            e_rp = rms(h.double() - rp.double())
+            if e_rp <= CONTROL_RATIO * max(e_c, floor):
+                flipped.append(name)
+                note = f"; with the HIP run's ReLU decisions replayed {e_rp:.3e} (x{e_rp / max(e_c, floor):.2f}): a flip"
+            else:
+                bad.append(f"{name}: HIP {e_h:.3e} vs control {e_c:.3e} (x{ratio:.2f}; replayed {e_rp:.3e})")
+        record_margin(what + " [f32 control]", f"{name}: rms err HIP {e_h:.3e} / torch-f32 {e_c:.3e} (max {m_h:.3e} / {m_c:.3e}; ref rms {base:.3e}){note}",
                       ratio, 1.0, CONTROL_RATIO)
-        if ratio > CONTROL_RATIO and e_h > 1e-6 * max(base, 1e-30):
-            bad.append(f"{name}: HIP {e_h:.3e} vs control {e_c:.3e} (x{ratio:.2f})")
 
-    one("output ent", hip["ent"], ctrl["ent"], ref["ent"])
-    one("output rel", hip["rel"], ctrl["rel"], ref["rel"])
+    one("output ent", hip["ent"], ctrl["ent"], ref["ent"], replay["ent"])
+    one("output rel", hip["rel"], ctrl["rel"], ref["rel"], replay["rel"])
     for k, r in ref["g"].items():
-        one(k, hip["g"][k], ctrl["g"][k], r)
+        one(k, hip["g"][k], ctrl["g"][k], r, replay["g"][k])
     for i, r in enumerate(ref["ga"]):
-        one(f"alpha grad {i}", hip["ga"][i], ctrl["ga"][i], r)
+        one(f"alpha grad {i}", hip["ga"][i], ctrl["ga"][i], r, replay["ga"][i])
     l_h, l_c = abs(hip["loss"] - ref["loss"]), abs(ctrl["loss"] - ref["loss"])
     record_margin(what + " [f32 control]", f"loss: |err| HIP {l_h:.3e} / torch-f32 {l_c:.3e}", l_h / max(l_c, 6e-8 * abs(ref["loss"])), 1.0, float("inf"))
     ratios = sorted(r[0] for r in rows)
-    med = ratios[len(ratios) // 2]
-    record_margin(what + " [f32 control]", "median over tensors of (HIP rms err / torch-f32 rms err)", med, 1.0, CONTROL_RATIO)
+    med, p90 = ratios[len(ratios) // 2], ratios[int(0.9 * len(ratios))]
+    record_margin(what + " [f32 control]", "median over tensors of (HIP rms err / torch-f32 rms err)", med, 1.0, CONTROL_MEDIAN)
+    record_margin(what + " [f32 control]", "90th percentile over tensors of (HIP rms err / torch-f32 rms err)", p90, 1.0, CONTROL_P90)
+    record_margin(what + " [f32 control]", f"tensors beyond {CONTROL_RATIO} x the control that a replayed ReLU decision explains: {', '.join(flipped) or 'none'}",
+                  len(flipped), max(len(rows), 1), 0.03 * len(rows))
     rows.sort(reverse=True)
-    print(f"{what}: f32 control: median ratio {med:.2f}, worst " + "; ".join(f"{n} x{r:.2f}" for r, n, *_ in rows[:6]))
+    print(f"{what}: f32 control: median ratio {med:.2f}, p90 {p90:.2f}, flip-explained {len(flipped)}, worst " + "; ".join(f"{n} x{r:.2f}" for r, n in rows[:6]))
+    assert med <= CONTROL_MEDIAN and p90 <= CONTROL_P90, f"{what}: error ratio against the float32 control: median {med:.2f}, p90 {p90:.2f}"
+    assert len(flipped) <= 0.03 * len(rows), f"{what}: {len(flipped)} of {len(rows)} tensors need a replayed decision to reach the control's error"
     assert not bad, f"{what}: {len(bad)} tensors are further from float64 than {CONTROL_RATIO} x the float32 torch run: " + " | ".join(bad[:10])
 
 
@@ -335,7 +351,7 @@ def test_c2_gradients_under_mask_replay(fb_case):
 
 
 def test_c2_error_against_the_float32_control(fb_case):
-    check_against_f32_control(fb_case["hip"], fb_case["f32"], fb_case["ref"], "C2 FB15k-237 supernet D=200")
+    check_against_f32_control(fb_case["hip"], fb_case["f32"], fb_case["ref"], fb_case["replay"], "C2 FB15k-237 supernet D=200")
 
 
 def test_c4_sharded_step_world1_rccl_full_size(fb_case):
@@ -383,7 +399,7 @@ def test_c3_wn18rr_supernet_step_matches_float64_oracle():
         assert float(rel_hist.sort(descending=True).values[:4].sum()) / c["g"].num_edges() > 0.45  # 4 of 22 directed relations hold half the edges
         check_step(c["hip"], c["ref"], "C3 WN18RR supernet D=200")
         check_replay(c["hip"], c["replay"], "C3 WN18RR supernet D=200")
-        check_against_f32_control(c["hip"], c["f32"], c["ref"], "C3 WN18RR supernet D=200")
+        check_against_f32_control(c["hip"], c["f32"], c["ref"], c["replay"], "C3 WN18RR supernet D=200")
     finally:
         c.clear()
         free()

@@ -737,6 +737,7 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
     base = torch.randn(rows, K1, generator=gen).to(DEV)
     res = {}
     try:
+        assert lib.mrg_gemm_set_q(0) == 0           # the 16 x 16 x 32 kernel (round 5) sums k 32 at a time: equal to rounding, tested below
         for order in ((0, 0, 1), (0, 0, 0), (0, 2, 0), (2, 0, 1), (2, 1, 1)):
             assert lib.mrg_gemm_set_mode(order[0]) == 0 and lib.mrg_gemm_set_epilogue(order[1]) == 0 and lib.mrg_gemm_set_wide8(order[2]) == 0
             outs = []
@@ -762,11 +763,88 @@ def test_split_core_kernels_are_bit_exact_with_each_other(rows, K1, K2, Nout):
         lib.mrg_gemm_set_epilogue(0)
         lib.mrg_gemm_set_mode(0)
         lib.mrg_gemm_set_wide8(1)
+        lib.mrg_gemm_set_q(1)
     assert len(res[(0, 0, 1)]) > 0
     for other in ((0, 0, 0), (0, 2, 0), (2, 0, 1), (2, 1, 1)):
         assert len(res[other]) == len(res[(0, 0, 1)])
         for i, (x, y) in enumerate(zip(res[(0, 0, 1)], res[other])):
             assert torch.equal(x, y), (other, i, float((x - y).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K1,K2,Nout", [(70001, 200, 0, 200), (66000, 200, 200, 200), (558771, 200, 0, 200), (33, 200, 0, 200), (64, 160, 0, 160),
+                                             (100003, 400, 0, 200), (4097, 132, 132, 132), (20000, 64, 0, 224), (12345, 200, 0, 129), (1, 200, 0, 200)])
+def test_three_waves_per_simd_row_gemm_agrees_with_the_two_wave_kernel(rows, K1, K2, Nout):
+    """rowgemm_x3q_k (round 5: 16 x 16 x 32 tiles, 16 rows per wave, three workgroups per CU, weight half-slabs through a ring of two
+    LDS buffers; the default for 129..224 output columns) against rowgemm_x3s_k (mrg_gemm_set_q(0)) and against float64: the same
+    six cross terms, summed over k 32 at a time instead of 16, so the two agree to rounding of the f32 accumulation -- each output
+    within 4e-6 of the output scale of the other, and the new kernel's error against float64 at most 1.5 x the old one's (+ 1e-6 of
+    the scale).  Every epilogue the kernel has: bias + none / ReLU / sigmoid, accumulate, gate with and without the stored product,
+    row scale; single and dual source, K % 32 != 0, ragged last strips, a single row, a partial last column pair, and the three
+    direction segments in one grouped launch (mrg_dense_filter_fwd3 / mrg_linear_bwd_input3 / _pair)."""
+    from mr_gnas_amd._lib import call, ptr, ptr_array, stream_of
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(rows + Nout + K2 + 5)
+    s = (torch.randn(rows, K1, generator=gen) * 2).to(DEV)
+    s_in = torch.randn(rows, K2, generator=gen).to(DEV) if K2 else None
+    K_ = K1 + K2
+    W = (torch.randn(Nout, K_, generator=gen) / K_ ** 0.5).to(DEV)
+    W3 = [(torch.randn(Nout, K_, generator=gen) / K_ ** 0.5).to(DEV) for _ in range(3)]
+    b = torch.randn(Nout, generator=gen).to(DEV)
+    b3 = [torch.randn(Nout, generator=gen).to(DEV) for _ in range(3)]
+    norm = (torch.rand(rows, generator=gen) + 0.1).to(DEV)
+    gy = torch.randn(rows, Nout, generator=gen).to(DEV)
+    base = torch.randn(rows, K1, generator=gen).to(DEV)
+    b0, b1 = rows // 3, rows - rows // 4
+    x = s if s_in is None else torch.cat((s, s_in), 1)
+    res, names = {}, []
+    try:
+        for q in (2, 0):                           # 2: every eligible K on the new kernel (the default, 1, takes K > 224 only)
+            assert lib.mrg_gemm_set_q(q) == 0
+            outs, names = [], []
+            if K2 == 0:
+                for act in (None, "relu", "sigmoid"):
+                    outs.append(K.linear(s, W, b, act)); names.append(f"linear {act}")
+                if Nout > 48:
+                    for acc in (0, 1):
+                        gx = base.clone()
+                        ws = torch.empty(max(16, int(lib.mrg_linear_bwd_input_workspace_bytes(K1, Nout))), dtype=torch.uint8, device=DEV)
+                        call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(ws), rows, K1, Nout, K1, acc, stream_of(gx)))
+                        outs.append(gx); names.append(f"bwd_input acc={acc}")
+            if Nout == K1:
+                for kind in (0, 1):
+                    for store in ((True, False) if kind == 0 else (True,)):
+                        out = torch.empty(rows, Nout, device=DEV) if store else None
+                        gate = torch.empty(rows, Nout, device=DEV) if kind == 0 else None
+                        ws = torch.empty(max(16, int(lib.mrg_gemm_workspace_bytes(K_, Nout))), dtype=torch.uint8, device=DEV)
+                        if store:
+                            call("mrg_dense_filter_fwd", (kind, ptr(s), ptr(s_in), ptr(W), ptr(b), ptr(norm), 1.0 / 3.0, ptr(out), ptr(gate), ptr(ws),
+                                                          rows, K1, stream_of(s)))
+                            outs += [out] + ([gate] if gate is not None else []); names += [f"filter kind={kind}"] + (["gate"] if gate is not None else [])
+                        # the three direction segments in one grouped launch (gate only when store is False)
+                        ws3n = int(lib.mrg_dense_filter3_workspace_bytes(Nout, K_))
+                        if ws3n > 0:
+                            out3 = torch.empty(rows, Nout, device=DEV) if store else None
+                            gate3 = torch.empty(rows, Nout, device=DEV) if kind == 0 else None
+                            ws3 = torch.empty(ws3n, dtype=torch.uint8, device=DEV)
+                            call("mrg_dense_filter_fwd3", (kind, ptr(s), ptr(s_in), ptr_array(W3), ptr_array(b3), ptr(norm), 1.0 / 3.0, 1.0, ptr(out3), ptr(gate3),
+                                                           ptr(ws3), b0, b1, rows, K1, stream_of(s)))
+                            outs += ([out3] if store else []) + ([gate3] if gate3 is not None else [])
+                            names += ([f"filter3 kind={kind}"] if store else []) + (["gate3"] if gate3 is not None else [])
+            res[q] = outs
+    finally:
+        lib.mrg_gemm_set_q(1)
+    assert len(res[2]) == len(res[0]) and len(res[2]) > 0
+    for nm, a_, b_ in zip(names, res[2], res[0]):
+        if a_.numel() == 0:
+            continue
+        scale = max(1.0, float(b_.abs().max()))
+        assert float((a_ - b_).abs().max()) <= 4e-6 * scale, (nm, float((a_ - b_).abs().max()), scale)
+    # against float64, for the plain product
+    if K2 == 0 and rows > 0:
+        ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+        e_q, e_s = float((res[2][0].double() - ref).abs().max()), float((res[0][0].double() - ref).abs().max())
+        assert e_q <= 1.5 * e_s + 1e-6 * float(ref.abs().max()), (e_q, e_s)
 
 
 @pytest.mark.gpu
