@@ -30,6 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as K
+from . import lazy as LZ
 from . import operations_lp as OPS
 from .operations_lp import PRE_OPS, FIRST_OPS, MIDDLE_OPS, LAST_OPS, MIXED_OPS, MIXED_OPS_sf, SF_OPS   # noqa: F401  (the reference module re-exports them)
 
@@ -59,6 +60,108 @@ def _plain(h):
     return h.materialize() if isinstance(h, K.LazyRows) else h
 
 
+def _identity_index(ops):
+    ids = [k for k, op in enumerate(ops) if type(op) is OPS.f_identity_op]
+    return ids[0] if len(ids) == 1 else None
+
+
+def _dense_pair(ops, x):
+    """(index of f_dense_comp, index of f_comp) when both are candidates of this MixedOp and may share a node, else None."""
+    if not x.is_cuda:
+        return None
+    d = [k for k, op in enumerate(ops) if type(op) is OPS.f_dense_op_comp]
+    c = [k for k, op in enumerate(ops) if type(op) is OPS.f_comp_op]
+    if len(d) != 1 or len(c) != 1:
+        return None
+    return (d[0], c[0])
+
+
+def _run(op, g, a, b, for_epilogue=False):
+    """op's result NOW (a tensor, or a functional.Candidate with for_epilogue): `op.run`, or -- when somebody registered hooks on the
+    operator module -- the module call itself, so that the hooks fire (its lazy handle is evaluated at once)."""
+    if op._forward_hooks or op._forward_pre_hooks or not hasattr(op, "run"):
+        return LZ.real(op(g, a, b, for_epilogue=True) if for_epilogue else op(g, a, b))
+    return op.run(g, a, b, for_epilogue=for_epilogue)
+
+
+def fused_candidates(ops, bns, weights, g, h, h_in, addend=None, group=None, total_rows=None, prepare_only=False):
+    """addend + sum_k weights[k] * ReLU(BatchNorm_k(ops[k](g, h, h_in)))  on the fused HIP path: ONE epilogue (statistics pass +
+    combine pass) for all candidates instead of BN / ReLU / scale / add launches per candidate; f_zero contributes
+    w * ReLU(beta) without materialising its all-zero output; f_dense_comp and f_comp share one autograd node; f_dense_comp arrives
+    as its gate and f_sparse_comp as a row factor (recomputed by the epilogue); the operands' gradients are K-way sums.
+
+    ops: the operator modules; bns: their nn.BatchNorm1d modules (or lazy.BatchNormView); weights [K]; h / h_in: tensors,
+    functional.Fan (a state with its reader bookkeeping) or functional.LazyRows (cell zero).  `group` / `total_rows`: rows sharded
+    over ranks; `addend`: the sum of the MixedOps that feed the same state so far (accumulated inside the combine kernel).
+    Called by MixedOp.forward below and by the lazy handles (lazy.py) that the reference's own MixedOp produces."""
+    if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
+        if (K.switches.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(ops) <= 3
+                and all(isinstance(op, OPS._PreOp) for op in ops)):
+            # ... and are never stored: statistics, combine and gradients recompute them from the two tables
+            return K.cell_zero_mixed([op.kind for op in ops], h, h_in, bns, weights, group, total_rows)
+        ys = [_run(op, g, h, h_in) for op in ops]
+        return K.mixed_epilogue(ys, bns, weights, group, total_rows, addend, fold_row_scales=True)
+    # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
+    # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
+    n = len(ops)
+    fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
+    fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
+    # f_dense_comp and f_comp read the same (h, h_in): one autograd node whose backward leaves ONE gradient per operand
+    pair = _dense_pair(ops, fh.x)
+    paired = {}
+    # f_sparse_comp as a row factor: only next to the gate-only f_dense_comp, whose folded gradient store receives its gradient
+    row_ok = pair is not None and K.switches.GATED_RECOMPUTE and K.switches.FOLD_ROW_SCALE
+    # The candidates are independent: they may run round-robin on a few HIP streams so that the tail of one
+    # kernel is filled by another candidate's kernels.  Autograd replays each candidate's backward on the stream its
+    # forward ran on.  (Launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows.)
+    dev = fh.x.device
+    nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.switches.FORK_MIN_ROWS else 1
+    if nstreams <= 1:
+        ys = []
+        for k, op in enumerate(ops):
+            if isinstance(op, OPS.f_zero_op):
+                ys.append(None)
+            elif pair is not None and k in pair:
+                if not paired:
+                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(ops[pair[0]], ops[pair[1]], g, fh.take(), fi.take(), for_epilogue=True)
+                ys.append(paired[k])
+            elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
+                ys.append(_run(op, g, fh.take(), fi.take(), for_epilogue=True))      # a functional.Candidate: consumed by the epilogue only
+            else:
+                ys.append(_run(op, g, fh.take(), fi.take()))
+        prep = K.mixed_epilogue_prepare(ys, bns, group, total_rows, True, _identity_index(ops))
+        # prepare_only (dist.py): the caller issues the statistics collective of several MixedOps at once (functional.StatChain)
+        return prep if prepare_only else prep(weights, addend)
+    fork = K.Fork(dev, nstreams, tag="candidates")
+    ys = []
+    for k, op in enumerate(ops):
+        if isinstance(op, OPS.f_zero_op):
+            ys.append(None)
+            continue
+        if pair is not None and k in pair and paired:
+            ys.append(paired[k])                   # computed with its partner
+            continue
+        side = fork.stream(k)
+        a, b = fh.take(), fi.take()
+        if side is not fork.main:                  # h / h_in live in main-stream blocks and are read (forward and,
+            a.record_stream(side)                  # through the saved tensors, backward) on the side stream: the
+            b.record_stream(side)                  # allocator must not recycle them before that stream is done
+        with torch.cuda.stream(side):
+            if pair is not None and k in pair:
+                paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(ops[pair[0]], ops[pair[1]], g, a, b, for_epilogue=True)
+                y = paired[k]
+                _tensor(paired[pair[0] + pair[1] - k]).record_stream(fork.main)
+            elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
+                y = _run(op, g, a, b, for_epilogue=True)
+            else:
+                y = _run(op, g, a, b)
+        _tensor(y).record_stream(fork.main)        # consumed by the epilogue on the main stream
+        ys.append(y)
+    fork.join()
+    prep = K.mixed_epilogue_prepare(ys, bns, group, total_rows, True, _identity_index(ops))
+    return prep if prepare_only else prep(weights, addend)
+
+
 class MixedOp(nn.Module):
     """sum_k w_k * ReLU(BN_k(op_k(g, h, h_in)))   (reference models/cell_lp.py:12-33)."""
 
@@ -77,95 +180,19 @@ class MixedOp(nn.Module):
         return nh
 
     def forward(self, weights, g, h, h_in, group=None, total_rows=None, addend=None, prepare_only=False):
-        """One fused HIP epilogue for all branches (statistics pass + combine pass) instead of
-        BN / ReLU / scale / add launches per branch.  f_zero contributes w * ReLU(beta) without
-        materialising its all-zero output.  `group`/`total_rows`: rows sharded over ranks; `addend`: the sum of the
-        MixedOps that feed the same state so far (accumulated inside the combine kernel)."""
+        """CALLER == "reference" (or CPU tensors): the reference's own lines.  Otherwise fused_candidates above."""
         if _literal(h):
             h, h_in = _plain(h), _plain(h_in)
             total = sum(w * self.op_forward(op, g, h, h_in) for w, op in zip(weights, self._ops))
             return total if addend is None else addend + total
-        if isinstance(h, K.LazyRows):                           # cell zero: the compose candidates gather on the fly
-            if (K.switches.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows) and addend is None and len(self._ops) <= 3
-                    and all(isinstance(op, OPS._PreOp) for op, _, _ in self._ops)):
-                # ... and are never stored: statistics, combine and gradients recompute them from the two tables
-                return K.cell_zero_mixed([op.kind for op, _, _ in self._ops], h, h_in, [bn for _, bn, _ in self._ops], weights,
-                                         group, total_rows)
-            ys = [op(g, h, h_in) for op, _, _ in self._ops]
-            return K.mixed_epilogue(ys, [bn for _, bn, _ in self._ops], weights, group, total_rows, addend, fold_row_scales=True)
-        # every candidate reads h (and most read h_in): hand out aliases whose gradients are summed in
-        # one K-way pass; a caller that already tracks the readers of a state passes its Fan.
-        n = len(self._ops)
-        fh = h if isinstance(h, K.Fan) else K.Fan(h, n)
-        fi = h_in if isinstance(h_in, K.Fan) else K.Fan(h_in, n)
-        # f_dense_comp and f_comp read the same (h, h_in): one autograd node whose backward leaves ONE gradient per operand
-        pair = self._dense_pair(fh.x)
-        paired = {}
-        # f_sparse_comp as a row factor: only next to the gate-only f_dense_comp, whose folded gradient store receives its gradient
-        row_ok = pair is not None and K.switches.GATED_RECOMPUTE and K.switches.FOLD_ROW_SCALE
-        # The candidates are independent: they may run round-robin on a few HIP streams so that the tail of one
-        # kernel is filled by another candidate's kernels.  Autograd replays each candidate's backward on the stream its
-        # forward ran on.  (Launch-bound step graphs gain nothing from it and pay the event traffic: one stream below 128k rows.)
-        dev = fh.x.device
-        nstreams = min(MIXED_STREAMS, n) if fh.x.shape[0] >= K.switches.FORK_MIN_ROWS else 1
-        if nstreams <= 1:
-            ys = []
-            for k, (op, _, _) in enumerate(self._ops):
-                if isinstance(op, OPS.f_zero_op):
-                    ys.append(None)
-                elif pair is not None and k in pair:
-                    if not paired:
-                        paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, fh.take(), fi.take(), for_epilogue=True)
-                    ys.append(paired[k])
-                elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
-                    ys.append(op(g, fh.take(), fi.take(), for_epilogue=True))      # a functional.Candidate: consumed by the epilogue only
-                else:
-                    ys.append(op(g, fh.take(), fi.take()))
-            prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
-            # prepare_only (dist.py): the caller issues the statistics collective of several MixedOps at once (functional.StatChain)
-            return prep if prepare_only else prep(weights, addend)
-        fork = K.Fork(dev, nstreams, tag="candidates")
-        ys = []
-        for k, (op, _, _) in enumerate(self._ops):
-            if isinstance(op, OPS.f_zero_op):
-                ys.append(None)
-                continue
-            if pair is not None and k in pair and paired:
-                ys.append(paired[k])                   # computed with its partner
-                continue
-            side = fork.stream(k)
-            a, b = fh.take(), fi.take()
-            if side is not fork.main:                  # h / h_in live in main-stream blocks and are read (forward and,
-                a.record_stream(side)                  # through the saved tensors, backward) on the side stream: the
-                b.record_stream(side)                  # allocator must not recycle them before that stream is done
-            with torch.cuda.stream(side):
-                if pair is not None and k in pair:
-                    paired[pair[0]], paired[pair[1]] = OPS.dense_pair_forward(self._ops[pair[0]][0], self._ops[pair[1]][0], g, a, b, for_epilogue=True)
-                    y = paired[k]
-                    _tensor(paired[pair[0] + pair[1] - k]).record_stream(fork.main)
-                elif (row_ok and type(op) is OPS.f_sparse_op_comp) or type(op) in (OPS.f_dense_op_comp, OPS.f_comp_op):
-                    y = op(g, a, b, for_epilogue=True)
-                else:
-                    y = op(g, a, b)
-            _tensor(y).record_stream(fork.main)        # consumed by the epilogue on the main stream
-            ys.append(y)
-        fork.join()
-        prep = K.mixed_epilogue_prepare(ys, [bn for _, bn, _ in self._ops], group, total_rows, True, self._identity_index())
-        return prep if prepare_only else prep(weights, addend)
+        return fused_candidates([op for op, _, _ in self._ops], [bn for _, bn, _ in self._ops], weights, g, h, h_in, addend, group,
+                                total_rows, prepare_only)
 
     def _identity_index(self):
-        ids = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_identity_op]
-        return ids[0] if len(ids) == 1 else None
+        return _identity_index([op for op, _, _ in self._ops])
 
     def _dense_pair(self, x):
-        """(index of f_dense_comp, index of f_comp) when both are candidates of this MixedOp and may share a node, else None."""
-        if not x.is_cuda:
-            return None
-        d = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_dense_op_comp]
-        c = [k for k, (op, _, _) in enumerate(self._ops) if type(op) is OPS.f_comp_op]
-        if len(d) != 1 or len(c) != 1:
-            return None
-        return (d[0], c[0])
+        return _dense_pair([op for op, _, _ in self._ops], x)
 
 
 class MixedOp_SF(nn.Module):

@@ -342,6 +342,8 @@ def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales
     """mixed_epilogue without running it: returns a PreparedEpilogue.  ys[k]: None (f_zero), a [rows, D] tensor (a stored
     candidate), or a Candidate from an operator's for_epilogue path (stored with a foldable first backward pass / gate-only /
     row factor)."""
+    from ..lazy import real as _real_tensor
+    ys = [_real_tensor(y) for y in ys]                     # an operator's lazy handle (lazy.py) handed over directly: its value
     cands = [y if isinstance(y, Candidate) else None for y in ys]
     ys = [c.y if c is not None else y for c, y in zip(cands, ys)]
     present = [y is not None for y in ys]

@@ -20,6 +20,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as K
+from . import lazy as LZ
+
+LZ.install_indexing()      # table[idx] of the callers (the gather G feeding the path) -> Gather handles; MRG_FAST_INDEX=0 / MRG_LAZY=0 opt out
 
 PRE_OPS = ['pre_mult', 'pre_sub', 'pre_add']
 FIRST_OPS = ['f_zero', 'f_identity', 'f_dense_comp', 'f_sparse_comp', 'f_comp']
@@ -35,12 +38,30 @@ def _bounds(g):
     return E // 2, E
 
 
+class _Operator(nn.Module):
+    """Base of the graph operators.  ``forward(g, src_emb, src_emb_in)`` -- what the reference's callers invoke
+    (models/cell_lp.py:30, models/model_lp.py:28) -- returns a LAZY HANDLE for HIP operands (mr_gnas_amd/lazy.py: a torch.Tensor
+    subclass that is evaluated when something other than the reference's BatchNorm -> ReLU -> w * . -> sum chain touches it, and
+    that lets that chain run as the fused MixedOp path); ``run(...)`` computes the result now (this package's own fused callers,
+    and the handle's evaluation).  With MRG_LAZY=0, or for CPU tensors, ``forward`` is ``run``."""
+
+    def out_shape(self, g, src_emb):
+        return tuple(src_emb.shape)
+
+    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+        if for_epilogue:
+            return self.run(g, src_emb, src_emb_in, for_epilogue=True)
+        if LZ.wanted(src_emb):
+            return LZ.defer(self, g, src_emb, src_emb_in, self.out_shape(g, src_emb))
+        return self.run(g, src_emb, src_emb_in)
+
+
 # ---- a1: compose -------------------------------------------------------------
-class _PreOp(nn.Module):
+class _PreOp(_Operator):
     kind = None
 
-    def forward(self, g, src_emb, hr):
-        return K.compose(self.kind, src_emb, hr)
+    def run(self, g, src_emb, hr, for_epilogue=False):
+        return K.compose(self.kind, LZ.real(src_emb), LZ.real(hr))
 
 
 class pre_mult_op(_PreOp):
@@ -56,18 +77,18 @@ class pre_add_op(_PreOp):
 
 
 # ---- trivial filters -----------------------------------------------------------
-class f_identity_op(nn.Module):
-    def forward(self, g, src_emb, src_emb_in):
-        return src_emb
+class f_identity_op(_Operator):
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        return LZ.real(src_emb)
 
 
-class f_zero_op(nn.Module):
-    def forward(self, g, src_emb, src_emb_in):
-        return 0 * src_emb
+class f_zero_op(_Operator):
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        return 0 * LZ.real(src_emb)
 
 
 # ---- a2 / a3: sparse (scalar-gate) filters ---------------------------------------
-class f_sparse_op_comp(nn.Module):
+class f_sparse_op_comp(_Operator):
     """Per-direction scalar gate sigmoid(a_x(W_x[s ; s_in])) * s * 1/3 (* norm on
     edge rows); one fused HIP pass instead of the reference's ~22 launches."""
 
@@ -78,9 +99,10 @@ class f_sparse_op_comp(nn.Module):
             setattr(self, "W_" + x, nn.Linear(2 * D, D, bias=True))
             setattr(self, "a_" + x, nn.Linear(D, 1, bias=False))
 
-    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
         """for_epilogue: the result goes to functional.mixed_epilogue and nowhere else -- it may then be the gate as a ROW FACTOR
         fvec [rows] (the candidate is src_emb * fvec[:, None], which the epilogue recomputes instead of reading it back)."""
+        src_emb, src_emb_in = LZ.real(src_emb), LZ.real(src_emb_in)
         b0, b1 = _bounds(g)
         p = []
         for x in ("in", "out", "self"):
@@ -91,18 +113,18 @@ class f_sparse_op_comp(nn.Module):
         return K.gate_comp(src_emb, src_emb_in, g.norm_flat(), b0, b1, *p)
 
 
-class f_sparse_op_last(nn.Module):
+class f_sparse_op_last(_Operator):
     def __init__(self, args):
         super().__init__()
         D = self._feature_dim = args.get('feature_dim', 100)
         self.W = nn.Linear(D, D, bias=True)
         self.a = nn.Linear(D, 1, bias=False)
 
-    def forward(self, g, src_emb, src_emb_in):
-        return K.gate_last(src_emb, self.W.weight, self.W.bias, self.a.weight)
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        return K.gate_last(LZ.real(src_emb), self.W.weight, self.W.bias, self.a.weight)
 
 
-class f_sparse_op(nn.Module):
+class f_sparse_op(_Operator):
     """Registered by the reference but in none of its op lists (:290-301)."""
 
     def __init__(self, args):
@@ -111,14 +133,14 @@ class f_sparse_op(nn.Module):
         self.W = nn.Linear(2 * D, D, bias=True)
         self.a = nn.Linear(D, 1, bias=False)
 
-    def forward(self, g, src_emb, src_emb_in):
-        M = src_emb.shape[0]
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        src_emb, src_emb_in = LZ.real(src_emb), LZ.real(src_emb_in)
         none3 = [None, None, None]
         return K._Gate.apply(src_emb, src_emb_in, None, 0, 0, 1.0, *none3, *none3, self.W.weight, self.W.bias, self.a.weight)
 
 
 # ---- dense (per-feature) filters: MFMA row GEMM with the gate / scale fused in its epilogue -----
-class f_dense_op_comp(nn.Module):
+class f_dense_op_comp(_Operator):
     def __init__(self, args):
         super().__init__()
         D = self._feature_dim = args.get('feature_dim', 100)
@@ -126,16 +148,17 @@ class f_dense_op_comp(nn.Module):
         self.W_out = nn.Linear(2 * D, D, bias=True)
         self.W_self = nn.Linear(2 * D, D, bias=True)
 
-    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
         """for_epilogue: the result goes to functional.mixed_epilogue and nowhere else -- a functional.Candidate whose Link lets the
         epilogue's gradient store perform this operator's first backward pass (cell_lp.MixedOp asks for it)."""
+        src_emb, src_emb_in = LZ.real(src_emb), LZ.real(src_emb_in)
         b0, b1 = _bounds(g)
         return K.dense_filter_comp(0, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, self.W_in.bias,
                                    self.W_out.weight, self.W_out.bias, self.W_self.weight, self.W_self.bias, 1.0 / 3.0,
                                    for_epilogue=for_epilogue and src_emb.is_cuda)
 
 
-class f_comp_op(nn.Module):
+class f_comp_op(_Operator):
     def __init__(self, args):
         super().__init__()
         D = self._feature_dim = args.get('feature_dim', 100)
@@ -143,7 +166,8 @@ class f_comp_op(nn.Module):
         self.W_out = nn.Linear(2 * D, D, bias=False)
         self.W_self = nn.Linear(2 * D, D, bias=False)
 
-    def forward(self, g, src_emb, src_emb_in, for_epilogue=False):
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        src_emb, src_emb_in = LZ.real(src_emb), LZ.real(src_emb_in)
         b0, b1 = _bounds(g)       # self rows are NOT scaled (reference :285-287)
         return K.dense_filter_comp(1, src_emb, src_emb_in, g.norm_flat(), b0, b1, self.W_in.weight, None,
                                    self.W_out.weight, None, self.W_self.weight, None, 1.0, for_epilogue=for_epilogue and src_emb.is_cuda)
@@ -154,10 +178,11 @@ def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=F
     shapes allow (functional.dense_filter_pair), else the two operators on their own.  for_epilogue: both results go to
     functional.mixed_epilogue and nowhere else -- two functional.Candidate values; f_dense_comp's may then be its GATE, which the
     epilogue recomputes the output from (functional.switches.GATED_RECOMPUTE)."""
+    src_emb, src_emb_in = LZ.real(src_emb), LZ.real(src_emb_in)
     D = src_emb.shape[1]
     tied = src_emb_in is not None and K.same_rows(src_emb, src_emb_in)
     if not (src_emb.is_cuda and K.dense_pair_available(D, tied)):
-        return op_dense(g, src_emb, src_emb_in, for_epilogue=for_epilogue), op_comp(g, src_emb, src_emb_in, for_epilogue=for_epilogue)
+        return op_dense.run(g, src_emb, src_emb_in, for_epilogue=for_epilogue), op_comp.run(g, src_emb, src_emb_in, for_epilogue=for_epilogue)
     b0, b1 = _bounds(g)
     dp = (op_dense.W_in.weight, op_dense.W_in.bias, op_dense.W_out.weight, op_dense.W_out.bias, op_dense.W_self.weight, op_dense.W_self.bias)
     cw = (op_comp.W_in.weight, op_comp.W_out.weight, op_comp.W_self.weight)
@@ -165,28 +190,28 @@ def dense_pair_forward(op_dense, op_comp, g, src_emb, src_emb_in, for_epilogue=F
                                for_epilogue=for_epilogue)
 
 
-class f_dense_op(nn.Module):
+class f_dense_op(_Operator):
     def __init__(self, args):
         super().__init__()
         D = self._feature_dim = args.get('feature_dim', 100)
         self.W = nn.Linear(2 * D, D, bias=True)
 
-    def forward(self, g, src_emb, src_emb_in):
-        return K.dense_filter_single(src_emb, src_emb_in, self.W.weight, self.W.bias)
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        return K.dense_filter_single(LZ.real(src_emb), LZ.real(src_emb_in), self.W.weight, self.W.bias)
 
 
-class f_dense_op_last(nn.Module):
+class f_dense_op_last(_Operator):
     def __init__(self, args):
         super().__init__()
         D = self._feature_dim = args.get('feature_dim', 100)
         self.W = nn.Linear(D, D, bias=True)
 
-    def forward(self, g, src_emb, src_emb_in):
-        return K.dense_filter_single(src_emb, None, self.W.weight, self.W.bias)
+    def run(self, g, src_emb, src_emb_in, for_epilogue=False):
+        return K.dense_filter_single(LZ.real(src_emb), None, self.W.weight, self.W.bias)
 
 
 # ---- a4 / a5 / a6: aggregators ---------------------------------------------------------
-class _LinReluAgg(nn.Module):
+class _LinReluAgg(_Operator):
     kind = None
 
     def __init__(self, args):
@@ -194,8 +219,11 @@ class _LinReluAgg(nn.Module):
         D = args.get('feature_dim', 100)
         self.linear = nn.Linear(D, D)
 
-    def forward(self, block, src_emb, src_emb_in):
-        return K.linear_relu_aggregate(self.kind, src_emb, self.linear.weight, self.linear.bias, block)
+    def out_shape(self, block, src_emb):
+        return (block.number_of_nodes(), int(src_emb.shape[1]))
+
+    def run(self, block, src_emb, src_emb_in, for_epilogue=False):
+        return K.linear_relu_aggregate(self.kind, LZ.real(src_emb), self.linear.weight, self.linear.bias, block)
 
 
 class a_max_op(_LinReluAgg):
@@ -206,13 +234,17 @@ class a_mean_op(_LinReluAgg):
     kind = "mean"
 
 
-class a_sum_op(nn.Module):
+class a_sum_op(_Operator):
     def __init__(self, args):
         super().__init__()
         self.drop_aggr = args.get('drop_aggr', 0.1)
         self.drop_sum = nn.Dropout(self.drop_aggr)
 
-    def forward(self, block, src_emb, src_emb_in):
+    def out_shape(self, block, src_emb):
+        return (block.number_of_nodes(), int(src_emb.shape[1]))
+
+    def run(self, block, src_emb, src_emb_in, for_epilogue=False):
+        src_emb = LZ.real(src_emb)
         keep = None
         if self.training and self.drop_aggr > 0:      # nn.Dropout semantics: keep-mask scaled by 1 / (1 - p), on the [N, D] sums
             N, D = block.number_of_nodes(), src_emb.shape[1]

@@ -128,22 +128,18 @@ class SearchNetwork(nn.Module):
             return self._forward(g_train, node_id, src_in, edge_type)
 
     def _forward(self, g_train, node_id, src_in, edge_type):
-        ent_all = (self.linear_e(self.embedding_h.weight) if _cell_lp.CALLER == "reference"
-                   else K.module_linear(self.linear_e, self.embedding_h.weight))
+        if _cell_lp.CALLER == "reference" and self.embedding_h.weight.is_cuda:
+            return self._forward_reference(g_train, node_id, src_in, edge_type)
+        ent_all = K.module_linear(self.linear_e, self.embedding_h.weight)
         rel = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel, p_in = self._plans(g_train, node_id, src_in, edge_type)
         ent = None
         weights = self.row_weights()
         for l, cell in enumerate(self.cells):
             wz, wf, wm, wl = weights[l]
-            if _cell_lp.CALLER == "reference" and ent_all.is_cuda:
-                # the reference's own lines (:144-145, :153-154): index, cat, index -- plain tensors into the cell
-                x = ent_all[p_ent.idx] if l == 0 else torch.cat((ent[src_in.long()], ent), dim=0)
-                ent = self.batchnorm_h(cell(g_train, x, rel[p_rel.idx], wz, wf, wm, wl))
-            else:
-                # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
-                x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
-                ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
+            # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
+            x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
+            ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
             if l > 0 or self._layers == 1:
                 if K.switches.MASK_TAP is not None and ent.is_cuda:           # test instrumentation (functional.switches.MASK_TAP)
                     K.switches.MASK_TAP(("net", l), [ent > 0])
@@ -151,6 +147,36 @@ class SearchNetwork(nn.Module):
             ent = F.dropout(ent, self._dropout, training=self.training)
             rel = torch.matmul(rel, self.w_rel)
         return ent, rel
+
+    def _forward_reference(self, g_train, node_id, src_in, edge_type):
+        """CALLER == "reference": the reference's own lines (models/model_search_lp.py:131-163), written as the reference writes them
+        -- index tensors built inside every forward, the gathers as plain tensor indexing, torch's Linear / BatchNorm / softmax
+        slicing -- so that `bench.py --caller reference` and the tests measure what the UNCHANGED caller gets on this package's
+        operators: with lazy handles (mr_gnas_amd/lazy.py, the default) the fused path; with MRG_LAZY=0 the operator swap alone."""
+        dev = self.embedding_h.weight.device
+        all_ent_emb = self.linear_e(self.embedding_h(torch.arange(self._num_ent, device=dev)))
+        rel_embed = torch.mm(self.rel_wt, self.embedding_e(torch.arange(self.embedding_e.num_embeddings, device=dev)))
+        src_in = src_in.long()
+        src_in_final = torch.cat((src_in, g_train.nodes()), dim=0)
+        edge_self = (torch.ones(g_train.nodes().shape) * (self._num_rel - 1)).long().to(dev)
+        src_id_final = node_id[src_in_final].squeeze()
+        edge_type_final = torch.cat((edge_type.long(), edge_self), dim=0)
+        ent_emb = None
+        for i, cell in enumerate(self.cells):
+            W_zero, W_first, W_middle, W_last = self.layer_weights(i)
+            if i == 0:
+                ent_emb_in = all_ent_emb[src_id_final]
+                ent_emb = cell(g_train, ent_emb_in, rel_embed[edge_type_final], W_zero, W_first, W_middle, W_last)
+                ent_emb = self.batchnorm_h(ent_emb)
+                if len(self.cells) == 1:
+                    ent_emb = F.relu(ent_emb)
+            else:
+                ent_emb_in = torch.cat((ent_emb[src_in], ent_emb), dim=0)
+                ent_emb = cell(g_train, ent_emb_in, rel_embed[edge_type_final], W_zero, W_first, W_middle, W_last)
+                ent_emb = F.relu(self.batchnorm_h(ent_emb))
+            ent_emb = F.dropout(ent_emb, self._dropout, training=self.training)
+            rel_embed = torch.matmul(rel_embed, self.w_rel)
+        return ent_emb, rel_embed
 
     def _score_plan(self, ent, rel, triplets):
         """Index plan of a scoring batch.  Reused only for the SAME triplets tensor object at the same in-place
@@ -162,10 +188,15 @@ class SearchNetwork(nn.Module):
     def calc_score(self, ent, rel, triplets, plan=None):
         """DistMult (reference models/model_search_lp.py:169-176) in one fused HIP kernel: no [T, D]
         gathers are materialised; the backward is three balanced segmented-sum launches.  `plan`: an explicit
-        functional.ScorePlan of `triplets` (callers that keep a batch across steps may build it once)."""
-        if not ent.is_cuda:
-            t = triplets.long()
-            return torch.sum(ent[t[:, 0]] * rel[t[:, 1]] * ent[t[:, 2]], dim=1)
+        functional.ScorePlan of `triplets` (callers that keep a batch across steps may build it once).
+        CALLER == "reference" (and CPU tensors): the reference's own four lines -- three gathers, a product, a row sum."""
+        if not ent.is_cuda or _cell_lp.CALLER == "reference":
+            if not ent.is_cuda:
+                triplets = triplets.long()
+            s = ent[triplets[:, 0]]
+            r = rel[triplets[:, 1]]
+            o = ent[triplets[:, 2]]
+            return torch.sum(s * r * o, dim=1)
         return K.distmult_score(ent, rel, plan if plan is not None else self._score_plan(ent, rel, triplets))
 
     def get_loss(self, g_train, ent, rel, triplets, labels):
@@ -231,7 +262,7 @@ class OpModule(nn.Module):
         self.register_buffer("_one", torch.ones(1), persistent=False)      # the one-branch epilogue's weight (not in state_dict; moves with .to())
 
     def forward(self, g, h, h_in):
-        h = self.op(g, h, h_in)
+        h = _cell_lp._run(self.op, g, h, h_in)             # the operator's value now (module call when it carries hooks)
         if self.op_name == 'pre_mult':
             return h
         if h.is_cuda:

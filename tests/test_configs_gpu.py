@@ -108,8 +108,10 @@ def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels
         return OO.seg_mean(lin * m.to(lin.dtype), og_.dst, og_.n)
 
     from oracle import ops as _OO
+    from mr_gnas_amd import lazy as _LZ
     ON.RELU_HOOK = hook
     _OO.AGG_HOOK = agg_hook
+    fast_index, _LZ.FAST_INDEX = _LZ.FAST_INDEX, False      # the checker's own table[idx] stay torch's (the float32 control must be all torch)
     try:
         ent, rel = ON.supernet_forward(og, P, al, node_id.view(-1), src_in, edge_type, 2 * R + 1, model._layers)
         loss = ON.distmult_bce(ent, rel, samples.long(), labels.to(dtype))
@@ -117,6 +119,7 @@ def oracle_supernet_f64(model, g, node_id, src_in, edge_type, R, samples, labels
     finally:
         ON.RELU_HOOK = None
         _OO.AGG_HOOK = None
+        _LZ.FAST_INDEX = fast_index
     out = dict(ent=ent.detach(), rel=rel.detach(), loss=float(loss.detach()), g={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()},
                ga=[a.grad for a in al[:4]], flips=flips, near=near)
     del og, P, al, ent, rel, loss
@@ -258,7 +261,9 @@ def check_against_f32_control(hip, ctrl, ref, replay, what):
         note = ""
         if ratio > CONTROL_RATIO:
             e_rp = rms(h.double() - rp.double())
-            if e_rp <= CONTROL_RATIO * max(e_c, floor):
+            # ... within CONTROL_RATIO x the control again, or within the tolerance of the path itself (1e-4 of the tensor's rms: the
+            # control's own error on a small bias gradient varies 5x from run to run -- torch's reductions are not deterministic)
+            if e_rp <= CONTROL_RATIO * max(e_c, floor) or e_rp <= 1e-4 * base:
                 flipped.append(name)
                 note = f"; with the HIP run's ReLU decisions replayed {e_rp:.3e} (x{e_rp / max(e_c, floor):.2f}): a flip"
             else:

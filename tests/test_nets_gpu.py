@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import assert_param_grad, load_golden, net_grad_names, net_params, sub
-from mr_gnas_amd import graph as G, supernet as S
+from mr_gnas_amd import graph as G, operations_lp as O, supernet as S
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -262,3 +262,153 @@ def test_cold_first_step_with_side_streams_matches_reference(monkeypatch):
         torch.cuda.synchronize()
         del junk
         _supernet_step("supernet_d24")          # a new RelGraph, new plans, side streams forced
+
+
+# ---------------------------------------------------------------------------
+# lazy candidate handles (mr_gnas_amd/lazy.py): the reference's UNCHANGED caller on the fused path
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["supernet_tiny", "supernet_d24", "supernet_d200_sampled"])
+@pytest.mark.parametrize("handles", ["off", "operators", "operators+gathers"])
+def test_reference_caller_with_and_without_lazy_handles_matches_golden(case, handles, monkeypatch):
+    """The literal caller -- supernet.SearchNetwork._forward_reference / calc_score: the reference's own lines
+    (models/model_search_lp.py:131-176, models/cell_lp.py:25-33, 95-152) -- against the reference's golden step:
+      off                 eager operators (MRG_LAZY=0: round 4's 'operator swap alone');
+      operators           the operators hand out lazy handles: the BatchNorm -> ReLU -> w * . -> sum chain of every MixedOp runs as
+                          ONE fused epilogue, the MixedOps feeding a state chain through its addend (the fixtures' gathers are
+                          shorter than lazy.MIN_GATHER_ROWS and stay torch's);
+      operators+gathers   ... and every table[idx] of the caller is a Gather handle (MIN_GATHER_ROWS = 1): cell zero recomputed
+                          from the tables, cat((ent[src_in], ent)) one gather, DistMult's three gathers one scoring kernel."""
+    from mr_gnas_amd import cell_lp as CL, lazy as LZ
+    monkeypatch.setattr(CL, "CALLER", "reference")
+    monkeypatch.setattr(LZ, "ENABLED", handles != "off")
+    if handles == "operators+gathers":
+        monkeypatch.setattr(LZ, "MIN_GATHER_ROWS", 1)
+    _supernet_step(case)
+
+
+def test_lazy_handles_run_the_fused_kernels(monkeypatch):
+    """With handles on, the literal caller's step launches the fused MixedOp epilogue (mrg_mix_*), the recomputed cell zero
+    (mrg_zero_*) and the fused DistMult scorer, and NO per-candidate torch BatchNorm; with handles off none of them.  (What the
+    handles buy is measured by bench.py --caller reference.)"""
+    from mr_gnas_amd import _lib, cell_lp as CL, lazy as LZ
+    monkeypatch.setattr(CL, "CALLER", "reference")
+    monkeypatch.setattr(LZ, "MIN_GATHER_ROWS", 1)
+    counts = {}
+    for handles in (True, False):
+        monkeypatch.setattr(LZ, "ENABLED", handles)
+        _lib.meter.start()
+        _supernet_step("supernet_d24")
+        st = _lib.meter.stop()
+        counts[handles] = {k: v["launches"] for k, v in st.items() if v["launches"]}
+    assert counts[True].get("mrg_mix_fwd", 0) >= 10 and counts[True].get("mrg_mix_bwd_apply", 0) >= 10
+    assert counts[False].get("mrg_mix_fwd", 0) == 0 and counts[False].get("mrg_zero_fwd", 0) == 0
+    # the paired dense-filter node, the row-factor gate, the recomputed cell zero and the fused scorer are reached through the handles
+    assert counts[True].get("mrg_linear_bwd_input3_pair", 0) + counts[True].get("mrg_linear_bwd_input", 0) > 0
+    assert counts[True].get("mrg_gate_row_fwd", 0) > 0
+    assert counts[True].get("mrg_zero_fwd", 0) == 2 and counts[True].get("mrg_distmult_score", 0) == 1
+
+
+def test_gather_handles_match_torch_indexing(monkeypatch):
+    """table[idx] through lazy.install_indexing: the rows are torch's bit for bit, the gradient torch's to rounding (a segmented
+    sum instead of the sort-based accumulate), cat((table[idx], table), 0) and sum(s * r * o, 1) keep their values; short index
+    lists, integer tables, slices and boolean masks never become handles."""
+    from mr_gnas_amd import lazy as LZ
+    gen = torch.Generator().manual_seed(9)
+    N, D, T = 3000, 48, 20000
+    tab = torch.randn(N, D, generator=gen).to(DEV).requires_grad_(True)
+    rel = torch.randn(40, D, generator=gen).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, N, (T,), generator=gen).to(DEV)
+    tri = torch.stack((torch.randint(0, N, (T,), generator=gen), torch.randint(0, 40, (T,), generator=gen), torch.randint(0, N, (T,), generator=gen)), 1).to(DEV)
+    gout = torch.randn(T, D, generator=gen).to(DEV)
+    h = tab[idx]
+    assert isinstance(h, LZ.Lazy) and isinstance(h.node, LZ.Gather) and tuple(h.shape) == (T, D)
+    assert not isinstance(tab[idx[:100]], LZ.Lazy) and not isinstance(tab[5:9], LZ.Lazy) and not isinstance(idx[idx > 5], LZ.Lazy)
+    monkeypatch.setattr(LZ, "FAST_INDEX", False)
+    ref = tab[idx]
+    assert not isinstance(ref, LZ.Lazy)
+    ref.backward(gout)
+    g_ref, tab.grad = tab.grad.clone(), None
+    ref_cat = torch.cat((tab[idx], tab), 0).detach()
+    ref_score = torch.sum(tab[tri[:, 0]] * rel[tri[:, 1]] * tab[tri[:, 2]], dim=1)
+    ref_score.sum().backward()
+    gs_ref, gr_ref, tab.grad, rel.grad = tab.grad.clone(), rel.grad.clone(), None, None
+    monkeypatch.setattr(LZ, "FAST_INDEX", True)
+    assert torch.equal(h + 0.0, ref.detach() + 0.0)
+    (h * 1.0).backward(gout)
+    torch.testing.assert_close(tab.grad, g_ref, rtol=1e-5, atol=1e-5)
+    tab.grad = None
+    c = torch.cat((tab[idx], tab), 0)
+    assert isinstance(c, LZ.Lazy) and isinstance(c.node, LZ.Gather) and tuple(c.shape) == (T + N, D)
+    assert torch.equal(c.detach() + 0.0, ref_cat + 0.0)
+    score = torch.sum(tab[tri[:, 0]] * rel[tri[:, 1]] * tab[tri[:, 2]], dim=1)
+    assert not isinstance(score, LZ.Lazy)
+    torch.testing.assert_close(score, ref_score, rtol=1e-5, atol=1e-5)
+    score.sum().backward()
+    torch.testing.assert_close(tab.grad, gs_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rel.grad, gr_ref, rtol=1e-4, atol=1e-3)
+
+
+def test_lazy_handle_is_observationally_a_tensor():
+    """Anything other than the reference's chain materialises the handle: arithmetic, indexing, cat, .backward(), a second
+    reader; the value is the eager operator's, bit for bit, and is computed once."""
+    from mr_gnas_amd import lazy as LZ
+    z = load_golden("ops_small_search")
+    g = G.RelGraph(z["N"], z["src"], z["dst"], z["etype"], z["norm"], device=DEV)
+    D = z["D"]
+    M = g.num_edges() + z["N"]
+    gen = torch.Generator().manual_seed(3)
+    x0, y0 = torch.randn(M, D, generator=gen), torch.randn(M, D, generator=gen)
+    for name in ("f_sparse_comp", "f_dense_comp", "f_comp", "a_max", "a_sum", "f_identity", "f_zero", "pre_sub"):
+        op = O.MIXED_OPS[name]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+        x, y = x0.clone().to(DEV).requires_grad_(True), y0.clone().to(DEV).requires_grad_(True)
+        h = op(g, x, y)
+        assert isinstance(h, LZ.Lazy) and h._value is None, name
+        rows = z["N"] if name.startswith("a_") else M
+        assert tuple(h.shape) == (rows, D) and h.dtype == torch.float32 and h.is_cuda and h.dim() == 2 and h.float() is h
+        eager = op.run(g, x, y)
+        assert h._value is None
+        out = h * 2.0 + 1.0                                   # not the reference's chain: materialises
+        assert h._value is not None and not isinstance(out, LZ.Lazy)
+        assert torch.equal(out, eager * 2.0 + 1.0), name
+        assert torch.equal(h[3:7], eager[3:7]) and torch.equal(torch.cat([h, h], 1), torch.cat([eager, eager], 1))
+        first = h._value
+        (h.sum() + (h * h).mean()).backward()
+        assert h._value is first                              # computed once
+        if name not in ("f_zero",):
+            assert x.grad is not None and torch.isfinite(x.grad).all()
+    # the chain itself stays lazy until it is read, and its value is the literal formulation's
+    op = O.MIXED_OPS["f_comp"]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+    ops = [op, O.MIXED_OPS["f_sparse_comp"]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)]
+    bns = [torch.nn.BatchNorm1d(D).to(DEV) for _ in range(2)]
+    x, y = x0.clone().to(DEV).requires_grad_(True), y0.clone().to(DEV).requires_grad_(True)
+    w = torch.tensor([0.25, 0.75], device=DEV, requires_grad=True)
+    t = sum(wk * torch.relu(bn(o(g, x, y).float())) for wk, o, bn in zip(w, ops, bns))
+    assert isinstance(t, LZ.Lazy) and isinstance(t.node, LZ.Sum) and len(t.node.parts) == 2
+    bns2 = [torch.nn.BatchNorm1d(D).to(DEV) for _ in range(2)]
+    ref = sum(wk * torch.relu(bn(o.run(g, x, y))) for wk, o, bn in zip(w, ops, bns2))
+    torch.testing.assert_close(t + 0.0, ref, rtol=1e-5, atol=1e-5)
+    for a_, b_ in zip(bns, bns2):
+        torch.testing.assert_close(a_.running_mean, b_.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a_.running_var, b_.running_var, rtol=1e-4, atol=1e-6)
+        assert int(a_.num_batches_tracked) == int(b_.num_batches_tracked) == 1
+
+
+def test_lazy_fixed_genotype_chain_and_discarded_dropout():
+    """The fixed-genotype OpModule's chain (models/model_lp.py:27-35: operator -> BatchNorm -> ReLU, weight one, and a dropout
+    whose result is thrown away) through handles: the value of the eager chain, and the discarded dropout is never computed."""
+    from mr_gnas_amd import lazy as LZ
+    z = load_golden("ops_small_search")
+    g = G.RelGraph(z["N"], z["src"], z["dst"], z["etype"], z["norm"], device=DEV)
+    D = z["D"]
+    M = g.num_edges() + z["N"]
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(M, D, generator=gen).to(DEV).requires_grad_(True)
+    op = O.MIXED_OPS["f_sparse_comp"]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+    bn, bn2 = torch.nn.BatchNorm1d(D).to(DEV), torch.nn.BatchNorm1d(D).to(DEV)
+    h = torch.nn.ReLU()(bn(op(g, x, x)))
+    d = torch.nn.functional.dropout(h, 0.3, training=True)       # the reference discards this
+    assert isinstance(h, LZ.Lazy) and isinstance(d, LZ.Lazy) and d._value is None
+    hs = sum([h])                                                # Cell.forward: states.append(sum(hs))
+    ref = torch.relu(bn2(op.run(g, x, x)))
+    torch.testing.assert_close(hs * 1.0, ref, rtol=1e-5, atol=1e-5)
+    assert d._value is None

@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 args = bench.parse()
+from mr_gnas_amd import cell_lp as _CL  # noqa: E402
+_CL.CALLER = args.caller                              # --caller reference: the literal formulation (lazy handles unless MRG_LAZY=0)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 if args.rehearse_shard:                               # one rank of a W-way sharded step on one GPU (timing only, bench.py --rehearse-shard)
