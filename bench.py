@@ -772,7 +772,8 @@ def main():
                                    f"relation-block edge shards x{world} + RCCL ({'bound directly, stream-ordered' if direct else 'torch.distributed nccl backend'})"),
                    "launch": launch_mode,
                    "caller": ("cell_lp.MixedOp on the fused HIP epilogue (this package's cell_lp.py / supernet.py)" if args.caller == "fused" else
-                              "the reference's literal MixedOp formulation (models/cell_lp.py:25-33) on this package's operators"),
+                              "the reference's literal formulation (models/cell_lp.py:25-33,95-152; models/model_search_lp.py:131-176) on this package's "
+                              "operators, lazy handles " + ("on" if os.environ.get("MRG_LAZY", "1") == "1" else "off (MRG_LAZY=0)")),
                    "step_graph": ("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
                                   "inside the timed region)" if args.resample else "resident, built before timing")},
         "loss": float(step.last_loss) if step.last_loss is not None else None,
@@ -855,24 +856,36 @@ def main():
                             "matrix_core": "exact f32 MFMA (v_mfma_f32_32x32x2_f32) for every GEMM"}
     if (world == 1 and not sharded and not fixed and args.caller == "fused" and not args.no_caller_leg and not args.hip_graph
             and not args.resample):
-        # the same step through the reference's literal caller formulation: what models/cell_lp.py gets unchanged
+        # the same step through the reference's literal caller formulation (supernet.SearchNetwork._forward_reference / calc_score: the
+        # reference's own lines of models/model_search_lp.py:131-176 and models/cell_lp.py:25-33,95-152 on this package's operators):
+        # `caller_reference` with the lazy handles of mr_gnas_amd/lazy.py (the default: what the UNCHANGED reference caller gets from the
+        # one import swap), `caller_reference_eager` with MRG_LAZY=0 (eager operators: round 4's 'operator swap alone')
+        from mr_gnas_amd import lazy as LZ
         CL.CALLER = "reference"
-        try:
-            step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+        lazy_was = LZ.ENABLED
+        for key, handles in (("caller_reference", True), ("caller_reference_eager", False)):
+            LZ.ENABLED = handles
+            try:
                 step()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 3 * 1e3
-            out["caller_reference"] = {"ms_per_step": round(ms, 3), "value": round(E_total / ms / 1e3, 4), "unit": "M edges/s",
-                                       "what": "per-candidate operator call + nn.BatchNorm1d + ReLU + scaled add, Python sums, gathers materialised "
-                                               "(reference models/cell_lp.py:25-33,95-113; models/model_search_lp.py:144-145) on the same HIP operators",
-                                       "loss": float(step.last_loss)}
-        except torch.cuda.OutOfMemoryError as e:
-            out["caller_reference"] = {"error": "out of memory: " + str(e)[:120]}
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / 3 * 1e3
+                out[key] = {"ms_per_step": round(ms, 3), "value": round(E_total / ms / 1e3, 4), "unit": "M edges/s",
+                            "over_headline": round(ms / ms_per_step, 3),
+                            "what": ("the reference's literal caller (per-candidate operator call + nn.BatchNorm1d + ReLU + scaled add, Python sums; gathers "
+                                     "and DistMult as plain tensor indexing: models/cell_lp.py:25-33,95-152; models/model_search_lp.py:131-176) on this "
+                                     "package's operators, " + ("lazy handles ON (mr_gnas_amd/lazy.py: the chain of every MixedOp evaluated as the fused "
+                                                                 "epilogue, table[idx] as Gather handles)" if handles else
+                                                                 "lazy handles OFF (MRG_LAZY=0: eager operators, torch BatchNorm / indexing)")),
+                            "loss": float(step.last_loss)}
+            except torch.cuda.OutOfMemoryError as e:
+                out[key] = {"error": "out of memory: " + str(e)[:120]}
+            torch.cuda.empty_cache()
+        LZ.ENABLED = lazy_was
         CL.CALLER = "fused"
-        torch.cuda.empty_cache()
     if world == 1 and not sharded and args.workload not in ("c5_fixed_cell", "compgcn_fb15k237"):
         log("timing the fused compose+scatter kernel (north-star kernel) on the benchmark graph")
         out["north_star_kernel"] = north_star_kernel(step.g, args.dim, tag=args.workload.split("_")[0])

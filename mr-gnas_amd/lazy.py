@@ -53,6 +53,10 @@ import torch.nn.functional as F
 ENABLED = os.environ.get("MRG_LAZY", "1") == "1"
 FAST_INDEX = os.environ.get("MRG_FAST_INDEX", "1") == "1"      # table[idx] -> Gather handles (install_indexing)
 MIN_GATHER_ROWS = int(os.environ.get("MRG_MIN_GATHER_ROWS", "1024"))   # shorter index lists stay with torch
+# Test switch (tests/test_dropin_cpu.py): hand out handles for CPU tensors too.  There is no fused path on the CPU, so every handle is
+# evaluated literally, in the caller's own order -- which is exactly what the test wants: the REFERENCE's unchanged cell_lp.py /
+# model_search_lp.py driving the handle protocol (every torch call they make on a handle), compared bit for bit with eager operators.
+FORCE_CPU = False
 
 # answered from the handle's metadata, never a reason to compute: methods ...
 _META = {"dim", "size", "numel", "is_floating_point", "is_complex", "ndimension", "nelement", "element_size", "__len__", "get_device"}
@@ -99,11 +103,12 @@ class Sum:
 
 
 class Gather:
-    """table[idx] not yet run (the gather G feeding the path)."""
-    __slots__ = ("table", "idx")
+    """table[idx] not yet run (the gather G feeding the path).  `then_table`: the caller wrote torch.cat((table[short], table), 0) and
+    `idx` is cat(short, arange(rows)) -- kept so that a literal evaluation can do exactly what the caller wrote."""
+    __slots__ = ("table", "idx", "then_table")
 
-    def __init__(self, table, idx):
-        self.table, self.idx = table, idx
+    def __init__(self, table, idx, then_table=None):
+        self.table, self.idx, self.then_table = table, idx, then_table
 
 
 class Prod:
@@ -211,7 +216,11 @@ class Lazy(torch.Tensor):
                     return x if isinstance(x.node, Sum) else Lazy(Sum([x]), x.shape, x)     # Python's sum() starts from 0
                 if isinstance(other, Lazy) and other._value is None and isinstance(other.node, (Term, Sum, Act)) and isinstance(x.node, (Term, Sum, Act)) \
                         and other.shape == x.shape:
-                    return Lazy(Sum(_parts(x) + _parts(other)), x.shape, x)
+                    # the caller's association is kept (a literal evaluation adds in the caller's order): a MixedOp's sum collects its
+                    # terms; the sum over MixedOps (models/cell_lp.py:103-107) collects the MixedOps' sums as parts
+                    if isinstance(other.node, Sum) and isinstance(x.node, Sum) and not any(isinstance(p.node, Sum) for p in x.node.parts if p._value is None):
+                        return Lazy(Sum([x, other]), x.shape, x)
+                    return Lazy(Sum(_parts(x) + [other]), x.shape, x)
         if name == "cat" and args and isinstance(args[0], (list, tuple)) and len(args[0]) == 2:
             first, second = args[0]
             dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
@@ -223,7 +232,7 @@ class Lazy(torch.Tensor):
                 from .graph import cached_on
                 full = cached_on(idx, "_mrg_idx_and_self", (idx,), int(t.shape[0]),
                                  lambda: torch.cat((idx.long(), torch.arange(t.shape[0], device=idx.device))))
-                return Lazy(Gather(t, full), (full.numel(), t.shape[1]), t)
+                return Lazy(Gather(t, full, then_table=idx), (full.numel(), t.shape[1]), t)
         if name in ("mul", "__mul__", "__rmul__") and len(args) == 2 and not kwargs:
             a, b = args
             if (isinstance(a, Lazy) and isinstance(b, Lazy) and a._value is None and b._value is None and a.shape == b.shape
@@ -234,7 +243,7 @@ class Lazy(torch.Tensor):
             if isinstance(b, Lazy) and not isinstance(a, Lazy):
                 a, b = b, a
             if (isinstance(a, Lazy) and a._value is None and isinstance(a.node, Act) and isinstance(b, torch.Tensor) and not isinstance(b, Lazy)
-                    and b.dim() == 0 and b.is_cuda):
+                    and b.dim() == 0 and b.device == a.device):
                 return Lazy(Term(b, a), a.shape, a)
         if name == "sum" and isinstance(x, Lazy) and x._value is None and isinstance(x.node, Prod):
             dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
@@ -243,8 +252,9 @@ class Lazy(torch.Tensor):
                 if score is not None:
                     return score
         # anything else: the handles become real tensors and the call proceeds on them
+        args, kwargs = _real(args), _real(kwargs)        # (evaluated with torch-function dispatch still ON: evaluation may itself meet handles)
         with torch._C.DisableTorchFunctionSubclass():
-            return func(*_real(args), **_real(kwargs))
+            return func(*args, **kwargs)
 
 
 def _parts(x):
@@ -275,12 +285,12 @@ def defer(op, g, a, b, shape):
 
 def wanted(a):
     """Do the operators hand out handles for this operand?  (CUDA float32 rows only: the CPU registries of the tests are eager.)"""
-    if not ENABLED:
+    if not ENABLED or not torch._C._is_torch_function_enabled():
         return False
     if isinstance(a, Lazy):
         return True
     t = a.table if hasattr(a, "table") else a
-    return isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32
+    return isinstance(t, torch.Tensor) and (t.is_cuda or FORCE_CPU) and t.dtype == torch.float32
 
 
 # ---- evaluation ------------------------------------------------------------------------------------------------------------------
@@ -296,7 +306,11 @@ def _evaluate(x):
     if isinstance(n, Drop):
         return F.dropout(real(n.src), n.p, True)
     if isinstance(n, Gather):
-        return x.lazy_rows().materialize()
+        if n.table.is_cuda:
+            return x.lazy_rows().materialize()
+        if n.then_table is not None:                          # (CPU test mode: the caller's own expression)
+            return torch.cat((_ORIG_GETITEM(n.table, n.then_table), n.table), dim=0)
+        return _ORIG_GETITEM(n.table, n.idx)
     if isinstance(n, Prod):
         out = real(n.factors[0])
         for f in n.factors[1:]:
@@ -349,7 +363,7 @@ def _operand(x):
     """An operator's operand for the fused path: the LazyRows form of a gather nobody has materialised (cell zero gathers on the
     fly), a Fan over a state that is itself a handle (its readers share one gradient sum), the object itself otherwise."""
     if isinstance(x, Lazy):
-        if x._value is None and isinstance(x.node, Gather):
+        if x._value is None and isinstance(x.node, Gather) and x.node.table.is_cuda:
             return x.lazy_rows()
         return x.fan()
     return x
@@ -365,8 +379,8 @@ def _gather_plan(idx, rows):
 
 def _gatherable(table, idx):
     return (isinstance(idx, torch.Tensor) and not isinstance(idx, Lazy) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32)
-            and idx.is_cuda and idx.numel() >= MIN_GATHER_ROWS and type(table) in _PLAIN and table.dim() == 2 and table.is_cuda
-            and table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] > 0)
+            and (idx.is_cuda or FORCE_CPU) and idx.numel() >= MIN_GATHER_ROWS and type(table) in _PLAIN and table.dim() == 2
+            and table.device == idx.device and table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] > 0)
 
 
 _PLAIN = (torch.Tensor, torch.nn.Parameter)
@@ -374,7 +388,8 @@ _ORIG_GETITEM = None
 
 
 def _getitem(self, idx):
-    if ENABLED and FAST_INDEX and _gatherable(self, idx):
+    # (no handles where nobody would see them: under DisableTorchFunctionSubclass a handle would reach the dispatcher)
+    if ENABLED and FAST_INDEX and _gatherable(self, idx) and torch._C._is_torch_function_enabled():
         # the library's kernels do not wrap negative indices and do not bound-check: trap (asynchronously) what torch would have
         # wrapped or refused
         torch._assert_async(((idx >= 0) & (idx < self.shape[0])).all())
@@ -400,7 +415,7 @@ def uninstall_indexing():
 def _distmult(factors):
     """torch.sum(ent[s] * rel[r] * ent[o], dim=1) over three Gather handles (models/model_search_lp.py:169-176) as ONE fused
     scoring kernel (functional.distmult_score: no [T, D] gather is written; backward three balanced segmented sums), or None."""
-    if len(factors) != 3 or not all(isinstance(f, Lazy) and f._value is None and isinstance(f.node, Gather) for f in factors):
+    if len(factors) != 3 or not all(isinstance(f, Lazy) and f._value is None and isinstance(f.node, Gather) and f.node.table.is_cuda for f in factors):
         return None
     a, b, c = (f.node for f in factors)
     if a.table is c.table and b.table is not a.table:
@@ -426,11 +441,41 @@ def _distmult(factors):
     return K.distmult_score(s.table, r.table, plan)
 
 
+def _leaves(parts):
+    out = []
+    for t in parts:
+        if isinstance(t, Lazy) and t._value is None and isinstance(t.node, Sum):
+            out += _leaves(t.node.parts)
+        else:
+            out.append(t)
+    return out
+
+
+def _literal_sum(parts):
+    """The sum as the caller wrote it: parts left to right, a nested sum evaluated as one value first."""
+    total = None
+    for t in parts:
+        if isinstance(t, Lazy) and t._value is None and isinstance(t.node, Sum):
+            t._value = v = _literal_sum(t.node.parts)
+            t.node = None
+        elif isinstance(t, Lazy) and t._value is None and isinstance(t.node, Term):
+            v = t.node.w * real(t.node.src)
+        elif isinstance(t, Lazy) and t._value is None and isinstance(t.node, Act):
+            v = F.relu(real(t.node.src))
+        else:
+            v = real(t)
+        total = v if total is None else total + v
+    return total
+
+
 def _evaluate_sum(parts):
     from . import cell_lp
+    leaves = _leaves(parts)
+    chains = [_chain(t) for t in leaves]
+    if not any(c is not None for c in chains):
+        return _literal_sum(parts)
     groups, order, rest = {}, [], []
-    for t in parts:
-        c = _chain(t)
+    for t, c in zip(leaves, chains):
         if c is None:
             rest.append(t)
             continue
@@ -447,10 +492,7 @@ def _evaluate_sum(parts):
         bns = [c[1] for c in grp]
         w = torch.stack([c[0] if c[0] is not None else _one(node0) for c in grp])
         total = cell_lp.fused_candidates(ops, bns, w, node0.g, _operand(node0.a), _operand(node0.b), addend=total)
-    for t in rest:                                           # foreign terms, in the order they were written
-        if isinstance(t, Lazy) and t._value is None and isinstance(t.node, Term):
-            v = t.node.w * real(t.node.src)
-        else:
-            v = real(t)
+    if rest:                                                 # foreign terms, in the order they were written
+        v = _literal_sum(rest)
         total = v if total is None else total + v
     return total

@@ -122,3 +122,112 @@ def test_reference_callers_construct_on_the_swapped_registry():
     assert out["net_ref_swapped_cells"] == out["net_ref"]
     assert all("cell_lp" in t and "mr_gnas_amd" in t or t.endswith("cell_lp") for t in out["swapped_cell_types"]), out["swapped_cell_types"]
     assert len(out["cell_lp_exports"]) == 9, out["cell_lp_exports"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# round 5: the reference's UNCHANGED cell_lp.py / model_search_lp.py drive the lazy-handle protocol (mr_gnas_amd/lazy.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+HANDLE_SCRIPT = r'''
+import json, sys, types
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+sys.path.insert(0, %(root)r + "/tests/golden")
+import make_golden as MG
+MG._install_standins()
+import mr_gnas_amd
+from mr_gnas_amd import graph as G, lazy as LZ, operations_lp as OPS
+import cpu_kernels as CK                         # CPU restatements of the operators (test infrastructure)
+
+# the operator registry a CPU run can execute: this package's _Operator protocol (forward -> handle, run -> value) around the CPU
+# restatements, parameters under the reference's names
+def wrap(ctor):
+    def make(args):
+        inner = ctor(args)
+        class W(OPS._Operator):
+            def __init__(self):
+                super().__init__()
+                for k, m in inner.named_children():
+                    setattr(self, k, m)
+                object.__setattr__(self, "_inner", inner)
+            def out_shape(self, g, src_emb):
+                rows = g.number_of_nodes() if type(inner).__name__ == "_Agg" else src_emb.shape[0]
+                return (rows, src_emb.shape[1])
+            def run(self, g, a, b, for_epilogue=False):
+                return inner(g, LZ.real(a), LZ.real(b))
+        return W()
+    return make
+reg = {k: wrap(v) for k, v in CK.registry().items()}
+mod = types.ModuleType("models.operations_lp")
+for name in ("PRE_OPS", "FIRST_OPS", "MIDDLE_OPS", "LAST_OPS", "SF_OPS", "MIXED_OPS_sf"):
+    setattr(mod, name, getattr(OPS, name))
+mod.MIXED_OPS = reg
+import models
+sys.modules["models.operations_lp"] = mod
+models.operations_lp = mod
+import models.cell_lp as CL                      # the reference's own files, unchanged
+import models.model_search_lp as MS
+
+rng = np.random.default_rng(3)
+n, R, T, D = 40, 5, 150, 12
+tri = np.stack([rng.integers(0, n, T), rng.integers(0, R, T), rng.integers(0, n, T)], 1)
+g = G.build_search_graph(n, R, tri)
+src, dst, _ = g.edges(form="all")
+node_id = torch.arange(n).view(-1, 1)
+samples = torch.from_numpy(np.stack([rng.integers(0, n, 300), rng.integers(0, 2 * R, 300), rng.integers(0, n, 300)], 1))
+labels = torch.from_numpy(rng.integers(0, 2, 300)).float()
+
+def run(handles):
+    LZ.ENABLED, LZ.FORCE_CPU, LZ.MIN_GATHER_ROWS = handles, handles, 1
+    torch.manual_seed(0)
+    net = MS.Network("cpu", n, R, 2, 1, 2, 2, D, 8, 2 * R + 1, 40.0, 0.0, 0.0)
+    net.train()
+    ent, rel = net(g, node_id, src, g.edata["e_type"])
+    seen = {"ent_is_tensor": type(ent) is torch.Tensor}
+    loss = net.get_loss(g, ent, rel, samples, labels)
+    loss.backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    return ent.detach(), rel.detach(), float(loss), grads, [a.grad.clone() for a in net.arch_parameters()[:4]], net, seen
+
+counts = {"lazy": 0, "materialised": 0}
+orig_init = LZ.Lazy.__init__
+def counting_init(self, node, shape, like):
+    counts["lazy"] += 1
+    orig_init(self, node, shape, like)
+LZ.Lazy.__init__ = counting_init
+h = run(True)
+made = counts["lazy"]
+e = run(False)
+assert counts["lazy"] == made, "eager run created handles"
+out = {"handles_created": made, "ent_equal": bool(torch.equal(h[0], e[0])), "rel_equal": bool(torch.equal(h[1], e[1])), "loss": [h[2], e[2]],
+       # relative to the tensor's largest entry, floored at 1e-3 of the largest gradient entry of the step (a bias in front of a BatchNorm
+       # has a gradient that is identically zero up to rounding: no relative scale of its own)
+       "grad_rel_diff": max([0.0] + [float((a - b).abs().max() / max(float(b.abs().max()), 1e-3 * max(float(v.abs().max()) for v in e[3].values() if v is not None)))
+                                     for (k, a), (_, b) in zip(sorted(h[3].items()), sorted(e[3].items())) if a is not None and b is not None]),
+       "grad_presence_equal": all((a is None) == (b is None) for (k, a), (_, b) in zip(sorted(h[3].items()), sorted(e[3].items()))),
+       "alpha_rel_diff": max(float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) for a, b in zip(h[4], e[4])),
+       "running_stats_equal": all(torch.equal(a, b) for a, b in zip(h[5].state_dict().values(), e[5].state_dict().values()))}
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is only present in the build container")
+def test_reference_callers_unchanged_drive_the_lazy_handles():
+    """models/cell_lp.py and models/model_search_lp.py AS THEY ARE, on an operator registry that hands out lazy handles (forced for CPU
+    tensors: lazy.FORCE_CPU; CPU restatements of the operators behind this package's forward / run protocol): the reference's own
+    lines -- nh.float(), the BatchNorm and ReLU modules, w * ., Python's sum over candidates and over MixedOps, states.append(s),
+    torch.cat of the states, all_ent_emb[src_id_final], cat((ent_emb[src_in], ent_emb)), the three gathers of calc_score -- all go
+    through Lazy.__torch_function__; on the CPU every handle is evaluated literally, in the caller's own association, so outputs,
+    loss and the BatchNorm running statistics must equal the eager run BIT FOR BIT; the gradients agree to float32 rounding (the
+    autograd nodes are created in evaluation order, which is not the eager order, so the engine accumulates the gradients of a
+    tensor with several readers in another order).  (The fused evaluation of the same handles is the GPU tests'
+    subject: tests/test_nets_gpu.py::test_reference_caller_with_and_without_lazy_handles_matches_golden.)"""
+    r = subprocess.run([sys.executable, "-c", HANDLE_SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "MRG_GOLDEN_OUT": "/tmp/mrg_dropin_unused"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert out["handles_created"] > 200, out                     # 2 layers x 22 MixedOps x (op + bn + relu + term) + sums + gathers
+    assert out["ent_equal"] and out["rel_equal"] and out["loss"][0] == out["loss"][1], out
+    assert out["running_stats_equal"] and out["grad_presence_equal"], out
+    assert out["grad_rel_diff"] <= 2e-5 and out["alpha_rel_diff"] <= 2e-5, out
