@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 13   /* 13: mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 13   /* 13: mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -179,6 +179,12 @@ int mrg_seg_reduce_fwd(int mode, const float *msg, const float *self_rows,
 int mrg_seg_reduce_bwd(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree,
                        const int32_t *arg, float *gmsg, float *gself, const float *relu_src,
                        int64_t E, int64_t N, int D, void *stream);
+/* The same (relu_src [E, D] or relu_bits [E, ceil(D / 32)] or neither) with the edges WALKED in destination order: order [E] = the edge
+ * ids sorted by destination (the eid list of mrg_chunk_plan_build; NULL = edge-id order).  Same values; the gathered rows of the [N, D]
+ * tables gout / arg are then re-used from cache by consecutive edges instead of being fetched per edge (C5: 5.05 -> see DESIGN.md). */
+int mrg_seg_reduce_bwd_ordered(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree, const int32_t *arg,
+                               float *gmsg, float *gself, const float *relu_src, const unsigned *relu_bits, const int32_t *order,
+                               int64_t E, int64_t N, int D, void *stream);
 
 /* ---- a9: fused gather -> compose -> segmented sum ------------------------------
  * CompGraphConv.forward steps 1-3, reference models/compgcn.py:58-87:

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mrg_linear_relu_segsum_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "mrg_seg_reduce_heads_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _P]),
     "mrg_seg_reduce_bwd_bits": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "mrg_seg_reduce_bwd_ordered": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mrg_linear_relu_segmax_workspace_bytes": (_L, [_L, _I, _I]),
     "mrg_linear_relu_segmax_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
     "mrg_linear_bwd_input_workspace_bytes": (_L, [_I, _I]),

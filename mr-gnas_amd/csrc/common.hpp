@@ -146,16 +146,19 @@ inline RowGeom row_geom(int D, bool all_aligned) {
 // b = ty, ty + 16, ... (coalesced along t; four interleaved accumulators), then the 16 row sums are added in order.
 // thread row ty's share of column t: partial rows b = ty, ty + 16, ... of ws[(b0 + b) * ld + t], four loads in flight
 // (the pass is latency-bound: a thread walks up to 64 partial rows); fixed association
+template <typename T> struct ordered_acc { typedef T type; };
+template <> struct ordered_acc<float> { typedef double type; };
 template <typename T>
-__device__ __forceinline__ T ordered_partial(const T* __restrict__ ws, int b0, int nb, int ld, int t, int ty) {
-  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+__device__ __forceinline__ typename ordered_acc<T>::type ordered_partial(const T* __restrict__ ws, int b0, int nb, int ld, int t, int ty) {
+  typedef typename ordered_acc<T>::type A;                  // float partials are added in double (round 5: the float32 control)
+  A a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   int b = ty;
   for (; b + 48 < nb; b += 64) {
     const T v0 = ws[(int64_t)(b0 + b) * ld + t], v1 = ws[(int64_t)(b0 + b + 16) * ld + t];
     const T v2 = ws[(int64_t)(b0 + b + 32) * ld + t], v3 = ws[(int64_t)(b0 + b + 48) * ld + t];
-    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    a0 += (A)v0; a1 += (A)v1; a2 += (A)v2; a3 += (A)v3;
   }
-  for (; b < nb; b += 16) a0 += ws[(int64_t)(b0 + b) * ld + t];
+  for (; b < nb; b += 16) a0 += (A)ws[(int64_t)(b0 + b) * ld + t];
   return (a0 + a1) + (a2 + a3);
 }
 
@@ -163,19 +166,20 @@ __device__ __forceinline__ T ordered_partial(const T* __restrict__ ws, int b0, i
 struct ReduceRanges { int x[5]; };
 template <typename T>
 __global__ void ordered_reduce_k(const T* __restrict__ ws, T* __restrict__ out, ReduceRanges bs, int out_stride, int ld, int len) {
-  __shared__ T part[16][64];
+  typedef typename ordered_acc<T>::type A;
+  __shared__ A part[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + tx;
   const int b0 = bs.x[blockIdx.y], nb = bs.x[blockIdx.y + 1] - b0;
   out += (int64_t)blockIdx.y * out_stride;
-  const T acc = t < len ? ordered_partial<T>(ws, b0, nb, ld, t, ty) : T(0);
+  const A acc = t < len ? ordered_partial<T>(ws, b0, nb, ld, t, ty) : A(0);
   part[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && t < len) {
-    T tot = part[0][tx];
+    A tot = part[0][tx];
 #pragma unroll
     for (int i = 1; i < 16; ++i) tot += part[i][tx];
-    out[t] = tot;
+    out[t] = (T)tot;
   }
 }
 

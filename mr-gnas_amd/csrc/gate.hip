@@ -13,6 +13,13 @@ struct SegPlan {
   int blk[4];             // blocks [blk[s], blk[s+1]) work on segment s
 };
 
+// rows in flight per lane group and trip of gate_fwd_k / gate_bwd_k when a wave owns a row (D > 128): 2 (default, round 5), 1 = rounds 1-4.
+// Lab override: environment MRG_GATE_RPT (read once).
+static int gate_rows_per_trip() {
+  static int v = [] { const char* e = getenv("MRG_GATE_RPT"); return e ? atoi(e) : 2; }();
+  return v;
+}
+
 static SegPlan make_plan(int64_t b0, int64_t b1, int64_t M, int grid) {
   SegPlan p;
   p.lo[0] = 0;  p.hi[0] = b0;
@@ -30,7 +37,11 @@ static SegPlan make_plan(int64_t b0, int64_t b1, int64_t M, int grid) {
   return p;                                    // blk[3] <= grid
 }
 
-template <int VEC, int LPR, int KMAX, bool HAS_IN>
+// RPT rows per trip and lane group (round 5): a trip is load -> dot -> group sum -> sigmoid -> scale -> store, one dependent chain per
+// row; with ONE row in flight per wave the C5 launches (D = 256: a wave per row) ran at 0.44 of the HBM peak with 39-55 % of the wave
+// cycles stalled at issue (profiles/r4_sq_counters_c5.txt).  With RPT = 2 the loads of two rows are issued before the first reduction
+// and the two chains interleave.  Same arithmetic per row: bit-identical outputs.
+template <int VEC, int LPR, int KMAX, bool HAS_IN, int RPT>
 __global__ __launch_bounds__(MRG_BLOCK) void gate_fwd_k(const float* __restrict__ s, const float* __restrict__ sin_,
                                                         const float* __restrict__ norm, const float* __restrict__ uvc,
                                                         float* __restrict__ out, SegPlan p, int D, float scale) {
@@ -51,39 +62,54 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_fwd_k(const float* __restrict_
     vk[k] = (HAS_IN && c < dv) ? Vec<VEC>::load(u + D + c * VEC) : Vec<VEC>::fill(0.f);
   }
   const bool use_norm = norm != nullptr && seg < 2;
-  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
-    Vec<VEC> sk[KMAX];
-    float dot = 0.f;
+  const int64_t stride = (int64_t)nb * RPB;
+  for (int64_t r0 = p.lo[seg] + (int64_t)jb * RPB + rw; r0 < p.hi[seg]; r0 += stride * RPT) {
+    Vec<VEC> sk[RPT][KMAX];
+    float dot[RPT];
+    int64_t rr[RPT];
+    bool live[RPT];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      int c = sl + k * LPR;
-      if (c < dv) {
-        sk[k] = Vec<VEC>::load(s + r * D + c * VEC);
+    for (int t = 0; t < RPT; ++t) {
+      const int64_t r = r0 + t * stride;
+      live[t] = r < p.hi[seg];
+      rr[t] = live[t] ? r : r0;                              // beyond the range: re-read the first row (never stored)
+      dot[t] = 0.f;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dot += sk[k][j] * uk[k][j];
-        if (HAS_IN) {
-          Vec<VEC> x = Vec<VEC>::load(sin_ + r * D + c * VEC);
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          sk[t][k] = Vec<VEC>::load(s + rr[t] * D + c * VEC);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) dot += x[j] * vk[k][j];
+          for (int j = 0; j < VEC; ++j) dot[t] += sk[t][k][j] * uk[k][j];
+          if (HAS_IN) {
+            Vec<VEC> x = Vec<VEC>::load(sin_ + rr[t] * D + c * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dot[t] += x[j] * vk[k][j];
+          }
         }
       }
     }
-    float z = group_sum<LPR>(dot) + cc;
-    float f = sigmoidf_fast(z) * scale * (use_norm ? norm[r] : 1.0f);
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      int c = sl + k * LPR;
-      if (c < dv) {
-        Vec<VEC> o;
+    for (int t = 0; t < RPT; ++t) {
+      float z = group_sum<LPR>(dot[t]) + cc;
+      float f = sigmoidf_fast(z) * scale * (use_norm ? norm[rr[t]] : 1.0f);
+      if (live[t]) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = sk[k][j] * f;
-        o.store(out + r * D + c * VEC);
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (c < dv) {
+            Vec<VEC> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = sk[t][k][j] * f;
+            o.store(out + rr[t] * D + c * VEC);
+          }
+        }
       }
     }
   }
 }
 
-template <int VEC, int LPR, int KMAX, bool HAS_IN>
+template <int VEC, int LPR, int KMAX, bool HAS_IN, int RPT>
 __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict__ g, const float* __restrict__ s,
                                                         const float* __restrict__ sin_, const float* __restrict__ norm,
                                                         const float* __restrict__ uvc, float* __restrict__ gs,
@@ -113,50 +139,67 @@ __global__ __launch_bounds__(MRG_BLOCK) void gate_bwd_k(const float* __restrict_
     dvv[k] = Vec<VEC>::fill(0.f);
   }
   const bool use_norm = norm != nullptr && seg < 2;
-  for (int64_t r = p.lo[seg] + (int64_t)jb * RPB + rw; r < p.hi[seg]; r += (int64_t)nb * RPB) {
-    Vec<VEC> sk[KMAX], xk[KMAX], gk[KMAX];
-    float dz_ = 0.f, dq = 0.f;
+  const int64_t stride = (int64_t)nb * RPB;
+  // rows of a lane group in ascending order whatever RPT is (trip t0 handles r0, r0 + stride, ...): du / dv / dc receive the same
+  // terms in the same order as with one row per trip -- bit-identical partial sums
+  for (int64_t r0 = p.lo[seg] + (int64_t)jb * RPB + rw; r0 < p.hi[seg]; r0 += stride * RPT) {
+    Vec<VEC> sk[RPT][KMAX], xk[RPT][KMAX], gk[RPT][KMAX];
+    float dz_[RPT], dq[RPT];
+    int64_t rr[RPT];
+    bool live[RPT];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      int c = sl + k * LPR;
-      if (c < dv) {
-        sk[k] = Vec<VEC>::load(s + r * D + c * VEC);
-        gk[k] = Vec<VEC>::load(g + r * D + c * VEC);
-        if (HAS_IN) xk[k] = Vec<VEC>::load(sin_ + r * D + c * VEC);
+    for (int t = 0; t < RPT; ++t) {
+      const int64_t r = r0 + t * stride;
+      live[t] = r < p.hi[seg];
+      rr[t] = live[t] ? r : r0;
+      dz_[t] = 0.f; dq[t] = 0.f;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          dz_ += sk[k][j] * uk[k][j];
-          if (HAS_IN) dz_ += xk[k][j] * vk[k][j];
-          dq += gk[k][j] * sk[k][j];
+      for (int k = 0; k < KMAX; ++k) {
+        int c = sl + k * LPR;
+        if (c < dv) {
+          sk[t][k] = Vec<VEC>::load(s + rr[t] * D + c * VEC);
+          gk[t][k] = Vec<VEC>::load(g + rr[t] * D + c * VEC);
+          if (HAS_IN) xk[t][k] = Vec<VEC>::load(sin_ + rr[t] * D + c * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            dz_[t] += sk[t][k][j] * uk[k][j];
+            if (HAS_IN) dz_[t] += xk[t][k][j] * vk[k][j];
+            dq[t] += gk[t][k][j] * sk[t][k][j];
+          }
         }
       }
     }
-    float z = group_sum<LPR>(dz_) + cc;
-    float q = group_sum<LPR>(dq);
-    float gt = sigmoidf_fast(z);
-    float t = scale * (use_norm ? norm[r] : 1.0f);
-    float dz = q * t * gt * (1.0f - gt);
-    float f = gt * t;
-    dc += (double)dz;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      int c = sl + k * LPR;
-      if (c < dv) {
-        Vec<VEC> o;
+    for (int t = 0; t < RPT; ++t) {
+      float z = group_sum<LPR>(dz_[t]) + cc;
+      float q = group_sum<LPR>(dq[t]);
+      float gt = sigmoidf_fast(z);
+      float tt = scale * (use_norm ? norm[rr[t]] : 1.0f);
+      float dz = live[t] ? q * tt * gt * (1.0f - gt) : 0.f;
+      float f = gt * tt;
+      if (live[t]) {
+        dc += (double)dz;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          o[j] = gk[k][j] * f + dz * uk[k][j];
-          du[k][j] += dz * sk[k][j];
-        }
-        o.store(gs + r * D + c * VEC);
-        if (HAS_IN) {
-          Vec<VEC> o2;
+        for (int k = 0; k < KMAX; ++k) {
+          int c = sl + k * LPR;
+          if (c < dv) {
+            Vec<VEC> o;
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            o2[j] = dz * vk[k][j];
-            dvv[k][j] += dz * xk[k][j];
+            for (int j = 0; j < VEC; ++j) {
+              o[j] = gk[t][k][j] * f + dz * uk[k][j];
+              du[k][j] += dz * sk[t][k][j];
+            }
+            o.store(gs + rr[t] * D + c * VEC);
+            if (HAS_IN) {
+              Vec<VEC> o2;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) {
+                o2[j] = dz * vk[k][j];
+                dvv[k][j] += dz * xk[t][k][j];
+              }
+              o2.store(gsin + rr[t] * D + c * VEC);
+            }
           }
-          o2.store(gsin + r * D + c * VEC);
         }
       }
     }
@@ -536,8 +579,13 @@ extern "C" int mrg_gate_fwd(const float* s, const float* s_in, const float* norm
     grid = grid_for(M, (MRG_BLOCK / L) * 4);                                                                                   \
     if (grid < 3) grid = 3;                                                                                             \
     SegPlan p = make_plan(b0, b1, M, grid);                                                                             \
-    if (s_in) hipLaunchKernelGGL((gate_fwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
-    else hipLaunchKernelGGL((gate_fwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+    if (gate_rows_per_trip() == 2 && L == 64) {                                                                          \
+      if (s_in) hipLaunchKernelGGL((gate_fwd_k<V, L, K, true, 2>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+      else hipLaunchKernelGGL((gate_fwd_k<V, L, K, false, 2>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+    } else {                                                                                                            \
+      if (s_in) hipLaunchKernelGGL((gate_fwd_k<V, L, K, true, 1>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+      else hipLaunchKernelGGL((gate_fwd_k<V, L, K, false, 1>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, s, s_in, norm, uvc, out, p, D, scale); \
+    }                                                                                                                   \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);
 #undef CALL
@@ -569,8 +617,13 @@ extern "C" int mrg_gate_bwd(const float* gout, const float* s, const float* s_in
     if (grid < 3) grid = 3;                                                                                             \
     p = make_plan(b0, b1, M, grid);                                                                                     \
     if (M > 0) {                                                                                                        \
-      if (s_in) hipLaunchKernelGGL((gate_bwd_k<V, L, K, true>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
-      else hipLaunchKernelGGL((gate_bwd_k<V, L, K, false>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+      if (gate_rows_per_trip() == 2 && L == 64) {                                                                        \
+        if (s_in) hipLaunchKernelGGL((gate_bwd_k<V, L, K, true, 2>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+        else hipLaunchKernelGGL((gate_bwd_k<V, L, K, false, 2>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+      } else {                                                                                                          \
+        if (s_in) hipLaunchKernelGGL((gate_bwd_k<V, L, K, true, 1>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+        else hipLaunchKernelGGL((gate_bwd_k<V, L, K, false, 1>), dim3(p.blk[3]), dim3(MRG_BLOCK), 0, st, gout, s, s_in, norm, uvc, gs, gs_in, (float*)ws, p, D, scale); \
+      }                                                                                                                 \
     }                                                                                                                   \
   } while (0)
   MRG_DISPATCH_GEOM(g, CALL);

@@ -2,6 +2,8 @@
 
 Part of ``mr_gnas_amd.functional`` (autograd Functions over the C ABI, include/mrgnas.h): every Function enqueues HIP kernels of
 libmrgnas_hip.so on torch's current stream through ctypes; every call site states the algorithmic bytes / flops of the launch."""
+import os
+
 import torch
 
 from .. import _lib
@@ -26,12 +28,22 @@ def _seg_fwd(mode, msg, self_rows, p, N, D, want_arg=True):
     return out, arg
 
 
-def _seg_bwd(mode, g, graph, arg, gmsg, gself, relu_src=None):
+ORDERED_BWD = os.environ.get("MRG_SEG_BWD_ORDERED", "1") == "1"     # lab switch: 0 = the aggregators' backward walks the edges in edge-id order (rounds 1-4)
+ORDERED_BWD_MIN_BYTES = int(os.environ.get("MRG_SEG_BWD_ORDERED_MIN_BYTES", str(128 << 20)))   # gathered tables smaller than this stay in edge-id order
+
+
+def _seg_bwd(mode, g, graph, arg, gmsg, gself, relu_src=None, relu_bits=None):
+    """gmsg [E, D] (and gself [N, D]) of the destination-segmented reducers' backward (mrg_seg_reduce_bwd_ordered): the edges are walked in
+    destination order (the plan's CSR-by-destination list), so the gathered rows of g / arg are re-used from cache."""
     p = graph.plan()
     E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
     nb = 4 * D * E * (1 + (relu_src is not None)) + 4 * E + 4 * D * N * (1 + (gself is not None) + (mode == 2))
-    call("mrg_seg_reduce_bwd", (mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), ptr(gself),
-                                ptr(relu_src), E, N, D, stream_of(g)), nbytes=nb)
+    # ... where the tables are beyond the caches (C5: 1 GB each, 5.26 -> 3.76 ms for a_max's backward); cache-resident tables (FB15k-237:
+    # 11.6 MB) gain nothing from the order and pay its indirection (0.190 -> 0.225 ms): edge-id order there (profiles/r5_stragglers.txt)
+    big = 4 * D * N * (2 if mode == 2 else 1) > ORDERED_BWD_MIN_BYTES
+    order = p["eid"] if (ORDERED_BWD and g.is_cuda and big) else None
+    call("mrg_seg_reduce_bwd_ordered", (mode, ptr(g), ptr(graph.i32("dst")), ptr(p["in_degree"]), ptr(arg), ptr(gmsg), ptr(gself),
+                                        ptr(relu_src), ptr(relu_bits), ptr(order), E, N, D, stream_of(g)), nbytes=nb)
 
 
 class _SegReduce(torch.autograd.Function):
@@ -224,8 +236,7 @@ class _LinReluAgg(torch.autograd.Function):
         gx = torch.empty_like(x)
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
         if ctx.fused == "mean":
-            call("mrg_seg_reduce_bwd_bits", (1, ptr(g), ptr(graph.i32("dst")), ptr(graph.plan()["in_degree"]), ptr(gy), ptr(gx[E:]), ptr(bits),
-                                             E, N, D, st), nbytes=4 * D * E + 4 * E + 8 * D * N)
+            _seg_bwd(1, g, graph, None, gy, gx[E:], relu_bits=bits)
         elif ctx.fused:
             _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)             # the winning message is ReLU-dead iff the maximum is 0
             gx[E:] = g
@@ -322,8 +333,7 @@ class _LinReluPartial(torch.autograd.Function):
             gx[E:].zero_()
         gy = torch.empty(E, D, dtype=torch.float32, device=x.device)
         if ctx.fused == "sum":
-            call("mrg_seg_reduce_bwd_bits", (0, ptr(g), ptr(graph.i32("dst")), ptr(graph.plan()["in_degree"]), ptr(gy), None, ptr(bits),
-                                             E, graph.number_of_nodes(), D, st), nbytes=4 * D * E + 4 * E + 4 * D * graph.number_of_nodes())
+            _seg_bwd(0, g, graph, None, gy, None, relu_bits=bits)
         elif ctx.fused:
             _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)          # the winning message is ReLU-dead iff the maximum is 0
         else:

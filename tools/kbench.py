@@ -75,10 +75,13 @@ def main():
             p = [t for i in range(3) for t in (W[i], b[i], a[i])]
             norm = g.norm_flat()
             rec("gate_fwd", timeit(lambda: K._Gate.forward(_Ctx(), x, x_in, norm, E // 2, E, 1 / 3, *p), args.reps), 12 * D * M + 4 * E)
+            rec("gate_fwd_tied", timeit(lambda: K._Gate.forward(_Ctx(), x, x, norm, E // 2, E, 1 / 3, *p), args.reps), 8 * D * M + 4 * E)
     if want("gate"):
         xs = x.clone().requires_grad_(True); xi_ = x_in.clone().requires_grad_(True)
         out = K.gate_comp(xs, xi_, g.norm_flat(), E // 2, E, *p)
         rec("gate_bwd(+param)", timeit(lambda: torch.autograd.grad(out, (xs, xi_), gM, retain_graph=True), args.reps), 20 * D * M + 4 * E)
+        out_t = K.gate_comp(xs, xs, g.norm_flat(), E // 2, E, *p)
+        rec("gate_bwd_tied(+param)", timeit(lambda: torch.autograd.grad(out_t, xs, gM, retain_graph=True), args.reps), 12 * D * M + 4 * E)
     if want("seg"):
         for kind in ("sum", "max"):
             with torch.no_grad():
