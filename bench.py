@@ -125,6 +125,10 @@ def parse():
     ap.add_argument("--resample", action="store_true",
                     help="sampled workloads only: draw a NEW step graph inside every timed step (device sampler, negative "
                          "sampling, graph build, index plans: reference search/mr_lp_search.py:187-214), so `value` pays for it")
+    ap.add_argument("--static-step", action="store_true",
+                    help="with --resample: the new step graph of every step is padded to a host-known node capacity and its node count stays "
+                         "on the device (sampler.static_step, mrg_set_dynamic_rows): no host read in the step, every shape fixed -- with "
+                         "--hip-graph the WHOLE step, sampler included, is captured once and replayed with a new draw every time")
     ap.add_argument("--comm", default=os.environ.get("MRG_COMM", "direct"), choices=["direct", "c10d"],
                     help="N > 1: 'direct' = RCCL bound through ctypes (mr_gnas_amd/rccl.py: stream-ordered launches, the step is captured in a "
                          "HIP graph when every rank's capture succeeds; torch.distributed/gloo only bootstraps and times); 'c10d' = "
@@ -194,6 +198,15 @@ class Step:
             self._kg = (torch.from_numpy(synth.synth_kg(N, R, T, self._args.seed)).to(self.samples.device), N, R)
             self._gen = torch.Generator(device=self.samples.device).manual_seed(self._args.seed + 7)
         tri, N, R = self._kg
+        if getattr(self._args, "static_step", False):
+            # capacity-padded step graph, node count on the device, no host read anywhere (sampler.static_step): every shape is the
+            # same from draw to draw, so the step -- this draw included -- can be captured once and replayed (--hip-graph)
+            st = SM.static_step(tri, sample_size, 0.5, R, negative, N)
+            self.g, self.E = st["g"], st["g"].num_edges()
+            self.node_id, self.src_in, self.edge_type = st["node_id"], st["src"], st["rel"]
+            self.samples, self.labels = st["samples"], st["labels"]
+            self.model.static_rows(st["n_rows"], st["n_nodes"])
+            return
         g, uniq_v, src_o, rel, _, samples, labels = SM.generate_sampled_graph_and_labels(tri, sample_size, 0.5, R, negative, N,
                                                                                         generator=self._gen)
         self.g, self.E = g, g.num_edges()
@@ -672,8 +685,10 @@ def main():
     dominant = max(table, key=lambda k: table[k]["ms_total"]) if table else None
 
     run_step = step
-    if args.resample and (args.hip_graph or sharded):
-        raise SystemExit("--resample is a single-GPU eager mode")
+    if args.resample and (sharded or (args.hip_graph and not args.static_step)):
+        raise SystemExit("--resample is a single-GPU mode; replaying it from a HIP graph needs --static-step (fixed shapes, counts on the device)")
+    if args.static_step and not args.resample:
+        raise SystemExit("--static-step goes with --resample")
     if args.hip_graph and sharded and not direct and os.environ.get("MRG_GRAPH_SHARDED") != "1":
         # c10d collectives inside a capture: worked in round 2, aborted in round 3 (the watchdog polls an event recorded inside the
         # capture).  MRG_GRAPH_SHARDED=1 retries it; the supported way is --comm direct (the default)
@@ -774,8 +789,10 @@ def main():
                    "caller": ("cell_lp.MixedOp on the fused HIP epilogue (this package's cell_lp.py / supernet.py)" if args.caller == "fused" else
                               "the reference's literal formulation (models/cell_lp.py:25-33,95-152; models/model_search_lp.py:131-176) on this package's "
                               "operators, lazy handles " + ("on" if os.environ.get("MRG_LAZY", "1") == "1" else "off (MRG_LAZY=0)")),
-                   "step_graph": ("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
-                                  "inside the timed region)" if args.resample else "resident, built before timing")},
+                   "step_graph": (("a new sample every timed step (device sampler + negative sampling + graph build + index plans "
+                                   "inside the timed region)" + ("; static shapes: node capacity padding, the draw's node count stays on the device "
+                                                                  "(mrg_set_dynamic_rows), no host read" if args.static_step else ""))
+                                  if args.resample else "resident, built before timing")},
         "loss": float(step.last_loss) if step.last_loss is not None else None,
     }
     # top level, next to dtype: the headline is the split-core figure; `exact_f32` below carries the all-f32-MFMA step

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 13   /* 13: mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 13   /* 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -256,6 +256,17 @@ int mrg_distmult_score(const float *ent, const float *rel, const int32_t *s_idx,
  * Statistics may be all-reduced between colstats/finalize (and reduce/finalize) when rows
  * are sharded over GPUs.  Needs K*6*D*4 <= 64 KiB of LDS. */
 int64_t mrg_mix_workspace_bytes(int K, int D);
+/* "Static step graphs" (round 5).  The reference's search loop draws a new step graph every step (search/mr_lp_search.py:187-214,
+ * utils/utils_rgcn.py:79-118) whose node count depends on the draw.  To replay the whole step -- sampler included -- from ONE captured
+ * HIP graph, the step graph is padded to a host-known node capacity and the true counts stay in DEVICE memory: after
+ *   mrg_set_dynamic_rows(cap_m, count_m, cap_n, count_n)
+ * every mrg_mix_* / mrg_zero_* launch whose `rows` equals cap_m (the [M, D] edge + node rows) or cap_n (the [N, D] node rows) treats
+ * the rows at and beyond *count_m / *count_n (int32, device) as PADDING: left out of the BatchNorm statistics and of every
+ * gradient reduction, not counted in the statistics' row total, and written as zeros by mrg_mix_fwd / mrg_zero_fwd and by the
+ * gradient stores.  Zero rows stay zero through every operator of the search space (a zero state row yields a zero candidate),
+ * so no other entry point needs the counts.  NULL counts switch a slot off.  Process-wide; the pointers are read by the kernels at
+ * run time (a captured launch re-reads them on every replay). */
+int mrg_set_dynamic_rows(int64_t cap_m, const int32_t *count_m, int64_t cap_n, const int32_t *count_n);
 /* `gated` (HOST pointer, NULL or k < 0 = none) of the five entry points that read the candidates: candidate k is the gated
  * filter f_dense_op_comp (reference models/operations_lp.py:356-390) and is NOT stored -- y_host[k] holds its gate
  * sigmoid(W [s ; s_in] + b) (mrg_dense_filter_fwd3 with out == NULL) and its value is recomputed wherever it is read as

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mrg_gemm_set_epilogue": (_I, [_I]),
     "mrg_gemm_set_wide8": (_I, [_I]),
     "mrg_gemm_set_q": (_I, [_I]),
+    "mrg_set_dynamic_rows": (_I, [_L, _P, _L, _P]),
     "mrg_act_grad_transpose": (_I, [_P, _P, _P, _L, _L, _I, _P]),
     "mrg_wgrad_set_variant": (_I, [_I]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

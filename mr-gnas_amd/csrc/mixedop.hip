@@ -40,7 +40,17 @@ struct GatedPack { int k; const float* s; const float* c;
                    int rk; const float* rf;
                    // ... its backward (mix_bwd_apply_k only): rh[r] = d pre-activation / d row dot, the collapsed gate vectors
                    // uvc[seg][uld] of the three direction segments [0, b0) [b0, b1) [b1, rows), rdq[r] out (the gradient w.r.t. rf[r])
-                   const float* rh; const float* uvc; int uld; int64_t b0, b1; float* rdq; };
+                   const float* rh; const float* uvc; int uld; int64_t b0, b1; float* rdq;
+                   // round 5, "static step graphs" (mrg_set_dynamic_rows): the number of VALID rows lives in device memory; rows at
+                   // and beyond it are capacity padding -- left out of every statistic, written as zeros by the passes that write
+                   const int32_t* vrows; };
+
+// rows that count: min(rows, *vrows) when the launch's row count is a registered capacity, else rows
+__device__ __forceinline__ int64_t valid_rows(const int32_t* vrows, int64_t rows) {
+  if (vrows == nullptr) return rows;
+  const int64_t v = (int64_t)*vrows;
+  return v < rows ? (v < 0 ? 0 : v) : rows;
+}
 
 // c: the candidate's per-row multiplier for ALL rows (the caller expands scale_edge * norm on edge rows, scale_self on self rows,
 // once per graph): an unconditional load.  A conditional one (edge rows only) was compiled into an exec-masked block that waited for
@@ -80,6 +90,7 @@ __device__ __forceinline__ void colstats_flush(const double (&s1)[KMAX][VEC], co
 // larger than the caches).  Each candidate's sums see the same values in the same order as a sweep of its own.
 template <int VEC, int LPR, int KMAX, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_colstats_k(PtrPack ys, int K, int64_t rows, int D, double* __restrict__ ws, GatedPack gp) {
+  rows = valid_rows(gp.vrows, rows);                        // capacity padding is not part of any statistic
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ double red[RPB * 2 * WIDTH];
@@ -199,7 +210,9 @@ __global__ void mix_reduce_k(const T* __restrict__ ws, T* __restrict__ out, int 
 // ---- finalize forward: statistics -> per-column coefficients, running-stat update
 // coef[k][0]=scale=gamma*invstd, [1]=shift=beta-mean*scale, [2]=invstd, [3]=mean*invstd
 __global__ void mix_finalize_fwd_k(const double* __restrict__ sums, PtrPack gamma, PtrPack beta, MutPack rmean, MutPack rvar,
-                                   int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef) {
+                                   int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef,
+                                   const int32_t* __restrict__ vrows) {
+  if (vrows) total_rows = *vrows > 0 ? (double)*vrows : 1.0;
   int k = blockIdx.y;
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= D || k >= K) return;
@@ -224,7 +237,9 @@ __global__ void mix_finalize_fwd_k(const double* __restrict__ sums, PtrPack gamm
 // between them): a 64 x 16 block owns 64 columns of one candidate, reduces their sum and sum of squares over the nb partial
 // rows exactly like ordered_reduce_k and turns them into the coefficients.  Bit-identical to the two-launch form.
 __global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb, PtrPack gamma, PtrPack beta, MutPack rmean, MutPack rvar,
-                                          int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef) {
+                                          int K, double total_rows, int D, float eps, float momentum, float* __restrict__ coef,
+                                          const int32_t* __restrict__ vrows) {
+  if (vrows) total_rows = *vrows > 0 ? (double)*vrows : 1.0;
   __shared__ double part[2][16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx, k = blockIdx.y;
@@ -277,7 +292,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
   float wk[KB];
 #pragma unroll
   for (int k = 0; k < KB; ++k) wk[k] = k < K ? w[k] : 0.f;
+  const int64_t nvalid = valid_rows(gp.vrows, rows);
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const bool pad = r >= nvalid;                            // capacity padding: the state keeps zero rows there
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
             }
           }
         }
+        if (pad) acc = Vec<VEC>::fill(0.f);
         acc.store(out + r * D + c * VEC);
       }
     }
@@ -334,6 +352,7 @@ template <int VEC, int LPR, int KMAX, int KB, bool GATED>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __restrict__ g, PtrPack ys, int K,
                                                               const float* __restrict__ coef, const float* __restrict__ w,
                                                               float* __restrict__ ws, int64_t rows, int D, GatedPack gp) {
+  rows = valid_rows(gp.vrows, rows);
   extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
@@ -426,7 +445,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
 // ---- finalize backward: red[k][3][D] -> c1 = sum gr / rows, c2 = sum gr*xhat / rows into coef2[k][2][D];
 //      dgamma_k = sum gr*xhat, dbeta_k = sum gr, dw[k] = sum_c sum g*relu(z)
 __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double total_rows, int D, float* __restrict__ coef2,
-                                   MutPack dgamma, MutPack dbeta, float* __restrict__ dw) {
+                                   MutPack dgamma, MutPack dbeta, float* __restrict__ dw, const int32_t* __restrict__ vrows) {
+  if (vrows) total_rows = *vrows > 0 ? (double)*vrows : 1.0;
   __shared__ float part[256];
   int k = blockIdx.x;
   float accw = 0.f;
@@ -481,7 +501,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
       for (int q = 0; q < KB; ++q) if (q == rsp.add_from[k]) need[q] = true;
     }
   const bool hasr = GATED && gp.rk >= 0;
+  const int64_t nvalid = valid_rows(gp.vrows, rows);
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const float live = r < nvalid ? 1.0f : 0.0f;             // capacity padding: every gradient row written there is zero
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
       const int c = sl + q * LPR;
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
               float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
-              ov[k][j] = (gr - c4[j] - xh * c5[j]) * c0[j];
+              ov[k][j] = (gr - c4[j] - xh * c5[j]) * c0[j] * live;
             }
           }
         }
@@ -614,7 +636,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
 // Per layer (rounds 1-2: 3 gather-compose launches + the generic epilogue on stored candidates): 27 [rows, D] passes -> 6.
 // Same values, same summation order per statistic as the stored form (mix_colstats_k / mix_bwd_reduce_k): the
 // coefficients, the output and every gy_k are bit-identical; only the association of the table gradients differs.
-struct ZeroSrc { const float* ent; const float* rel; const int32_t* ei; const int32_t* ri; int op[4]; int K; };
+struct ZeroSrc { const float* ent; const float* rel; const int32_t* ei; const int32_t* ri; int op[4]; int K; const int32_t* vrows; };
 
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> zero_val(int op, const Vec<VEC>& a, const Vec<VEC>& b) {
@@ -628,6 +650,7 @@ constexpr int ZK = 3;      // at most three compose candidates
 
 template <int VEC, int LPR, int KMAX>
 __global__ __launch_bounds__(MRG_BLOCK) void zero_colstats_k(ZeroSrc z, int64_t rows, int D, double* __restrict__ ws) {
+  rows = valid_rows(z.vrows, rows);
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
   __shared__ double red[RPB * 2 * WIDTH];
@@ -728,9 +751,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_fwd_k(ZeroSrc z, const float* 
   float wk[ZK];
 #pragma unroll
   for (int k = 0; k < ZK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  const int64_t nvalid = valid_rows(z.vrows, rows);
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
     const float* a = z.ent + (int64_t)z.ei[r] * D;
     const float* b = z.rel + (int64_t)z.ri[r] * D;
+    const bool pad = r >= nvalid;
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
@@ -749,6 +774,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_fwd_k(ZeroSrc z, const float* 
             }
           }
         }
+        if (pad) acc = Vec<VEC>::fill(0.f);
         acc.store(out + r * D + c * VEC);
       }
     }
@@ -758,6 +784,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_fwd_k(ZeroSrc z, const float* 
 template <int VEC, int LPR, int KMAX>
 __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_reduce_k(const float* __restrict__ g, ZeroSrc z, const float* __restrict__ coef,
                                                                const float* __restrict__ w, float* __restrict__ ws, int64_t rows, int D) {
+  rows = valid_rows(z.vrows, rows);
   extern __shared__ float lds[];                 // coef [K][4][D], then the block-reduction buffer
   constexpr int RPB = MRG_BLOCK / LPR;
   constexpr int WIDTH = LPR * KMAX * VEC;
@@ -852,9 +879,11 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __res
   float wk[ZK];
 #pragma unroll
   for (int k = 0; k < ZK; ++k) wk[k] = k < K ? w[k] : 0.f;
+  const int64_t nvalid = valid_rows(z.vrows, rows);
   for (int64_t r = (int64_t)blockIdx.x * RPB + rw; r < rows; r += (int64_t)gridDim.x * RPB) {
     const float* a = z.ent + (int64_t)z.ei[r] * D;
     const float* b = z.rel + (int64_t)z.ri[r] * D;
+    const float live = r < nvalid ? 1.0f : 0.0f;
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {
       int c = sl + q * LPR;
@@ -875,7 +904,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __res
               float zz = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
               float gr = zz > 0.f ? wk[k] * gv[j] : 0.f;
-              const float o = (gr - c4[j] - xh * c5[j]) * c0[j];
+              const float o = (gr - c4[j] - xh * c5[j]) * c0[j] * live;
               ge[j] += op == MRG_COMPOSE_MULT ? o * vb[j] : o;
               gr2[j] += op == MRG_COMPOSE_MULT ? o * va[j] : (op == MRG_COMPOSE_SUB ? -o : o);
             }
@@ -889,6 +918,21 @@ __global__ __launch_bounds__(MRG_BLOCK) void zero_bwd_apply_k(const float* __res
 }
 
 static int lab_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// ---- "static step graphs" (round 5): row counts that live in device memory ------------------------------------------------------
+// The reference's search loop draws a NEW step graph every step (search/mr_lp_search.py:187-214) whose node count depends on the
+// draw; to replay that step from ONE captured HIP graph every tensor must keep its shape, so the step graph is padded to a host-known
+// node CAPACITY and the true counts stay in device memory.  A launch of the MixedOp-epilogue / cell-zero kernels whose row count
+// equals a registered capacity treats rows at and beyond the device count as padding: left out of the BatchNorm statistics and of
+// every gradient reduction, counted out of `total_rows`, and WRITTEN AS ZEROS by the combine and gradient passes -- which keeps the
+// padding rows of every state zero, and a zero row yields a zero candidate in every operator of the search space, so no other kernel
+// needs to know.  Two slots: the [M, D] edge + node rows and the [N, D] node rows of a step graph.
+static struct { int64_t cap[2]; const int32_t* count[2]; } g_dyn = {{-1, -1}, {nullptr, nullptr}};
+static const int32_t* dyn_rows_for(int64_t rows) {
+  for (int i = 0; i < 2; ++i)
+    if (g_dyn.count[i] != nullptr && g_dyn.cap[i] == rows) return g_dyn.count[i];
+  return nullptr;
+}
 // statistics: the flat kernels' bound (512 blocks measured best: profiles/r3_stream_grid.txt)
 static int mix_grid(int64_t rows, int lpr) {
   int g = stream_grid_for(rows, (MRG_BLOCK / lpr) * 8);
@@ -920,9 +964,11 @@ static bool pack_ok(const void* const* host, int K) { return host != nullptr && 
 // host descriptor (include/mrgnas.h: mrg_gated_branch) -> kernel argument; *al: every pointer it adds is 16-byte aligned.
 // Absent candidates keep their index < 0 and get SAFE pointers (valid [rows] / [rows, D] memory): the kernels load their row
 // factors unconditionally and discard them by a select.
-static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, int K, GatedPack* gp, bool* al, bool apply = false) {
+static const int32_t* dyn_rows_for(int64_t rows);
+static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, int K, GatedPack* gp, bool* al, bool apply = false, int64_t rows = -1) {
   *gp = GatedPack{};
   gp->k = -1; gp->pair_k = -1; gp->rk = -1;
+  gp->vrows = rows >= 0 ? dyn_rows_for(rows) : nullptr;
   if (!gb || (gb->k < 0 && gb->row_k < 0)) return MRG_OK;
   if (gb->k >= K || gb->row_k >= K || (gb->k >= 0 && gb->k == gb->row_k)) return MRG_E_SHAPE;
   if (!gb->s) return MRG_E_NULLPTR;
@@ -955,6 +1001,13 @@ static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, in
 
 using namespace mrg;
 
+extern "C" int mrg_set_dynamic_rows(int64_t cap_m, const int32_t* count_m, int64_t cap_n, const int32_t* count_n) {
+  if ((count_m && cap_m < 0) || (count_n && cap_n < 0) || (count_m && count_n && cap_m == cap_n)) return MRG_E_SHAPE;
+  g_dyn.cap[0] = cap_m; g_dyn.count[0] = count_m;
+  g_dyn.cap[1] = cap_n; g_dyn.count[1] = count_n;
+  return MRG_OK;
+}
+
 extern "C" int64_t mrg_mix_workspace_bytes(int K, int D) {
   if (K < 1 || K > MRG_MIX_MAXK || D <= 0) return 0;
   return (int64_t)1024 * K * 3 * D * sizeof(double);
@@ -984,7 +1037,7 @@ extern "C" int mrg_mix_stats_coef(const float* const* y_host, const float* const
     if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
   }
   hipLaunchKernelGGL(mix_reduce_finalize_fwd_k, dim3((D + 63) / 64, K), dim3(1024), 0, st, (const double*)ws, grid, ga, be, rm, rv, K,
-                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef, total_rows == (double)rows ? dyn_rows_for(rows) : nullptr);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -1012,7 +1065,7 @@ static int mix_colstats_blocks(const float* const* y_host, int K, int64_t rows, 
   bool al = true;
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
   GatedPack gp;
-  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  const int grc = gated_pack(gated, y_host, K, &gp, &al, false, rows);
   if (grc != MRG_OK) return grc;
   RowGeom g = row_geom(D, al);
   if (!g.ok) return MRG_E_SHAPE;
@@ -1045,7 +1098,7 @@ extern "C" int mrg_mix_finalize_fwd(const double* sums, const float* const* gamm
     if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
   }
   hipLaunchKernelGGL(mix_finalize_fwd_k, dim3((D + 127) / 128, K), dim3(128), 0, (hipStream_t)stream, sums, ga, be, rm, rv, K,
-                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef, (const int32_t*)nullptr);   // (sharded path: host-known totals)
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -1060,7 +1113,7 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
   bool al = aligned16(out) && aligned16(addend);
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
   GatedPack gp;
-  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  const int grc = gated_pack(gated, y_host, K, &gp, &al, false, rows);
   if (grc != MRG_OK) return grc;
   RowGeom g = row_geom(D, al);
   if (!g.ok) return MRG_E_SHAPE;
@@ -1094,7 +1147,7 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
   bool al = aligned16(g);
   for (int k = 0; k < K; ++k) { ys.p[k] = y_host[k]; al = al && aligned16(y_host[k]); }
   GatedPack gp;
-  const int grc = gated_pack(gated, y_host, K, &gp, &al);
+  const int grc = gated_pack(gated, y_host, K, &gp, &al, false, rows);
   if (grc != MRG_OK) return grc;
   RowGeom gm = row_geom(D, al);
   if (!gm.ok) return MRG_E_SHAPE;
@@ -1128,8 +1181,10 @@ extern "C" int mrg_mix_finalize_bwd(const float* red, int K, double total_rows, 
     dg.p[k] = dgamma_host ? dgamma_host[k] : nullptr;
     db.p[k] = dbeta_host ? dbeta_host[k] : nullptr;
   }
+  // (total_rows is the launch's own row count unless the rows are sharded over ranks: a registered capacity then names the device count)
+  const int32_t* vr = (total_rows >= 0 && total_rows == (double)(int64_t)total_rows) ? dyn_rows_for((int64_t)total_rows) : nullptr;
   hipLaunchKernelGGL(mix_finalize_bwd_k, dim3(K), dim3(256), 0, (hipStream_t)stream, red, K, total_rows > 0 ? total_rows : 1.0, D,
-                     coef2, dg, db, dw);
+                     coef2, dg, db, dw, vr);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -1179,7 +1234,7 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
     }
   }
   GatedPack gp;
-  const int grc = gated_pack(gated, y_host, K, &gp, &al, true);
+  const int grc = gated_pack(gated, y_host, K, &gp, &al, true, rows);
   if (grc != MRG_OK) return grc;
   // the recomputed candidate's folded gradient store reads s and the gate it already holds: they must be the same tensors
   if (gp.k >= 0 && rsp.on[gp.k] == 2 && (rsp.s[gp.k] != gp.s || rsp.gate[gp.k] != y_host[gp.k])) return MRG_E_SHAPE;
@@ -1255,6 +1310,7 @@ static int zero_colstats_blocks(const ZeroSrc& z, int64_t rows, int D, void* ws,
 extern "C" int mrg_zero_colstats(const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx, const int* ops_host, int K,
                                  int64_t rows, int D, double* sums, void* ws, void* stream) {
   ZeroSrc z{};
+  z.vrows = dyn_rows_for(rows);
   int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
   if (rc != MRG_OK) return rc;
   if (!sums) return MRG_E_NULLPTR;
@@ -1273,6 +1329,7 @@ extern "C" int mrg_zero_stats_coef(const float* ent, const float* rel, const int
                                    float* const* rvar_host, int64_t rows, double total_rows, int D, float eps, float momentum, float* coef,
                                    void* ws, void* stream) {
   ZeroSrc z{};
+  z.vrows = dyn_rows_for(rows);
   int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
   if (rc != MRG_OK) return rc;
   if (D <= 0 || total_rows < 0) return MRG_E_SHAPE;
@@ -1290,7 +1347,7 @@ extern "C" int mrg_zero_stats_coef(const float* ent, const float* rel, const int
     if ((rm.p[k] == nullptr) != (rv.p[k] == nullptr)) return MRG_E_NULLPTR;
   }
   hipLaunchKernelGGL(mix_reduce_finalize_fwd_k, dim3((D + 63) / 64, K), dim3(1024), 0, st, (const double*)ws, grid, ga, be, rm, rv, K,
-                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef);
+                     total_rows > 0 ? total_rows : 1.0, D, eps, momentum, coef, total_rows == (double)rows ? dyn_rows_for(rows) : nullptr);
   MRG_LAUNCH_CHECK();
   return MRG_OK;
 }
@@ -1298,6 +1355,7 @@ extern "C" int mrg_zero_stats_coef(const float* ent, const float* rel, const int
 extern "C" int mrg_zero_fwd(const float* ent, const float* rel, const int32_t* ent_idx, const int32_t* rel_idx, const int* ops_host, int K,
                             const float* coef, const float* w, float* out, int64_t rows, int D, void* stream) {
   ZeroSrc z{};
+  z.vrows = dyn_rows_for(rows);
   const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
   if (rc != MRG_OK) return rc;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
@@ -1320,6 +1378,7 @@ extern "C" int mrg_zero_bwd_reduce(const float* g, const float* ent, const float
                                    const int* ops_host, int K, const float* coef, const float* w, float* red, void* ws, int64_t rows, int D,
                                    void* stream) {
   ZeroSrc z{};
+  z.vrows = dyn_rows_for(rows);
   const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
   if (rc != MRG_OK) return rc;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;
@@ -1349,6 +1408,7 @@ extern "C" int mrg_zero_bwd_apply(const float* g, const float* ent, const float*
                                   const int* ops_host, int K, const float* coef, const float* coef2, const float* w, float* g_ent_rows,
                                   float* g_rel_rows, int64_t rows, int D, void* stream) {
   ZeroSrc z{};
+  z.vrows = dyn_rows_for(rows);
   const int rc = zero_src(&z, ent, rel, ent_idx, rel_idx, ops_host, K);
   if (rc != MRG_OK) return rc;
   if (rows < 0 || D <= 0) return MRG_E_SHAPE;

@@ -35,6 +35,11 @@ def register_stream(stream):
     KNOWN_STREAMS.setdefault(stream.device.index, set()).add(stream)
 
 
+# Set by the static search step (sampler.static_step / supernet.SearchNetwork.static_*): plans built while it is True never talk to
+# the host and settle() is a no-op (one stream).
+STATIC_SHAPES = False
+
+
 def settle(device):
     """Order every stream this package launches on after the work enqueued so far on the CURRENT stream of `device`
     (no-op on CPU).  Every lazily built, cached index structure ends with this: the candidates of a MixedOp run on
@@ -44,8 +49,8 @@ def settle(device):
     synchronisation, so a launch-bound step that rebuilds its plans (a new sampled graph per step) keeps its queue
     full.  Streams created later are ordered through Fork's wait on the main stream."""
     device = torch.device(device)
-    if device.type != "cuda":
-        return
+    if device.type != "cuda" or STATIC_SHAPES:              # (a static step runs on ONE stream -- and may be inside a capture, where an
+        return                                               #  event wait by a stream outside the capture would invalidate it)
     cur = torch.cuda.current_stream(device)
     register_stream(cur)
     others = [st for st in KNOWN_STREAMS.get(cur.device.index, ()) if st != cur]
@@ -102,6 +107,12 @@ class _Plan(dict):
     def __init__(self, items, counts, names):
         super().__init__(items)
         self._counts, self._names = counts, names
+        if STATIC_SHAPES:
+            # static step graphs (round 5): the plan is built inside a step that is being captured into (or must stay replayable as) ONE
+            # HIP graph -- launches always run over the host-known capacities (the builders pad with -1 and the kernels skip the
+            # padding), nothing travels to the host, no event is queried
+            self._host = self._ev = None
+            return
         # the counts also travel to pinned host memory right behind the build: once that copy has landed (checked with a
         # non-blocking event query) launches switch from the padded capacity to the exact sizes without ever waiting
         self._host = torch.empty(len(names), dtype=torch.int32, pin_memory=True)
@@ -111,7 +122,7 @@ class _Plan(dict):
 
     def _resolve(self):
         if self._counts is not None:
-            if self._ev.query():
+            if self._ev is not None and self._ev.query():
                 vals = self._host.tolist()
             else:
                 vals = self._counts.tolist()                            # explicit request for exact sizes: the one host wait
@@ -123,6 +134,8 @@ class _Plan(dict):
         """True when the exact sizes are known without waiting (resolving them on the way if their copy has landed)."""
         if self._counts is None:
             return True
+        if self._ev is None:                                 # built under STATIC_SHAPES: capacities only
+            return False
         if self._ev.query():
             self._resolve()
             return True
@@ -389,6 +402,11 @@ class RelGraph:
         return self._src, self._dst
 
     def in_degrees(self):
+        deg = getattr(self, "_in_degree32", None)          # device-built graphs carry it (mrg_build_graph)
+        if deg is not None:
+            return deg.long()
+        if self._dst.is_cuda:                               # (torch.bincount reads its output size back to the host: not capturable)
+            return torch.zeros(self._n, dtype=torch.long, device=self.device).scatter_add_(0, self._dst.long(), torch.ones_like(self._dst, dtype=torch.long))
         return torch.bincount(self._dst, minlength=self._n)
 
     @property

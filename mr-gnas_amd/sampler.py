@@ -87,12 +87,16 @@ def sample_edge_neighborhood(adj, sample_size, draws=None, generator=None):
 def negative_sampling(pos_samples, num_entity, negative_rate, values=None, choices=None, generator=None):
     """Reference utils/utils_rgcn.py:191-204.  pos_samples [B, 3] int64 on the device; returns (samples
     [(rate+1) B, 3] int64, labels float32).  `values` (int64 [B * rate] in [0, num_entity)) and `choices` (float64
-    [B * rate] in [0, 1)) are the reference's two random draws; drawn on the device when absent."""
+    [B * rate] in [0, 1)) are the reference's two random draws; drawn on the device when absent.  `num_entity` may be a DEVICE
+    tensor (the node count of a static step graph, static_step below): the bound of the drawn entity ids then never visits the host."""
     pos = pos_samples.long().contiguous()
     require_hip(pos)
     B, n = int(pos.shape[0]), int(pos.shape[0]) * int(negative_rate)
     dev = pos.device
-    if values is None:
+    if values is None and torch.is_tensor(num_entity):
+        ne = num_entity.to(torch.float64).reshape(())
+        values = torch.minimum((torch.rand(n, device=dev, dtype=torch.float64, generator=generator) * ne).floor(), ne - 1).clamp_(min=0).long()
+    elif values is None:
         values = torch.randint(0, int(num_entity), (n,), device=dev, generator=generator)
     if choices is None:
         choices = torch.rand(n, device=dev, dtype=torch.float64, generator=generator)
@@ -105,20 +109,51 @@ def negative_sampling(pos_samples, num_entity, negative_rate, values=None, choic
     return samples, labels
 
 
-def relabel_nodes(src, dst, num_nodes):
+def relabel_nodes(src, dst, num_nodes, static=False):
     """`uniq_v, edges = np.unique((src, dst), return_inverse=True)` (reference utils/utils_rgcn.py:97-101):
-    returns (uniq_v ascending, new_src, new_dst)."""
+    returns (uniq_v ascending, new_src, new_dst).  static: no host read -- returns (uniq_v padded with node 0 to its host-known
+    capacity min(2 n, num_nodes), new_src, new_dst, count [1] int32 on the device)."""
     src, dst = src.long().contiguous(), dst.long().contiguous()
     require_hip(src, dst)
     dev, n = src.device, int(src.numel())
     cap = max(min(2 * n, int(num_nodes)), 1)
-    uniq = torch.empty(cap, dtype=torch.int64, device=dev)
+    uniq = torch.zeros(cap, dtype=torch.int64, device=dev) if static else torch.empty(cap, dtype=torch.int64, device=dev)
     ns, nd = torch.empty_like(src), torch.empty_like(dst)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     nb = load().mrg_relabel_workspace_bytes(int(num_nodes))
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     call("mrg_relabel_nodes", (ptr(src), ptr(dst), n, int(num_nodes), ptr(uniq), ptr(ns), ptr(nd), ptr(count), ptr(ws), nb, stream_of(src)))
+    if static:
+        return uniq, ns, nd, count
     return uniq[: int(count.item())], ns, nd
+
+
+def static_step(triplets, sample_size, split_size, num_rels, negative_rate, num_nodes, generator=None):
+    """generate_sampled_graph_and_labels (uniform sampler) WITHOUT a host read and with host-known shapes, so that a whole search step
+    -- this function included -- can be captured into one HIP graph and replayed with a new draw every time (reference
+    search/mr_lp_search.py:187-245: a new step graph per step; utils/utils_rgcn.py:79-118).  The number of distinct nodes of a draw
+    stays in device memory: the step graph has `cap = min(2 * sample_size, num_nodes)` nodes, of which the first *n_nodes are the
+    draw's (relabelled 0 .. n - 1 as the reference does) and the rest are isolated padding nodes (uniq_v entry 0; no edge touches
+    them; the MixedOp kernels keep their rows zero and out of every statistic: mrg_set_dynamic_rows, supernet.SearchNetwork.static_rows).
+    Draws come from torch's default device generator unless `generator` is registered with the capturing graph.
+    Returns dict(g, node_id [cap, 1], src, rel, samples, labels, n_nodes [1] int32, n_rows [1] int32 = E + n_nodes, cap)."""
+    dev = triplets.device
+    T = int(triplets.shape[0])
+    pick = sample_edge_uniform(T, sample_size, dev, generator)
+    edges = triplets[pick].long()
+    uniq_v, src, dst, count = relabel_nodes(edges[:, 0], edges[:, 2], num_nodes, static=True)
+    rel = edges[:, 1].contiguous()
+    relabeled = torch.stack((src, rel, dst), dim=1)
+    samples, labels = negative_sampling(relabeled, count, negative_rate, generator=generator)
+    n_split = int(sample_size * split_size)
+    split = torch.randperm(int(sample_size), device=dev, generator=generator)[:n_split]
+    cap = int(uniq_v.numel())
+    graph_triples = relabeled[split]
+    g = G.build_search_graph(cap, num_rels, graph_triples, device=dev)
+    src_o, _, _ = g.edges(form="all")
+    n_rows = count + int(g.num_edges())
+    return dict(g=g, node_id=uniq_v.view(-1, 1), src=src_o, rel=g.edata["e_type"], samples=samples, labels=labels,
+                n_nodes=count, n_rows=n_rows.to(torch.int32), cap=cap, graph_triples=graph_triples)
 
 
 def generate_sampled_graph_and_labels(triplets, sample_size, split_size, num_rels, negative_rate, num_nodes, sampler="uniform",

@@ -123,6 +123,47 @@ class SearchNetwork(nn.Module):
 
     _plans = prepare
 
+    # ---- static step graphs (round 5) ------------------------------------------------------------------------------------------
+    # The reference's search loop draws a new step graph every step (search/mr_lp_search.py:187-214).  sampler.static_step pads it to a
+    # host-known node capacity and keeps the draw's node count on the device; static_rows hands those counts to the MixedOp kernels
+    # (mrg_set_dynamic_rows), after which a forward / backward over the padded graph computes exactly the unpadded step's values on the
+    # valid rows and keeps the padding rows zero -- with every tensor shape fixed, so the whole step (sampler, graph build, index
+    # plans, forward, loss, backward, optimizer) is ONE capturable, replayable HIP graph.
+    static_counts = None                                   # (n_rows [1] int32, n_nodes [1] int32) device tensors, or None
+
+    def static_rows(self, n_rows, n_nodes):
+        """Switch the static (capacity-padded) step on -- device counts of the valid [M, D] rows (edges + nodes) and node rows -- or
+        off (None, None)."""
+        from . import _lib, graph as G
+        self.static_counts = None if n_rows is None else (n_rows, n_nodes)
+        G.STATIC_SHAPES = self.static_counts is not None
+        if self.static_counts is None:
+            _lib.load().mrg_set_dynamic_rows(-1, None, -1, None)
+
+    def _layer_norm_static(self, h, relu):
+        """batchnorm_h (+ ReLU) over the VALID node rows of a capacity-padded [N, D] tensor, padding rows left zero: the MixedOp
+        epilogue kernels with one candidate (statistics over *n_nodes rows: mrg_set_dynamic_rows).  Without the ReLU the kernels'
+        own ReLU is cancelled exactly: z = relu(z) - relu(-z), two candidates over the same rows with (gamma, beta) and
+        (-gamma, -beta) and weights (+1, -1)."""
+        from .lazy import BatchNormView
+        bn = self.batchnorm_h
+        if relu:
+            return K.mixed_epilogue([h], [bn], self._ones(h.device)[:1])
+        neg = BatchNormView(None, None, -bn.weight, -bn.bias, True, bn.momentum, bn.eps)
+        neg.track_running_stats = bn.track_running_stats      # (bns[0] decides; this view has no running statistics of its own)
+        return K.mixed_epilogue([h, h], [bn, neg], self._ones(h.device) * self._pm(h.device))
+
+    def _ones(self, dev):
+        t = getattr(self, "_ones2", None)
+        if t is None or t.device != dev:
+            t = self._ones2 = torch.ones(2, dtype=torch.float32, device=dev)
+            self._pm2 = torch.tensor([1.0, -1.0], dtype=torch.float32, device=dev)
+        return t
+
+    def _pm(self, dev):
+        self._ones(dev)
+        return self._pm2
+
     def forward(self, g_train, node_id, src_in, edge_type):
         with K.deferred_counters():                        # the BatchNorm step counters of all MixedOps: one launch at the end
             return self._forward(g_train, node_id, src_in, edge_type)
@@ -133,13 +174,26 @@ class SearchNetwork(nn.Module):
         ent_all = K.module_linear(self.linear_e, self.embedding_h.weight)
         rel = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel, p_in = self._plans(g_train, node_id, src_in, edge_type)
+        static = self.static_counts is not None and ent_all.is_cuda
+        if static:                                          # the kernels read the counts at run time: registering costs nothing per step
+            from . import _lib
+            n_cap = int(g_train.number_of_nodes())
+            rc = _lib.load().mrg_set_dynamic_rows(int(g_train.num_edges()) + n_cap, _lib.ptr(self.static_counts[0]), n_cap, _lib.ptr(self.static_counts[1]))
+            if rc != 0:
+                raise _lib.MrgnasError(f"mrg_set_dynamic_rows failed ({rc})")
         ent = None
         weights = self.row_weights()
         for l, cell in enumerate(self.cells):
             wz, wf, wm, wl = weights[l]
             # the gather G (reference :135-145, :153-154) is not materialised: the cell's first stage gathers inside its compose kernels
             x = K.LazyRows(ent_all, p_ent) if l == 0 else K.LazyRows(ent, p_in)
-            ent = self.batchnorm_h(cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl))
+            h = cell(g_train, x, K.LazyRows(rel, p_rel), wz, wf, wm, wl)
+            if static and self.training:
+                ent = self._layer_norm_static(h, relu=(l > 0 or self._layers == 1))
+                ent = F.dropout(ent, self._dropout, training=self.training)
+                rel = torch.matmul(rel, self.w_rel)
+                continue
+            ent = self.batchnorm_h(h)
             if l > 0 or self._layers == 1:
                 if K.switches.MASK_TAP is not None and ent.is_cuda:           # test instrumentation (functional.switches.MASK_TAP)
                     K.switches.MASK_TAP(("net", l), [ent > 0])

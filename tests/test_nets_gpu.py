@@ -412,3 +412,71 @@ def test_lazy_fixed_genotype_chain_and_discarded_dropout():
     ref = torch.relu(bn2(op.run(g, x, x)))
     torch.testing.assert_close(hs * 1.0, ref, rtol=1e-5, atol=1e-5)
     assert d._value is None
+
+
+# ---------------------------------------------------------------------------
+# static step graphs (round 5): capacity padding + device-side row counts
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("D,sample", [(24, 300), (200, 300), (64, 2000)])
+def test_static_padded_step_equals_the_unpadded_step(D, sample):
+    """sampler.static_step pads the draw's step graph to min(2 * sample, N) nodes and leaves the node count on the device;
+    SearchNetwork.static_rows hands the counts to the MixedOp kernels (mrg_set_dynamic_rows).  The padded step must compute the
+    unpadded step's values: node embeddings on the valid rows (padding rows exactly zero), loss, every parameter / alpha gradient
+    and the BatchNorm running statistics -- against the same draw run unpadded (exact graph, host-known counts)."""
+    import copy
+    from mr_gnas_amd import sampler as SM
+    gen = torch.Generator().manual_seed(D + sample)
+    N_all, R, T = 3000, 7, 40000
+    tri = torch.stack((torch.randint(0, N_all, (T,), generator=gen), torch.randint(0, R, (T,), generator=gen),
+                       torch.randint(0, N_all, (T,), generator=gen)), 1).to(DEV)
+    torch.manual_seed(1)
+    net = S.SearchNetwork(DEV, N_all, R, 2, 1, 2, 2, D, 16, 2 * R + 1, 9.0, 0.0, 0.0).to(DEV)
+    S.xavier_init_(net)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    net.train()
+    state0 = copy.deepcopy(net.state_dict())
+    st = SM.static_step(tri, sample, 0.5, R, 3, N_all)
+    n = int(st["n_nodes"].item())
+    cap = st["cap"]
+    assert cap == min(2 * sample, N_all) and 0 < n < cap and int(st["n_rows"].item()) == n + st["g"].num_edges()
+    assert int(st["samples"][:, [0, 2]].max()) < n                       # the scored triples only name the draw's nodes
+
+    def run(g, node_id, src, rel, static):
+        net.load_state_dict(state0)
+        net.zero_grad(set_to_none=True)
+        for a in net.arch_parameters():
+            a.grad = None
+        net.static_rows(*(static if static else (None, None)))
+        try:
+            ent, relo = net(g, node_id, src, rel)
+            loss = net.get_loss(g, ent, relo, st["samples"], st["labels"])
+            loss.backward()
+        finally:
+            net.static_rows(None, None)
+        torch.cuda.synchronize()
+        return (ent.detach().clone(), relo.detach().clone(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                [a.grad.clone() for a in net.arch_parameters()[:4]], {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+
+    g_exact = G.build_search_graph(n, R, st["graph_triples"], device=DEV)
+    src_e, _, _ = g_exact.edges(form="all")
+    exact = run(g_exact, st["node_id"][:n], src_e, g_exact.edata["e_type"], None)
+    padded = run(st["g"], st["node_id"], st["src"], st["rel"], (st["n_rows"], st["n_nodes"]))
+    assert torch.equal(st["src"], src_e) and st["g"].num_edges() == g_exact.num_edges()      # same edges, same (rel, dst, src) order
+    assert tuple(padded[0].shape) == (cap, D) and float(padded[0][n:].abs().max()) == 0.0      # padding rows stay zero
+    # (equal to float32 rounding, not bit for bit: the padded launch has more rows, so its grids -- and with them the association of the
+    #  per-block partial sums of the statistics -- differ)
+    torch.testing.assert_close(padded[0][:n], exact[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(padded[1], exact[1], rtol=1e-4, atol=1e-5)
+    assert abs(padded[2] - exact[2]) <= 1e-5 * max(1.0, abs(exact[2]))
+    assert sorted(padded[3]) == sorted(exact[3])
+    gmax = max(float(v.abs().max()) for v in exact[3].values())
+    for k, v in exact[3].items():
+        scale = max(float(v.abs().max()), 1e-3 * gmax)
+        assert float((padded[3][k] - v).abs().max()) <= 5e-4 * scale, (k, float((padded[3][k] - v).abs().max()), scale)
+    for a, b in zip(padded[4], exact[4]):
+        assert float((a - b).abs().max()) <= 5e-4 * max(float(b.abs().max()), 1e-8)
+    for k, v in exact[5].items():
+        torch.testing.assert_close(padded[5][k], v, rtol=1e-4, atol=1e-6)
