@@ -805,7 +805,7 @@ def main():
         # algorithmic work / summed HIP-event time of its launches; `traffic` = counter bytes of its largest entry point
         f = families[dom_family]
         big = max(f["entry_points"], key=lambda n: table[n]["ms_total"] if n in table else 0.0)
-        # per-launch counter bytes exist for the launches of the default workload only (tools/profile_r4.sh profiles that command)
+        # per-launch counter bytes exist for the launches of the default workload only (tools/lab/profile.sh profiles that command)
         counted = args.workload == "fb15k237_supernet_full" and args.dim == 200 and not sharded and args.caller == "fused"
         out["roofline"] = {"kernel": dom_family, "bound": f["bound"], "achieved": f["achieved"], "peak": f["peak"], "unit": f["unit"],
                            "frac": f["frac"], "traffic": load_traffic(big) if counted else None, "traffic_entry_point": big,
