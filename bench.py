@@ -128,7 +128,7 @@ def parse():
     ap.add_argument("--static-step", action="store_true",
                     help="with --resample: the new step graph of every step is padded to a host-known node capacity and its node count stays "
                          "on the device (sampler.static_step, mrg_set_dynamic_rows): no host read in the step, every shape fixed -- with "
-                         "--hip-graph the WHOLE step, sampler included, is captured once and replayed with a new draw every time")
+                         "--hip-graph (which implies it) the WHOLE step, sampler included, is captured once and replayed with a new draw every time")
     ap.add_argument("--comm", default=os.environ.get("MRG_COMM", "direct"), choices=["direct", "c10d"],
                     help="N > 1: 'direct' = RCCL bound through ctypes (mr_gnas_amd/rccl.py: stream-ordered launches, the step is captured in a "
                          "HIP graph when every rank's capture succeeds; torch.distributed/gloo only bootstraps and times); 'c10d' = "
@@ -138,7 +138,10 @@ def parse():
                          "launch of the real run on a one-rank RCCL communicator; the other ranks' contributions are zeros)")
     ap.add_argument("--no-shard-graph", action="store_true", help="N > 1 with --comm direct: do not capture the sharded step in a HIP graph")
     ap.add_argument("--seed", type=int, default=0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.resample and a.hip_graph:
+        a.static_step = True         # a new draw per REPLAY needs fixed shapes and device-side counts: --resample --hip-graph implies --static-step
+    return a
 
 
 def build_step_inputs(workload, negative, seed):
