@@ -249,7 +249,7 @@ class FixedStep:
         self.model = S.FixedNetwork(device, geno, N, R, dim, init_dim, nbase, dropout_cell=0.3, drop_aggr=0.1).to(device)
         S.xavier_init_(self.model)
         self.model.train()
-        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3)
+        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3, capturable=bool(getattr(args, "hip_graph", False)))
         idx = SM.LabelIndex(tri, R, N, device)
         rng = np.random.default_rng(args.seed + 3)
         pick = rng.integers(0, T, 256)
@@ -287,7 +287,7 @@ class CompGCNStep:
         self.model = C.CompGCN(100, 2 * R, N, in_dim=args.dim, layer_size=[args.dim, args.dim], comp_fn=args.comp_fn, batchnorm=True,
                                dropout=0.1, layer_dropout=[0.3, 0.3]).to(device)
         self.model.train()
-        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3)
+        self.opt = torch.optim.Adam(self.model.parameters(), 1e-3, capturable=bool(getattr(args, "hip_graph", False)))
         self.samples = torch.empty(0, 3)
         self.last_loss = None
 
