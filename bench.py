@@ -645,7 +645,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             barrier = dist.barrier
         s_rank, s_world = rehearse if rehearse is not None else (rank, world)
-        step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), s_rank, s_world, group=comm)
+        if args.workload == "c5_fixed_cell":                 # the fixed-genotype step on relation blocks, node tables row-sharded
+            args.dim = 256
+            step = MD.ShardedFixedStep(args, device, "synthetic10m", s_rank, s_world, group=comm, dim=256, init_dim=64, nbase=64)
+        elif args.workload == "fb15k237_fixed_d64":
+            args.dim = 64
+            step = MD.ShardedFixedStep(args, device, "fb15k237", s_rank, s_world, group=comm, dim=64, init_dim=64, nbase=23)
+        elif args.workload == "compgcn_fb15k237":
+            raise SystemExit("compgcn_fb15k237 is a single-GPU workload")
+        else:
+            step = MD.ShardedStep(args, device, build_step_inputs(args.workload, args.negative, args.seed), s_rank, s_world, group=comm)
     elif args.workload == "fb15k237_fixed_d64":
         args.dim = 64
         step = FixedStep(args, device)

@@ -561,6 +561,149 @@ class ShardedSupernet:
         return F.binary_cross_entropy_with_logits(score, labels_local, reduction="sum") / total_samples
 
 
+# ---------------------------------------------------------------------------
+# the sharded fixed-genotype step (reference models/model_lp.py:77-150; BASELINE C5: 10 M edges, 1 M nodes)
+# ---------------------------------------------------------------------------
+class ShardedFixedNet:
+    """Forward of supernet.FixedNetwork on one relation block.  Same cell code (supernet.FixedCell.forward with its two hooks),
+    rows partitioned like the supernet's, and -- what the supernet's replicated tables do not need at FB15k-237 size but the
+    1 M-node table of C5 does -- the NODE TABLES ROW-SHARDED:
+
+    * the initial table: every rank owns the rows [node_lo, node_hi) of embedding_h as its own leaf (`emb_own`, taken out of
+      the replicated parameter list: no gradient exchange, 1/P of the optimiser state), projects them and all-gathers the
+      [N, D] result once per step;
+    * the last cell's output is NOT all-gathered: the [B, N] scorer (reference models/operations_lp.py:115-127) is
+      evaluated on the own columns [B, n_own] against the labels' own columns, and the B subject rows travel in one [B, D]
+      all-reduce (each rank contributes the subjects it owns).  At C5 that is 256 KB instead of a 1 GB all-gather.
+
+    Per cell: an aggregator node = partial over the local edges -> reduce-scatter over node chunks (dist._ReduceScatterRows);
+    every node's BatchNorm over ALL ranks' rows (statistics all-reduce inside the fused epilogue on the GPU, sync_batch_norm on
+    CPU); between cells one all-gather of the [n_own, D] output.  `kernels`: as for ShardedSupernet."""
+
+    def __init__(self, model, shard, group=None, kernels=K):
+        self.m, self.s, self.group, self.k = model, shard, group, kernels
+        s, dev = shard, shard.device
+        src, _, _ = s.edges(form="all")
+        own = torch.arange(s.node_lo, s.node_hi, device=dev)
+        N = s.number_of_nodes()
+        self.rows_total = s.E_global + N
+        self.p_ent = kernels.GatherPlan(torch.cat((src, own)), N)
+        rel_idx = torch.cat((s.edata["e_type"].long(), torch.full((s.n_own,), model._num_rel - 1, dtype=torch.long, device=dev)))
+        self.p_rel = kernels.GatherPlan(rel_idx, model._num_rel)
+        self.emb_own = torch.nn.Parameter(model.embedding_h.weight.detach()[s.node_lo:s.node_hi].clone())
+        self._info = (s.node_cuts, s.node_chunk, s.rank)
+
+    def replicated_parameters(self):
+        """The parameters every rank holds in full (their gradients are all-reduced): all but the row-sharded initial table."""
+        skip = self.m.embedding_h.weight
+        return [p for p in self.m.parameters() if p is not skip]
+
+    def parameters(self):
+        return self.replicated_parameters() + [self.emb_own]
+
+    def _stat_group(self):
+        return self.group if self.group is not None else dist.group.WORLD
+
+    def _inv_degree(self):
+        if getattr(self, "_inv_deg", None) is None:
+            s = self.s
+            self._inv_deg = (1.0 / s.global_in_degree[s.node_lo:s.node_hi].clamp(min=1).to(torch.float32)).view(-1, 1).contiguous()
+        return self._inv_deg
+
+    def _bn_relu(self, y, bn, total, one):
+        if y.is_cuda:
+            one = one if one.device == y.device else one.to(y.device)
+            return K.mixed_epilogue([y], [bn], one, self._stat_group(), total)
+        return F.relu(sync_batch_norm(y.float(), bn, total, self.group))
+
+    def _aggregate(self, op, name, x):
+        """a_max / a_sum / a_mean over a relation block: partial over the LOCAL in-edges, reduce-scatter over the node chunks,
+        residual self rows (reference models/operations_lp.py:223-264)."""
+        s, E = self.s, self.s.num_edges()
+        hip = x.is_cuda and getattr(self.k, "linear_relu_partial", None) is not None
+        kind = "max" if name == "a_max" else "sum"
+        if name == "a_sum":
+            part, self_rows = self.k.sum_partial(x, s) if hip else (self.k.seg_reduce("sum", x[:E], None, s), x[E:])
+        elif hip:
+            part, self_rows = self.k.linear_relu_partial(kind, x, op.linear.weight, op.linear.bias, s)
+        else:
+            part, self_rows = self.k.seg_reduce(kind, self.k.linear(x[:E], op.linear.weight, op.linear.bias, act="relu"), None, s), x[E:]
+        own = reduce_scatter_rows(part, s, kind, self.group)
+        if name == "a_sum":
+            own = op.drop_sum(own)
+        elif name == "a_mean":
+            own = own * self._inv_degree()
+        return own + self_rows
+
+    def _node_rows(self, mod):
+        """Does this op module's output have one row per NODE (True) or per edge-and-self row (False)?  f_zero / f_identity are
+        in FIRST_OPS and LAST_OPS alike: they take the kind of the other ops feeding the same cell node, else of their input."""
+        kinds = getattr(self, "_kinds", None)
+        if kinds is None:
+            kinds = self._kinds = {}
+            node_ops = set(OPS.MIDDLE_OPS) | (set(OPS.LAST_OPS) - set(OPS.FIRST_OPS))
+            edge_ops = set(OPS.PRE_OPS) | (set(OPS.FIRST_OPS) - set(OPS.LAST_OPS))
+            for cell in self.m.cells:
+                state = [False, False]                       # state 0 (gathered rows) and the zero node's output: edge rows
+                kinds[id(cell._ops[0][0][0])] = False
+                for n in range(1, cell._nb):
+                    mods = [(i, cell._ops[n][i][0]) for i in range(n + 1) if len(cell._ops[n][i])]
+                    names = {m_.op_name for _, m_ in mods}
+                    kind = True if names & node_ops else False if names & edge_ops else state[mods[0][0]]
+                    for _, m_ in mods:
+                        kinds[id(m_)] = kind
+                    state.append(kind)
+        return kinds[id(mod)]
+
+    def _apply(self, mod, h, h_in):
+        """One node of the fixed cell (supernet.OpModule: op -> BN -> ReLU, 'pre_mult' bare) on this rank's rows."""
+        name = mod.op_name
+        N = self.s.number_of_nodes()
+        if name in OPS.MIDDLE_OPS:
+            y, total = self._aggregate(mod.op, name, h), N
+        else:
+            from . import cell_lp as _cell_lp
+            y = _cell_lp._run(mod.op, self.s, h, h_in) if h.is_cuda else mod.op(self.s, h, h_in)
+            total = N if self._node_rows(mod) else self.rows_total
+        if name == "pre_mult":
+            return y
+        return self._bn_relu(y, mod.batchnorm_h, total, mod._one)
+
+    def forward(self, subj, rel):
+        """Returns pred_own [B, n_own]: this rank's columns of the reference's [B, N] prediction."""
+        with K.deferred_counters():
+            return self._forward(subj, rel)
+
+    def _forward(self, subj, rel):
+        m, s = self.m, self.s
+        N = s.number_of_nodes()
+        own = K.module_linear(m.linear_e, self.emb_own)                      # [n_own, D]: the own rows of the projected table
+        ent = _AllGatherRows.apply(own, self._info, self.group)
+        rel_emb = torch.mm(m.rel_wt, m.embedding_e.weight)
+        for ci, cell in enumerate(m.cells):
+            x, hr = self.k.gather(ent, self.p_ent), self.k.gather(rel_emb, self.p_rel)
+            own = cell(s, x, hr, apply=self._apply, finish=lambda h, c=cell: self._bn_relu(h, c.batchnorm_h, N, c._one))
+            own = F.dropout(own, m._dropout, training=m.training)
+            if ci + 1 < len(m.cells):
+                ent = _AllGatherRows.apply(own, self._info, self.group)
+            rel_emb = torch.matmul(rel_emb, m.w_rel)
+        # the B subject rows: each rank contributes the subjects it owns, one [B, D] all-reduce
+        subj = subj.view(-1).long()
+        mine = ((subj >= s.node_lo) & (subj < s.node_hi)).view(-1, 1).to(own.dtype)
+        local = own[(subj - s.node_lo).clamp(0, max(s.n_own - 1, 0))] * mine if s.n_own else own.new_zeros(subj.numel(), own.shape[1])
+        sub = _AllReduceSum.apply(local, self.group, True)
+        r = rel_emb[rel.view(-1).long()]
+        if not own.is_cuda and hasattr(self.k, "score_all"):                  # the gloo tests' stand-in (tests/cpu_kernels.py)
+            return self.k.score_all(m.score_func, own, sub, r)
+        return m.score_func(own, sub, r)
+
+    def loss(self, pred_own, label):
+        """This rank's share of nn.BCELoss over [B, N] (reference train/mr_lp_train.py:139-141): the ranks' values add up."""
+        s = self.s
+        B, N = label.shape
+        return F.binary_cross_entropy(pred_own, label[:, s.node_lo:s.node_hi], reduction="sum") / (B * N)
+
+
 def all_reduce_gradients(tensors, group=None):
     """One flat all-reduce (sum) over the gradients of `tensors` (parameters and alphas);
     tensors that received no gradient on this rank contribute zeros."""
@@ -611,6 +754,50 @@ class ShardedStep:
         self.opt.zero_grad(set_to_none=True)
         for a in self.arch:
             a.grad = None
+        total = loss.detach().clone()
+        all_reduce(total, dist.ReduceOp.SUM, self.group)
+        self.last_loss = total
+
+
+class ShardedFixedStep:
+    """bench.py's fixed-genotype step (C1 / C5 shape) on N GPUs: README genotype, Adam, labels built on the device; edges in
+    relation blocks, node tables row-sharded (ShardedFixedNet)."""
+
+    def __init__(self, args, device, shape, rank, world, group=None, dim=256, init_dim=100, nbase=100, batch=256):
+        from . import graph as G, sampler as SM, supernet as S, synth
+        N, R, T = synth.SHAPES[shape]
+        tri = synth.synth_kg(N, R, T, args.seed)
+        torch.manual_seed(args.seed)                      # identical parameters on every rank
+        g = G.build_train_graph(N, R, tri, device=device)
+        src, dst, _ = g.edges(form="all")
+        self.g = EdgeShard(N, src, dst, g.edata["e_type"], g.edata["norm"], R, rank, world, device)
+        del g
+        self.E, self.E_global = self.g.num_edges(), self.g.E_global
+        geno = [S.Genotype(alpha_cell=[('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2), ('a_max', 5, 3),
+                                       ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)], concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+        self.model = S.FixedNetwork(device, geno, N, R, dim, init_dim, nbase, dropout_cell=0.3, drop_aggr=0.1).to(device)
+        S.xavier_init_(self.model)
+        self.model.train()
+        self.net = ShardedFixedNet(self.model, self.g, group)
+        self.replicated = self.net.replicated_parameters()
+        self.opt = torch.optim.Adam(self.net.parameters(), 1e-3, capturable=True)
+        self.idx = SM.LabelIndex(tri, R, N, device)
+        rng = np.random.default_rng(args.seed + 3)
+        pick = rng.integers(0, T, batch)
+        self.subj = torch.from_numpy(tri[pick, 0]).to(device)
+        self.rel = torch.from_numpy(tri[pick, 1]).to(device)
+        self.samples = self.subj
+        self.group, self.last_loss = group, None
+        torch.manual_seed(args.seed + 1000 + rank)         # dropout masks differ per rank (disjoint rows)
+
+    def __call__(self):
+        labels = self.idx.labels(self.subj, self.rel, 0.1)
+        pred = self.net.forward(self.subj, self.rel)
+        loss = self.net.loss(pred, labels)
+        loss.backward()
+        all_reduce_gradients(self.replicated, self.group)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
         total = loss.detach().clone()
         all_reduce(total, dist.ReduceOp.SUM, self.group)
         self.last_loss = total

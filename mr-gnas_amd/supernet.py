@@ -357,20 +357,25 @@ class FixedCell(nn.Module):
             self._reader_caps = caps
         return caps
 
-    def forward(self, g, src_emb, hr):
+    def forward(self, g, src_emb, hr, apply=None, finish=None):
+        """apply(op_module, h, h_in) -> the node's candidate, finish(concat output) -> the cell's output: the hooks through which
+        dist.ShardedFixedNet runs the same cell on a relation block (aggregator exchanges, statistics over all ranks' rows)."""
         caps = self._caps()
+        apply = apply or (lambda mod, h, h_in: mod(g, h, h_in))
         # a state with several readers hands out aliases (functional.Fan): its gradient is ONE K-way sum of the readers' gradients
         # instead of autograd's chain of pairwise adds (K - 1 launches of three [rows, D] passes each: 12.8 ms of the C5 step)
         fan = lambda x, i: K.Fan(x, caps[i]) if (x.is_cuda and caps[i] > 1) else None
         take = lambda i: fans[i].take() if fans[i] is not None else states[i]
         states = [src_emb]
         fans = [fan(src_emb, 0)]
-        states.append(self._ops[0][0][0](g, take(0), hr))
+        states.append(apply(self._ops[0][0][0], take(0), hr))
         fans.append(fan(states[1], 1))
         for n in range(1, self._nb):
-            states.append(_tsum(self._ops[n][i][0](g, take(i), take(1)) for i in range(n + 1) if len(self._ops[n][i])))
+            states.append(_tsum(apply(self._ops[n][i][0], take(i), take(1)) for i in range(n + 1) if len(self._ops[n][i])))
             fans.append(fan(states[-1], n + 1))
         h = K.module_linear(self.concat, torch.cat([take(i) for i in self._concat_node], dim=1))
+        if finish is not None:
+            return finish(h)
         if h.is_cuda:                                   # BN + ReLU on the MixedOp epilogue kernels with one branch of weight 1 (OpModule.forward)
             one = self._one if self._one.device == h.device else self._one.to(h.device)
             return K.mixed_epilogue([h], [self.batchnorm_h], one)

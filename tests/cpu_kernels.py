@@ -18,6 +18,12 @@ def linear(x, W, b=None, act=None):
     return F.relu(y) if act == "relu" else y
 
 
+def score_all(score_func, all_ent, sub, rel):
+    """sf_DisMult_op on CPU rows (reference models/operations_lp.py:115-127): sigmoid((sub * rel) all_ent^T)."""
+    assert type(score_func).__name__ == "sf_DisMult_op"
+    return torch.sigmoid(torch.mm(sub * rel, all_ent.t()))
+
+
 def seg_reduce(kind, msg, self_rows, graph):
     _, dst, _ = graph.edges(form="all")
     n = graph.number_of_nodes()

@@ -127,6 +127,66 @@ def test_sharded_supernet_matches_reference(tmp_path, world, case):
         assert float((got - v).abs().max()) <= 2e-3 * scale + 5e-6, k
 
 
+README_CELL = [('pre_sub', 1, 0), ('f_sparse_comp', 2, 1), ('f_sparse_comp', 3, 2), ('a_max', 4, 2), ('a_max', 5, 3),
+               ('f_sparse_last', 6, 5), ('f_sparse_last', 7, 5)]
+
+
+def _fixed_worker(rank, world, port, case, out):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels as CK
+    from mr_gnas_amd import supernet as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        z = load_golden(case)
+        geno = [S.Genotype(alpha_cell=README_CELL, concat_node=[4, 5, 6, 7], score_func='sf_DisMult')]
+        net = S.FixedNetwork("cpu", geno, z["N"], z["R"], z["D"], z["D0"], z["nbase"], registry=CK.registry())
+        net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+        net.train()
+        shard = MD.EdgeShard(z["N"], z["src"], z["dst"], z["etype"], z["norm"], z["R"], rank, world, "cpu")
+        sn = MD.ShardedFixedNet(net, shard, kernels=CK)
+        pred = sn.forward(z["subj"], z["rel"])
+        loss = sn.loss(pred, z["label"])
+        loss.backward()
+        MD.all_reduce_gradients(sn.replicated_parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        # the row-sharded pieces travel to rank 0 for the comparison only: prediction columns and the own rows' table gradient
+        preds = [None] * world
+        gembs = [None] * world
+        dist.all_gather_object(preds, pred.detach())
+        dist.all_gather_object(gembs, sn.emb_own.grad)
+        if rank == 0:
+            res = {"pred": torch.cat(preds, dim=1), "loss": total, "g/embedding_h.weight": torch.cat(gembs, dim=0),
+                   "own": [int(p.shape[1]) for p in preds], "replicated_has_table": any(p is net.embedding_h.weight for p in sn.replicated_parameters())}
+            for k, p in net.named_parameters():
+                if k != "embedding_h.weight":
+                    res["g/" + k] = p.grad
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "fixednet_d64"), (2, "fixednet_tiny"), (3, "fixednet_tiny")])
+def test_sharded_fixed_network_matches_reference(tmp_path, world, case):
+    """The fixed-genotype network (reference models/model_lp.py:77-150, README genotype) on relation blocks with ROW-SHARDED node
+    tables (dist.ShardedFixedNet) against the reference's own prediction, loss and gradients."""
+    out = str(tmp_path / "res.pt")
+    port = 29500 + (os.getpid() % 2000) + 10 + world
+    mp.spawn(_fixed_worker, args=(world, port, case, out), nprocs=world, join=True)
+    res = torch.load(out)
+    z = load_golden(case)
+    assert sum(res["own"]) == z["N"] and not res["replicated_has_table"]
+    torch.testing.assert_close(res["pred"], z["pred"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(res["loss"], z["loss"], rtol=1e-5, atol=1e-7)
+    for k, v in sub(z, "gparam/").items():
+        got = res["g/" + k]
+        assert got is not None, k
+        scale = max(float(v.abs().max()), 1e-8)
+        assert float((got - v).abs().max()) <= 2e-3 * scale + 1e-7, k
+
+
 def _bring_up_worker(rank, world, port, fault, out):
     """rccl.bring_up with a fault injected on ONE rank: every rank must leave it together with None (advisor r4)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

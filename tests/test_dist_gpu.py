@@ -142,3 +142,96 @@ def test_virtual_world_rehearsal_runs(comm):
         assert torch.isfinite(loss) and ent.shape[0] == n and vw.launches >= 20
     finally:
         vw.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the sharded FIXED-genotype network (reference models/model_lp.py:77-150; BASELINE C5 at N > 1): node tables row-sharded
+# ---------------------------------------------------------------------------------------------------------------------------
+def _fixed_golden(case):
+    from test_nets_gpu import README_GENOTYPE
+    from conftest import sub
+    z = load_golden(case)
+    net = S.FixedNetwork(DEV, README_GENOTYPE, z["N"], z["R"], z["D"], z["D0"], z["nbase"], score_args={"gamma": 9.0}).to(DEV)
+    net.load_state_dict({**sub(z, "param/"), **sub(z, "buffer/")})
+    net.train()
+    return z, net
+
+
+@pytest.mark.parametrize("case", ["fixednet_tiny", "fixednet_d64"])
+def test_sharded_fixed_network_on_direct_rccl_matches_reference(case, comm):
+    """dist.ShardedFixedNet on the HIP kernels with an RCCL communicator of one rank against the reference's own run: prediction,
+    loss, every gradient (the row-sharded initial table's through its own-rows leaf).  Multi-rank arithmetic: the gloo tests."""
+    from conftest import assert_param_grad
+    z, net = _fixed_golden(case)
+    shard = MD.EdgeShard(z["N"], z["src"].to(DEV), z["dst"].to(DEV), z["etype"].to(DEV), z["norm"].to(DEV), z["R"], 0, 1, DEV)
+    sn = MD.ShardedFixedNet(net, shard, group=comm)
+    before = comm.launches
+    pred = sn.forward(z["subj"].to(DEV), z["rel"].to(DEV))
+    loss = sn.loss(pred, z["label"].to(DEV))
+    loss.backward()
+    MD.all_reduce_gradients(sn.replicated_parameters(), comm)
+    assert comm.launches - before >= 20                    # statistics, two aggregator exchanges, table all-gather, subject rows, gradients
+    torch.testing.assert_close(pred.cpu(), z["pred"], rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(loss.detach().cpu(), z["loss"], rtol=1e-4, atol=1e-6)
+    assert net.embedding_h.weight.grad is None and not any(p is net.embedding_h.weight for p in sn.replicated_parameters())
+    for k, p in net.named_parameters():
+        g = sn.emb_own.grad if k == "embedding_h.weight" else p.grad
+        assert_param_grad(z, k, g if g is not None else torch.zeros_like(p), 5e-4, 5e-6, case + " sharded")
+
+
+def test_sharded_fixed_step_replays_from_a_hip_graph(comm):
+    """Forward + loss + backward + gradient all-reduce + Adam of the sharded fixed-genotype step captured once and replayed."""
+    z, net = _fixed_golden("fixednet_d64")
+    shard = MD.EdgeShard(z["N"], z["src"].to(DEV), z["dst"].to(DEV), z["etype"].to(DEV), z["norm"].to(DEV), z["R"], 0, 1, DEV)
+    sn = MD.ShardedFixedNet(net, shard, group=comm)
+    subj, rel, label = z["subj"].to(DEV), z["rel"].to(DEV), z["label"].to(DEV)
+    static = {}
+
+    def step():
+        for p in sn.parameters():
+            p.grad = None
+        pred = sn.forward(subj, rel)
+        loss = sn.loss(pred, label)
+        loss.backward()
+        MD.all_reduce_gradients(sn.replicated_parameters(), comm)
+        static["loss"], static["pred"] = loss.detach(), pred.detach()
+        static["grads"] = [p.grad for p in sn.parameters()]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager_loss, eager_grads = float(static["loss"]), [g.clone() for g in static["grads"]]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(static["loss"]) - eager_loss) <= 1e-6 * max(1.0, abs(eager_loss))
+    torch.testing.assert_close(static["pred"].cpu(), z["pred"], rtol=1e-4, atol=5e-5)
+    for a, b in zip(static["grads"], eager_grads):
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6) + 1e-9
+
+
+def test_virtual_world_rehearsal_of_the_fixed_step_runs():
+    """bench.py --rehearse-shard R/8 --workload c5_fixed_cell in small: rank 5 of 8 of the fixed-genotype step on one GPU (timing
+    only: the other ranks contribute zeros), values finite, own columns = the rank's node chunk."""
+    from mr_gnas_amd import rccl
+    z, net = _fixed_golden("fixednet_d64")
+    vw = rccl.VirtualWorld(5, 8, DEV)
+    try:
+        shard = MD.EdgeShard(z["N"], z["src"].to(DEV), z["dst"].to(DEV), z["etype"].to(DEV), z["norm"].to(DEV), z["R"], 5, 8, DEV)
+        sn = MD.ShardedFixedNet(net, shard, group=vw)
+        pred = sn.forward(z["subj"].to(DEV), z["rel"].to(DEV))
+        loss = sn.loss(pred, z["label"].to(DEV))
+        loss.backward()
+        MD.all_reduce_gradients(sn.replicated_parameters(), vw)
+        torch.cuda.synchronize()
+        assert pred.shape == (len(z["subj"]), shard.n_own) and bool(torch.isfinite(pred).all()) and bool(torch.isfinite(loss))
+        assert all(bool(torch.isfinite(p.grad).all()) for p in sn.parameters() if p.grad is not None)
+    finally:
+        vw.destroy()
