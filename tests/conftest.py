@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 # ---- measured parity margins: every gradient / output comparison records its worst error next to the
 # bound it was held to, so a regression inside the tolerance is visible.  Written to gpurun_out/parity_margins.json at the end of
-# the session; the copy kept for the judge is profiles/r3_parity_margins.json.
+# the session; the copy kept for the judge is profiles/rN_parity_margins.json (trimmed to the full-size and control records).
 MARGINS = []
 
 

@@ -392,6 +392,76 @@ def test_c4_sharded_step_world1_rccl_full_size(fb_case):
         dist.destroy_process_group()
 
 
+def _c4_rank(rank, world, port, inp, out):
+    """One rank of the FB15k-237-size sharded step on the HIP kernels (this box's one GPU is shared by the ranks' processes;
+    collectives over gloo on device tensors -- the transport is not what is tested)."""
+    import datetime
+    import torch.distributed as dist
+    from mr_gnas_amd import dist as MD
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    try:
+        torch.cuda.set_device(0)
+        c = torch.load(inp, weights_only=False)          # this test's own temporary file (holds numpy arrays)
+        N, R = c["N"], c["R"]
+        model = S.SearchNetwork(DEV, N, R, 2, 1, 2, 2, 200, 100, 2 * R + 1, 40.0, 0.0, 0.0).to(DEV)
+        model.load_state_dict(c["state"])
+        model.load_alpha([a.to(DEV) for a in c["alphas"]])
+        model.train()
+        g = G.build_search_graph(N, R, c["tri"]).to(DEV)
+        src, dst, _ = g.edges(form="all")
+        shard = MD.EdgeShard(N, src, dst, g.edata["e_type"], g.edata["norm"], R, rank, world, DEV)
+        sn = MD.ShardedSupernet(model, shard, torch.arange(N))
+        ent, rel = sn.forward()
+        lo = MD.node_ranges(len(c["samples"]), world)
+        loss = sn.loss(ent, rel, c["samples"][lo[rank]:lo[rank + 1]].to(DEV), c["labels"][lo[rank]:lo[rank + 1]].to(DEV), len(c["samples"]))
+        loss.backward()
+        MD.all_reduce_gradients(list(model.parameters()) + model.arch_parameters()[:4])
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        torch.cuda.synchronize()
+        edges = [None] * world
+        dist.all_gather_object(edges, int(shard.num_edges()))
+        if rank == 0:
+            torch.save(dict(ent=ent.detach().cpu(), rel=rel.detach().cpu(), loss=float(total), edges=edges,
+                            g={k: (p.grad if p.grad is not None else torch.zeros_like(p)).cpu() for k, p in model.named_parameters()},
+                            ga=[a.grad.cpu() for a in model.arch_parameters()[:4]]), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_sharded_step_on_four_ranks_full_size(fb_case, tmp_path):
+    """C4 with MORE THAN ONE rank on the HIP kernels: the FB15k-237-size supernet step cut into four relation blocks, one process
+    per rank (all on this box's single GPU, gloo transport), against the plain single-GPU step and the float64 oracle.  What the
+    world-1 RCCL test cannot see -- partial aggregators meeting in a reduce-scatter, statistics summed over ranks' rows, own-row
+    chunks of unequal size -- runs here at full size on the product's kernels."""
+    import time
+    import torch.multiprocessing as mp
+    c = fb_case
+    world, inp, out = 4, str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
+    torch.save(dict(N=c["N"], R=c["R"], tri=c["tri"], samples=c["samples"].cpu(), labels=c["labels"].cpu(),
+                    state={k: v.cpu() for k, v in c["model"].state_dict().items()},
+                    alphas=[a.detach().cpu() for a in c["model"].arch_parameters()]), inp)
+    port = 29500 + (os.getpid() % 2000) + 60
+    ctx = mp.start_processes(_c4_rank, args=(world, port, inp, out), nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + 600
+    try:
+        while not ctx.join(timeout=5):
+            assert time.time() < deadline, "a rank did not finish"
+    finally:
+        for p in ctx.processes:                            # exactly the processes started here
+            if p.is_alive():
+                p.kill()
+    got = torch.load(out, weights_only=False)
+    E = sum(got["edges"])
+    assert E == c["g"].num_edges() and max(got["edges"]) <= 1.1 * E / world, got["edges"]
+    got = dict(ent=got["ent"].to(DEV), rel=got["rel"].to(DEV), loss=got["loss"], g={k: v.to(DEV) for k, v in got["g"].items()},
+               ga=[a.to(DEV) for a in got["ga"]])
+    assert abs(got["loss"] - c["hip"]["loss"]) <= 1e-4 * max(1.0, abs(c["hip"]["loss"]))
+    assert rel_err(got["ent"], c["hip"]["ent"]) <= 1e-4
+    check_step(got, c["ref"], "C4 sharded world=4 (HIP kernels, one GPU, gloo transport)")
+
+
 # ---------------------------------------------------------------------------
 # C3: WN18RR supernet, D = 200
 # ---------------------------------------------------------------------------
@@ -785,3 +855,110 @@ def test_c5_fixed_cell_readme_genotype(c5):
     assert rel_err(s.grad[rows], a64.grad) <= 1e-4 and rel_err(s_in.grad[rows], b64.grad) <= 1e-4
     del s, s_in, gM
     free()
+
+
+# ---------------------------------------------------------------------------
+# C5 on more than one rank: the sharded fixed-genotype network (dist.ShardedFixedNet) at 10 M edges / 1 M nodes / D = 256
+# ---------------------------------------------------------------------------
+C5_NET = dict(D=256, D0=64, nbase=64, B=256)
+
+
+def _c5_model(N, R):
+    geno = [S.Genotype(alpha_cell=[("pre_sub", 1, 0), ("f_sparse_comp", 2, 1), ("f_sparse_comp", 3, 2), ("a_max", 4, 2), ("a_max", 5, 3),
+                                   ("f_sparse_last", 6, 5), ("f_sparse_last", 7, 5)], concat_node=[4, 5, 6, 7], score_func="sf_DisMult")]
+    return S.FixedNetwork(DEV, geno, N, R, C5_NET["D"], C5_NET["D0"], C5_NET["nbase"], dropout_cell=0.0, drop_aggr=0.0).to(DEV)
+
+
+def _c5_rank(rank, world, port, inp, out):
+    import datetime
+    import torch.distributed as dist
+    from mr_gnas_amd import dist as MD
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    try:
+        torch.cuda.set_device(0)
+        c = torch.load(inp, weights_only=False)          # this test's own temporary file
+        N, R, T = synth.SHAPES["synthetic10m"]
+        g = G.build_train_graph(N, R, synth.synth_kg(N, R, T, 0), device=DEV)
+        src, dst, _ = g.edges(form="all")
+        shard = MD.EdgeShard(N, src, dst, g.edata["e_type"], g.edata["norm"], R, rank, world, DEV)
+        del g, src, dst
+        model = _c5_model(N, R)
+        model.load_state_dict(c["state"])
+        model.train()
+        sn = MD.ShardedFixedNet(model, shard)
+        pred = sn.forward(c["subj"].to(DEV), c["rel"].to(DEV))
+        loss = sn.loss(pred, c["label"].to(DEV))
+        loss.backward()
+        MD.all_reduce_gradients(sn.replicated_parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        torch.cuda.synchronize()
+        torch.save(dict(pred=pred.detach().cpu(), gemb=sn.emb_own.grad.cpu(), lo=shard.node_lo, hi=shard.node_hi, edges=int(shard.num_edges()),
+                        loss=float(total), peak_GiB=torch.cuda.max_memory_allocated() / 2**30,
+                        g=({k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None} if rank == 0 else None)), f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_sharded_fixed_network_on_four_ranks(c5, tmp_path):
+    """BASELINE config 5 is a multi-GPU config: the README-genotype network at E = 10 M, N = 1 M, D = 256 on FOUR relation blocks
+    with row-sharded node tables (one process per rank on this box's single GPU, gloo transport) against the plain single-GPU
+    network on the same parameters: prediction columns, loss, every parameter gradient (the initial table's from the ranks' own
+    rows).  Both sides are the product's f32 kernels in different summation orders."""
+    import time
+    import torch.multiprocessing as mp
+    from conftest import record_margin
+    N, R, B = c5["N"], c5["R"], C5_NET["B"]
+    T = synth.SHAPES["synthetic10m"][2]
+    tri = synth.synth_kg(N, R, T, 0)
+    g = G.build_train_graph(N, R, tri, device=DEV)
+    torch.manual_seed(4)
+    model = _c5_model(N, R)
+    S.xavier_init_(model)
+    model.train()
+    rng = np.random.default_rng(9)
+    pick = rng.integers(0, T, B)
+    subj, rel = torch.from_numpy(tri[pick, 0]).to(DEV), torch.from_numpy(tri[pick, 1]).to(DEV)
+    label = (torch.rand(B, N, device=DEV, generator=c5["gen"]) < 0.01).float()
+    inp, out, world = str(tmp_path / "in.pt"), str(tmp_path / "out.pt"), 4
+    torch.save(dict(state={k: v.cpu() for k, v in model.state_dict().items()}, subj=subj.cpu(), rel=rel.cpu(), label=label.cpu()), inp)
+    pred = model(g, subj, rel)
+    loss = F.binary_cross_entropy(pred, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    plain = dict(pred=pred.detach().cpu(), loss=float(loss.detach()), g={k: p.grad.cpu() for k, p in model.named_parameters()})
+    del pred, loss, model, g, label
+    free()
+    port = 29500 + (os.getpid() % 2000) + 80
+    ctx = mp.start_processes(_c5_rank, args=(world, port, inp, out), nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + 900
+    try:
+        while not ctx.join(timeout=5):
+            assert time.time() < deadline, "a rank did not finish"
+    finally:
+        for p in ctx.processes:                            # exactly the processes started here
+            if p.is_alive():
+                p.kill()
+    parts = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    what = "C5 sharded fixed network, world=4 (HIP kernels, one GPU, gloo transport)"
+    assert [p["lo"] for p in parts] + [parts[-1]["hi"]] == [0, 250000, 500000, 750000, 1000000]
+    assert sum(p["edges"] for p in parts) == 10_000_000 and max(p["edges"] for p in parts) <= 1.1 * 10_000_000 / world
+    got_pred = torch.cat([p["pred"] for p in parts], dim=1)
+    err = rel_err(got_pred, plain["pred"])
+    record_margin(what, "prediction [256, 1 M] against the single-GPU network", err, 1.0, 1e-4)
+    record_margin(what, "peak HBM per rank (GiB)", max(p["peak_GiB"] for p in parts), 1.0, float("inf"))
+    assert err <= 1e-4, err
+    assert abs(parts[0]["loss"] - plain["loss"]) <= 1e-5 * max(1.0, abs(plain["loss"]))
+    grads = dict(parts[0]["g"])
+    grads["embedding_h.weight"] = torch.cat([p["gemb"] for p in parts], dim=0)
+    bad = []
+    for k, ref in plain["g"].items():
+        e, scale = grad_err(grads[k], ref)
+        tol = GRAD_RTOL * max(scale, 1e-8) + 1e-7          # biases in front of a BatchNorm have a zero gradient: ~3e-8 of rounding on both sides
+        d = (grads[k].double() - ref.double()).abs()
+        outliers = float((d > tol).double().mean())
+        record_margin(what, k, e, scale, tol, outliers)
+        if e > tol and not (outliers <= 0.005 and e <= 2e-2 * max(scale, 1e-8)):          # isolated ReLU / arg-max flips: as in check_step
+            bad.append(f"{k}: {e:.3e} (scale {scale:.3e}, {outliers:.2%})")
+    assert not bad, " | ".join(bad)

@@ -235,3 +235,84 @@ def test_virtual_world_rehearsal_of_the_fixed_step_runs():
         assert all(bool(torch.isfinite(p.grad).all()) for p in sn.parameters() if p.grad is not None)
     finally:
         vw.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# FOUR ranks on the HIP kernels: one process per rank sharing this box's one GPU, collectives over gloo on device tensors.
+# The multi-rank arithmetic of tests/test_dist_cpu.py (CPU stand-in kernels) and the HIP kernels of the one-rank RCCL tests meet
+# here: every rank runs the product's kernels on its relation block and the results must be the reference's.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _hip_rank(rank, world, port, case, out):
+    import datetime
+    import os
+    import torch.distributed as dist
+    from conftest import sub
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        torch.cuda.set_device(0)
+        z = load_golden(case)
+        res = {}
+        if case.startswith("fixednet"):
+            z, net = _fixed_golden(case)
+            shard = MD.EdgeShard(z["N"], z["src"].to(DEV), z["dst"].to(DEV), z["etype"].to(DEV), z["norm"].to(DEV), z["R"], rank, world, DEV)
+            sn = MD.ShardedFixedNet(net, shard)
+            pred = sn.forward(z["subj"].to(DEV), z["rel"].to(DEV))
+            loss = sn.loss(pred, z["label"].to(DEV))
+            loss.backward()
+            MD.all_reduce_gradients(sn.replicated_parameters())
+            preds, gembs = [None] * world, [None] * world
+            dist.all_gather_object(preds, pred.detach().cpu())
+            dist.all_gather_object(gembs, sn.emb_own.grad.cpu())
+            res["pred"] = torch.cat(preds, dim=1)
+            grads = {k: (torch.cat(gembs, dim=0) if k == "embedding_h.weight" else None if p.grad is None else p.grad.cpu())
+                     for k, p in net.named_parameters()}
+        else:
+            z, net = _golden_net(case)
+            n = z["node_id"].numel()
+            shard = MD.EdgeShard(n, z["src"].to(DEV), z["dst"].to(DEV), z["edge_type"].to(DEV), z["norm"].to(DEV), z["R"], rank, world, DEV)
+            sn = MD.ShardedSupernet(net, shard, z["node_id"])
+            ent, rel = sn.forward()
+            lo = MD.node_ranges(len(z["data"]), world)
+            loss = sn.loss(ent, rel, z["data"][lo[rank]:lo[rank + 1]].to(DEV), z["labels"][lo[rank]:lo[rank + 1]].to(DEV), len(z["data"]))
+            loss.backward()
+            MD.all_reduce_gradients(list(net.parameters()) + net.arch_parameters()[:4])
+            res["ent"] = ent.detach().cpu()
+            grads = {k: None if p.grad is None else p.grad.cpu() for k, p in net.named_parameters()}
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        torch.cuda.synchronize()
+        if rank == 0:
+            res.update(loss=total.cpu(), grads=grads, edges=int(shard.num_edges()))
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["supernet_d200_sampled", "fixednet_d64"])
+def test_four_ranks_on_the_hip_kernels_match_reference(tmp_path, case):
+    import os
+    import time
+    import torch.multiprocessing as mp
+    from conftest import assert_param_grad
+    world, out = 4, str(tmp_path / "res.pt")
+    port = 29500 + (os.getpid() % 2000) + 40
+    ctx = mp.start_processes(_hip_rank, args=(world, port, case, out), nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + 420
+    try:
+        while not ctx.join(timeout=5):
+            assert time.time() < deadline, "a rank did not finish"
+    finally:
+        for p in ctx.processes:                            # exactly the processes started here
+            if p.is_alive():
+                p.kill()
+    res = torch.load(out)
+    z = load_golden(case)
+    what = f"{case} on 4 ranks (HIP kernels, gloo transport)"
+    if case.startswith("fixednet"):
+        torch.testing.assert_close(res["pred"], z["pred"], rtol=1e-4, atol=5e-5)
+    else:
+        torch.testing.assert_close(res["ent"], z["ent"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(res["loss"], z["loss"], rtol=1e-4, atol=1e-6)
+    for k, g in res["grads"].items():
+        assert_param_grad(z, k, g, 2e-3 if not case.startswith("fixednet") else 5e-4, 5e-6, what)
