@@ -180,8 +180,15 @@ class Step:
         S.xavier_init_(self.model)
         self.model.train()
         self.params, self.arch = list(self.model.parameters()), list(self.model.arch_parameters())
-        self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         self.clip = 5.0
+        # clip_grad_norm_ + SGD(momentum) (reference search/mr_lp_search.py:118-119,243-245) as one library call: mr_gnas_amd/optim.py;
+        # MRG_TORCH_OPTIM=1 restores torch's pair (~30 multi_tensor_apply launches)
+        self.fused_opt = os.environ.get("MRG_TORCH_OPTIM", "0") != "1"
+        if self.fused_opt:
+            from mr_gnas_amd.optim import ClippedSGD
+            self.opt = ClippedSGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0, max_norm=self.clip)
+        else:
+            self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         self.last_loss = None
         self._args = args
         self.sample_size = 0
@@ -222,7 +229,8 @@ class Step:
         ent, rel = self.model(self.g, self.node_id, self.src_in, self.edge_type)
         loss = self.model.get_loss(self.g, ent, rel, self.samples, self.labels)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.params, self.clip)          # the list is built once: walking the module tree costs ~1 ms per step
+        if not self.fused_opt:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)      # the list is built once: walking the module tree costs ~1 ms per step
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         for a in self.arch:

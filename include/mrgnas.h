@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 13   /* 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 14   /* 14: mrg_clip_sgd_step, mrg_optim_chunk (clip_grad_norm_ + SGD with momentum over every parameter tensor in three launches); 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -267,6 +267,21 @@ int64_t mrg_mix_workspace_bytes(int K, int D);
  * so no other entry point needs the counts.  NULL counts switch a slot off.  Process-wide; the pointers are read by the kernels at
  * run time (a captured launch re-reads them on every replay). */
 int mrg_set_dynamic_rows(int64_t cap_m, const int32_t *count_m, int64_t cap_n, const int32_t *count_n);
+
+/* ---- the step's tail: gradient clipping + SGD -------------------------------------------
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.SGD(momentum, weight_decay, dampening 0, no Nesterov).step()
+ * (reference search/mr_lp_search.py:118-119,243-245) over ALL parameter tensors in three launches: chunked sum of squares (double),
+ * one-workgroup ordered total -> norm_coef[0] = total 2-norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0),
+ * then per element g = coef * grad + weight_decay * p; buf = momentum * buf + g; p -= lr * buf.
+ * params / grads / bufs: DEVICE arrays of n_tensors device pointers (float32, contiguous); a null gradient pointer leaves that
+ * tensor (and its momentum buffer) untouched, like torch's skip of parameters without a gradient.  Momentum buffers start at zero
+ * (torch initialises buf = g on the first step: the same value).  The tensors are cut into chunks of mrg_optim_chunk() elements by
+ * the caller: chunk b covers elements [chunk_off[b], chunk_off[b] + chunk_len[b]) of tensor chunk_tensor[b] (device arrays; shapes
+ * never change, so they are built once).  partial: n_chunks doubles of workspace.  Deterministic. */
+int mrg_optim_chunk(void);
+int mrg_clip_sgd_step(void *const *params, const void *const *grads, void *const *bufs, const int32_t *chunk_tensor,
+                      const int64_t *chunk_off, const int32_t *chunk_len, int64_t n_chunks, double *partial, float *norm_coef,
+                      float max_norm, float lr, float momentum, float weight_decay, void *stream);
 /* `gated` (HOST pointer, NULL or k < 0 = none) of the five entry points that read the candidates: candidate k is the gated
  * filter f_dense_op_comp (reference models/operations_lp.py:356-390) and is NOT stored -- y_host[k] holds its gate
  * sigmoid(W [s ; s_in] + b) (mrg_dense_filter_fwd3 with out == NULL) and its value is recomputed wherever it is read as

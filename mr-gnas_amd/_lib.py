@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRG_LIB_PATH") or os.path.join(_HERE, "lib", "libmrgnas_hip.so")     # MRG_LIB_PATH: lab builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrgnas.h")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class MrgnasLibraryError(RuntimeError):
@@ -77,6 +77,8 @@ SIGNATURES = {
     "mrg_gemm_set_wide8": (_I, [_I]),
     "mrg_gemm_set_q": (_I, [_I]),
     "mrg_set_dynamic_rows": (_I, [_L, _P, _L, _P]),
+    "mrg_optim_chunk": (_I, []),
+    "mrg_clip_sgd_step": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P]),
     "mrg_act_grad_transpose": (_I, [_P, _P, _P, _L, _L, _I, _P]),
     "mrg_wgrad_set_variant": (_I, [_I]),
     "mrg_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

@@ -773,6 +773,11 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   const int ny = (p.TN + (p.TM <= 4 ? 16 : 8) - 1) / (p.TM <= 4 ? 16 : 8);
   const int64_t gmax = 256 / ny > 32 ? 256 / ny : 32;
   int64_t G = (tiles + 15) / 16 < gmax ? (tiles + 15) / 16 : gmax;
+  // few rows (a sampled step graph, a rank's node chunk): a workgroup walks its 16-row tiles one barrier at a time (~2 us each), so
+  // one or two workgroups of 16 tiles are a 30 us latency chain on an idle chip -- up to eight workgroups of >= 4 tiles instead
+  // (the extra partial tiles are a few MB for the ordered reduction)
+  const int64_t gsmall = (tiles + 3) / 4 < 8 ? (tiles + 3) / 4 : 8;
+  if (G < gsmall) G = gsmall;
   if (G < 1) G = 1;
   int64_t tpb = (tiles + G - 1) / G;
   if (tpb < 1) tpb = 1;

@@ -740,8 +740,13 @@ class ShardedStep:
         self.labels = torch.from_numpy(labels[lo[rank]:lo[rank + 1]]).to(device)
         self.total_samples = len(samples)
         self.params, self.arch = list(self.model.parameters()), list(self.model.arch_parameters())
-        self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         self.clip, self.group, self.last_loss = 5.0, group, None
+        self.fused_opt = os.environ.get("MRG_TORCH_OPTIM", "0") != "1" and torch.device(device).type == "cuda"
+        if self.fused_opt:                                  # clip + SGD(momentum) in three launches (optim.ClippedSGD)
+            from .optim import ClippedSGD
+            self.opt = ClippedSGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0, max_norm=self.clip)
+        else:
+            self.opt = torch.optim.SGD(self.params, 1e-3, momentum=0.9, weight_decay=0.0)
         torch.manual_seed(args.seed + 1000 + rank)         # dropout masks differ per rank (disjoint rows)
 
     def __call__(self):
@@ -749,7 +754,8 @@ class ShardedStep:
         loss = self.net.loss(ent, rel, self.samples, self.labels, self.total_samples)
         loss.backward()
         all_reduce_gradients(self.params + self.arch[:4], self.group)
-        torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        if not self.fused_opt:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         for a in self.arch:

@@ -1104,3 +1104,36 @@ def test_gate_only_candidate_is_bit_exact_with_the_stored_one(N, E, R, D, tied):
     finally:
         set_call(real_call)
         K.switches.GATED_RECOMPUTE, K.switches.ROW_FACTOR, K.switches.FOLD_ROW_SCALE, K.switches.FOLD_IDENTITY = True, True, True, True
+
+
+@pytest.mark.parametrize("max_norm,wd", [(5.0, 0.0), (0.05, 0.0), (0.0, 0.0), (1.0, 3e-4)])
+def test_clipped_sgd_equals_torch_clip_grad_norm_and_sgd(max_norm, wd):
+    """optim.ClippedSGD (mrg_clip_sgd_step: three launches) against torch.nn.utils.clip_grad_norm_ + torch.optim.SGD(momentum)
+    (reference search/mr_lp_search.py:118-119,243-245) over four steps: ragged tensor sizes around the chunk size, a parameter that
+    never receives a gradient, one that misses it in one step, clipping active / inactive / off, weight decay."""
+    from mr_gnas_amd.optim import ClippedSGD
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(200, 400), (200,), (1,), (4096,), (4097,), (3, 5, 7), (14541, 100), (475, 200), (8191,)]
+    mine = [torch.randn(*s, device=DEV, generator=gen).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    opt = ClippedSGD(mine, 1e-2, momentum=0.9, weight_decay=wd, max_norm=max_norm)
+    topt = torch.optim.SGD(ref, 1e-2, momentum=0.9, weight_decay=wd)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i == 2 or (i == 4 and step == 1):
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(a.shape, device=DEV, generator=gen) * (0.01 if step == 3 else 1.0)
+            a.grad, b.grad = g.clone(), g.clone()
+        if max_norm > 0:
+            tn = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        else:
+            tn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in ref if p.grad is not None]))
+        topt.step()
+        nc = opt.step()
+        assert abs(float(nc[0]) - float(tn)) <= 1e-5 * float(tn)
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            close(a.detach(), b.detach().cpu(), f"step {step} parameter {i}", rtol=2e-6, atol=2e-7, rms_rtol=2e-6)
+    assert torch.equal(mine[2], ref[2])                      # never had a gradient: untouched, bit for bit
+    with pytest.raises(Exception):
+        ClippedSGD([torch.zeros(3)], 0.1)

@@ -23,7 +23,7 @@ O=gpurun_out/$TAG; mkdir -p "$O"
 GREP=""
 while [ $# -gt 0 ]; do
   case "$1" in
-    --tests) shift; timeout -k 10 ${LAB_TEST_TIMEOUT:-900} python -m pytest $1 -p no:cacheprovider > "$O/tests.log" 2>&1; rc=$?; tail -4 "$O/tests.log"; [ $rc -eq 0 ] || exit $rc; shift;;
+    --tests) shift; timeout -k 10 ${LAB_TEST_TIMEOUT:-900} bash -c "python -m pytest $1 -p no:cacheprovider" > "$O/tests.log" 2>&1; rc=$?; tail -4 "$O/tests.log"; [ $rc -eq 0 ] || exit $rc; shift;;
     --grep) shift; GREP=$1; shift;;
     *) break;;
   esac
@@ -39,7 +39,8 @@ for spec in "$@"; do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 c = d.get("config", {})
-print(f"   {d['ms_per_step']:.3f} ms/step  {d['value']:.4f} {d['unit']}  launch={c.get('launch')}  loss={d.get('loss')}"
+val = "value=null (timing only)" if d["value"] is None else f"{d['value']:.4f} {d['unit']}"
+print(f"   {d['ms_per_step']:.3f} ms/step  {val}  launch={c.get('launch')}  loss={d.get('loss')}"
       + (f"  roofline.frac={d['roofline']['frac']:.3f}" if d.get("roofline") else "")
       + "".join(f"  {k}={v.get('ms_per_step')}" for k, v in d.items() if k.startswith("caller_") and isinstance(v, dict)))
 PY
