@@ -434,7 +434,7 @@ def load_traffic(kernel):
 
 def traffic_source(kernel):
     """Which committed counter pass `load_traffic(kernel)` read (the PMC passes need rocprofv3 around the process: they are
-    collected by tools/profile_r3.sh, not inside this run)."""
+    collected by tools/lab/profile.sh TAG traffic, not inside this run)."""
     import glob
     src = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
