@@ -659,6 +659,11 @@ class ShardedFixedNet:
         """One node of the fixed cell (supernet.OpModule: op -> BN -> ReLU, 'pre_mult' bare) on this rank's rows."""
         name = mod.op_name
         N = self.s.number_of_nodes()
+        if isinstance(h, K.LazyRows):                        # the zero node on un-materialised gathers (supernet.OpModule.forward)
+            if name != "pre_mult" and K.switches.CELL_ZERO_FUSED and isinstance(mod.op, OPS._PreOp):
+                one = mod._one if mod._one.device == h.device else mod._one.to(h.device)
+                return K.cell_zero_mixed([mod.op.kind], h, h_in, [mod.batchnorm_h], one, self._stat_group(), self.rows_total)
+            h, h_in = h.materialize(), h_in.materialize()
         if name in OPS.MIDDLE_OPS:
             y, total = self._aggregate(mod.op, name, h), N
         else:
@@ -681,7 +686,10 @@ class ShardedFixedNet:
         ent = _AllGatherRows.apply(own, self._info, self.group)
         rel_emb = torch.mm(m.rel_wt, m.embedding_e.weight)
         for ci, cell in enumerate(m.cells):
-            x, hr = self.k.gather(ent, self.p_ent), self.k.gather(rel_emb, self.p_rel)
+            if ent.is_cuda and self.k is K:
+                x, hr = K.LazyRows(ent, self.p_ent), K.LazyRows(rel_emb, self.p_rel)
+            else:
+                x, hr = self.k.gather(ent, self.p_ent), self.k.gather(rel_emb, self.p_rel)
             own = cell(s, x, hr, apply=self._apply, finish=lambda h, c=cell: self._bn_relu(h, c.batchnorm_h, N, c._one))
             own = F.dropout(own, m._dropout, training=m.training)
             if ci + 1 < len(m.cells):

@@ -316,6 +316,16 @@ class OpModule(nn.Module):
         self.register_buffer("_one", torch.ones(1), persistent=False)      # the one-branch epilogue's weight (not in state_dict; moves with .to())
 
     def forward(self, g, h, h_in):
+        if isinstance(h, K.LazyRows):
+            # the cell's zero node on un-materialised gathers (FixedNetwork._forward): pre_sub / pre_add -> BN -> ReLU recomputed from
+            # the two tables (functional.cell_zero_mixed with one branch of weight 1): no [M, D] gather, compose or BatchNorm tensor
+            if (self.op_name != 'pre_mult' and K.switches.CELL_ZERO_FUSED and isinstance(h_in, K.LazyRows)
+                    and isinstance(self.op, OPS._PreOp) and not (self.op._forward_hooks or self.op._forward_pre_hooks)):
+                one = self._one if self._one.device == h.device else self._one.to(h.device)
+                return K.cell_zero_mixed([self.op.kind], h, h_in, [self.batchnorm_h], one)
+            h = h.materialize()
+        if isinstance(h_in, K.LazyRows):
+            h_in = h_in.materialize()
         h = _cell_lp._run(self.op, g, h, h_in)             # the operator's value now (module call when it carries hooks)
         if self.op_name == 'pre_mult':
             return h
@@ -364,7 +374,7 @@ class FixedCell(nn.Module):
         apply = apply or (lambda mod, h, h_in: mod(g, h, h_in))
         # a state with several readers hands out aliases (functional.Fan): its gradient is ONE K-way sum of the readers' gradients
         # instead of autograd's chain of pairwise adds (K - 1 launches of three [rows, D] passes each: 12.8 ms of the C5 step)
-        fan = lambda x, i: K.Fan(x, caps[i]) if (x.is_cuda and caps[i] > 1) else None
+        fan = lambda x, i: K.Fan(x, caps[i]) if (torch.is_tensor(x) and x.is_cuda and caps[i] > 1) else None
         take = lambda i: fans[i].take() if fans[i] is not None else states[i]
         states = [src_emb]
         fans = [fan(src_emb, 0)]
@@ -418,7 +428,10 @@ class FixedNetwork(nn.Module):
         rel_emb = torch.mm(self.rel_wt, self.embedding_e.weight)
         p_ent, p_rel = self._plans(g)
         for cell in self.cells:
-            ent = cell(g, K.gather(ent, p_ent), K.gather(rel_emb, p_rel))
+            if ent.is_cuda:              # the gathers stay un-materialised: only the cell's zero node reads them (FixedCell._caps: caps[0] == 1)
+                ent = cell(g, K.LazyRows(ent, p_ent), K.LazyRows(rel_emb, p_rel))
+            else:
+                ent = cell(g, K.gather(ent, p_ent), K.gather(rel_emb, p_rel))
             ent = F.dropout(ent, self._dropout, training=self.training)
             rel_emb = torch.matmul(rel_emb, self.w_rel)
         return self.score_func(ent, ent[subj], rel_emb[rel])
