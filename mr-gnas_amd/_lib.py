@@ -247,18 +247,24 @@ class GatedBranch(ctypes.Structure):
     """include/mrgnas.h: mrg_gated_branch."""
     _fields_ = [("k", ctypes.c_int32), ("s", ctypes.c_void_p), ("rowscale", ctypes.c_void_p),
                 ("row_k", ctypes.c_int32), ("row_f", ctypes.c_void_p), ("row_h", ctypes.c_void_p), ("row_uvc", ctypes.c_void_p),
-                ("row_ld", ctypes.c_int32), ("b0", ctypes.c_int64), ("b1", ctypes.c_int64), ("row_dq", ctypes.c_void_p)]
+                ("row_ld", ctypes.c_int32), ("b0", ctypes.c_int64), ("b1", ctypes.c_int64), ("row_dq", ctypes.c_void_p),
+                ("act", ctypes.c_int32)]
 
 
-def gated_branch(spec, row_dq=None):
+ACTS = {"relu": 0, "tanh": 1}
+
+
+def gated_branch(spec, row_dq=None, act=0):
     """HOST mrg_gated_branch for spec = dict(k, s, c) and / or dict(row_k, s, row_f, row_h, row_uvc, row_ld, b0, b1) merged, or None.
     row_dq: the [rows] output of mrg_mix_bwd_apply.  Returns the by-reference argument (which keeps the structure alive for the call)."""
     if spec is None:
-        return None
+        if not act:
+            return None
+        return ctypes.byref(GatedBranch(-1, None, None, -1, None, None, None, 0, 0, 0, None, int(act)))   # the activation alone
     dp = lambda t: None if t is None else t.data_ptr()
     g = GatedBranch(int(spec.get("k", -1)), dp(spec["s"]), dp(spec.get("c")), int(spec.get("row_k", -1)), dp(spec.get("row_f")),
                     dp(spec.get("row_h")), dp(spec.get("row_uvc")), int(spec.get("row_ld", 0)), int(spec.get("b0", 0)), int(spec.get("b1", 0)),
-                    dp(row_dq))
+                    dp(row_dq), int(act))
     return ctypes.byref(g)
 
 

@@ -43,7 +43,10 @@ struct GatedPack { int k; const float* s; const float* c;
                    const float* rh; const float* uvc; int uld; int64_t b0, b1; float* rdq;
                    // round 5, "static step graphs" (mrg_set_dynamic_rows): the number of VALID rows lives in device memory; rows at
                    // and beyond it are capacity padding -- left out of every statistic, written as zeros by the passes that write
-                   const int32_t* vrows; };
+                   const int32_t* vrows;
+                   // the activation behind the BatchNorm: 0 = ReLU (every MixedOp of the search space), 1 = tanh (CompGraphConv's tail,
+                   // reference models/compgcn.py:100-111).  Wave-uniform: a scalar branch around the inner statement.
+                   int act; };
 
 // rows that count: min(rows, *vrows) when the launch's row count is a registered capacity, else rows
 __device__ __forceinline__ int64_t valid_rows(const int32_t* vrows, int64_t rows) {
@@ -332,10 +335,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
               for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
             }
             Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
+            if (gp.act == 0) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-              float z = v[j] * sc[j] + sh[j];
-              acc[j] += wk[k] * (z > 0.f ? z : 0.f);
+              for (int j = 0; j < VEC; ++j) {
+                float z = v[j] * sc[j] + sh[j];
+                acc[j] += wk[k] * (z > 0.f ? z : 0.f);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) acc[j] += wk[k] * tanhf(v[j] * sc[j] + sh[j]);
             }
           }
         }
@@ -404,8 +412,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
             for (int j = 0; j < VEC; ++j) {
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
-              float rl = z > 0.f ? z : 0.f;
-              float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              float rl, gr;
+              if (gp.act == 0) { rl = z > 0.f ? z : 0.f; gr = z > 0.f ? wk[k] * gv[j] : 0.f; }
+              else { rl = tanhf(z); gr = wk[k] * gv[j] * (1.f - rl * rl); }
               a0[k][q][j] += gr;
               a1[k][q][j] += gr * xh;
               a2[k][q][j] += gv[j] * rl;
@@ -559,7 +568,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
             for (int j = 0; j < VEC; ++j) {
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
-              float gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              float gr;
+              if (gp.act == 0) gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              else { const float th = tanhf(z); gr = wk[k] * gv[j] * (1.f - th * th); }
               ov[k][j] = (gr - c4[j] - xh * c5[j]) * c0[j] * live;
             }
           }
@@ -969,6 +980,8 @@ static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, in
   *gp = GatedPack{};
   gp->k = -1; gp->pair_k = -1; gp->rk = -1;
   gp->vrows = rows >= 0 ? dyn_rows_for(rows) : nullptr;
+  if (gb && gb->act != 0 && gb->act != 1) return MRG_E_ENUM;
+  gp->act = gb ? gb->act : 0;
   if (!gb || (gb->k < 0 && gb->row_k < 0)) return MRG_OK;
   if (gb->k >= K || gb->row_k >= K || (gb->k >= 0 && gb->k == gb->row_k)) return MRG_E_SHAPE;
   if (!gb->s) return MRG_E_NULLPTR;

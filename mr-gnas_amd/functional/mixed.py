@@ -16,8 +16,9 @@ class _MixCfg:
     """Non-tensor arguments of the epilogue: the BatchNorm modules (running statistics are
     updated in place like torch does), which branches are all-zero, sharding info."""
 
-    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None, identity=None, gated=None):
+    def __init__(self, bns, present, group=None, total_rows=None, has_addend=False, rowscale=None, identity=None, gated=None, act=0):
         self.bns, self.present, self.group, self.total_rows, self.has_addend = bns, present, group, total_rows, has_addend
+        self.act = act                 # 0 ReLU, 1 tanh behind the BatchNorm (_lib.ACTS)
         # (k, s, c [rows]): candidate k arrives as its GATE and is recomputed as gate * s * c[r] wherever the kernels read it
         # (include/mrgnas.h: mrg_gated_branch), or None
         self.gated = gated
@@ -56,7 +57,7 @@ class _MixedEpilogue(torch.autograd.Function):
         total = float(cfg.total_rows if cfg.total_rows is not None else rows)
         coef = torch.empty(K_, 4, D, dtype=torch.float32, device=dev)
         ypa = ptr_array(ys)
-        gb = _lib.gated_branch(cfg.gated)
+        gb = _lib.gated_branch(cfg.gated, act=cfg.act)
         # [rows, D] tensors a pass reads: the stored candidates, the gate of the recomputed one, and s once for every candidate that is a function of it
         nz_rd = len({y.data_ptr() for y in ys if y is not None} | ({cfg.gated["s"].data_ptr()} if cfg.gated is not None else set()))
         bn0 = cfg.bns[0]
@@ -115,7 +116,7 @@ class _MixedEpilogue(torch.autograd.Function):
         ys = _row_candidate_as_s(cfg, [next(it) if p else None for p in cfg.present])
         rows, D = g.shape
         ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", K_, D), g)
-        call("mrg_mix_bwd_reduce", (ptr(g), ptr_array(ys), K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, _lib.gated_branch(cfg.gated), stream_of(g)),
+        call("mrg_mix_bwd_reduce", (ptr(g), ptr_array(ys), K_, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, _lib.gated_branch(cfg.gated, act=cfg.act), stream_of(g)),
              nbytes=4 * D * rows * (ctx.nz_rd + 1))
 
     @staticmethod
@@ -130,7 +131,7 @@ class _MixedEpilogue(torch.autograd.Function):
         rows, D = g.shape
         dev, st = g.device, stream_of(g)
         ypa = ptr_array(ys)
-        gb = _lib.gated_branch(cfg.gated)
+        gb = _lib.gated_branch(cfg.gated, act=cfg.act)
         shared = None
         if cfg.group is not None and ctx.training and cfg.chain is not None:
             shared = cfg.chain[0].reduced_gradient_sums(cfg.chain[1], g, _MixedEpilogue._launch_bwd_reduce)
@@ -175,7 +176,7 @@ class _MixedEpilogue(torch.autograd.Function):
             rlink = cfg.gated["row_link"]
             if rlink is not None:
                 rlink.row_written = row_dq.data_ptr()     # the factor's node checks that THIS buffer reaches it (one reader)
-                gb = _lib.gated_branch(dict(cfg.gated, row_h=rlink.row_h, row_uvc=rlink.row_uvc, row_ld=rlink.row_uvc.shape[1]), row_dq)
+                gb = _lib.gated_branch(dict(cfg.gated, row_h=rlink.row_h, row_uvc=rlink.row_uvc, row_ld=rlink.row_uvc.shape[1]), row_dq, act=cfg.act)
         n_out = sum(t is not None and t.dim() == 2 for t in gys_nz)
         if rs is not None and any(r is not None for r in rs):
             import ctypes
@@ -217,11 +218,12 @@ class _MixedEpilogue(torch.autograd.Function):
         return (None, dw, *gys_nz, *dgam, *dbet) + ((g,) if cfg.has_addend else ())       # d out / d addend = identity
 
 
-def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_row_scales=False, identity=None):
+def mixed_epilogue(ys, bns, w, group=None, total_rows=None, addend=None, fold_row_scales=False, identity=None, act="relu"):
     """addend + sum_k w[k] * relu(bn_k(ys[k]))  (reference models/cell_lp.py:25-33).  ys[k] is None for an
     all-zero operator output (f_zero); bns are the nn.BatchNorm1d modules (affine); addend: the output of the MixedOp this
-    one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel."""
-    return mixed_epilogue_prepare(ys, bns, group, total_rows, fold_row_scales, identity)(w, addend)
+    one is summed with (the sum of the MixedOps feeding a state, :104-113), accumulated inside the combine kernel.
+    act: "relu" (the MixedOp) or "tanh" (CompGraphConv's BatchNorm -> tanh tail, reference models/compgcn.py:100-111)."""
+    return mixed_epilogue_prepare(ys, bns, group, total_rows, fold_row_scales, identity, act)(w, addend)
 
 
 class PreparedEpilogue:
@@ -280,7 +282,7 @@ class StatChain:
             rows = y0.shape[0]
             ws = _ws(_ws_bytes("mrg_mix_workspace_bytes", ks[j], D), y0)
             nz_rd = len({y.data_ptr() for y in ys if y is not None} | ({m.cfg.gated["s"].data_ptr()} if m.cfg.gated is not None else set()))
-            call("mrg_mix_colstats", (ptr_array(ys), ks[j], rows, D, ptr(sums[off:off + ks[j]]), ptr(ws), _lib.gated_branch(m.cfg.gated), stream_of(y0)),
+            call("mrg_mix_colstats", (ptr_array(ys), ks[j], rows, D, ptr(sums[off:off + ks[j]]), ptr(ws), _lib.gated_branch(m.cfg.gated, act=m.cfg.act), stream_of(y0)),
                  nbytes=4 * D * rows * nz_rd)
             off += ks[j]
         _all_reduce_sum(sums, group)
@@ -338,7 +340,7 @@ class StatChain:
         return self.bwd[1][j], self.bwd[2][j]
 
 
-def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales=False, identity=None):
+def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales=False, identity=None, act="relu"):
     """mixed_epilogue without running it: returns a PreparedEpilogue.  ys[k]: None (f_zero), a [rows, D] tensor (a stored
     candidate), or a Candidate from an operator's for_epilogue path (stored with a foldable first backward pass / gate-only /
     row factor)."""
@@ -383,5 +385,5 @@ def mixed_epilogue_prepare(ys, bns, group=None, total_rows=None, fold_row_scales
             gated.update(row_k=k, row_f=y, b0=rb0, b1=rb1, row_link=c.link if wants_grad else None)
         else:
             ys[k] = c.materialize()
-    cfg = _MixCfg(list(bns), present, group, total_rows, False, rowscale, identity, gated)
+    cfg = _MixCfg(list(bns), present, group, total_rows, False, rowscale, identity, gated, _lib.ACTS[act])
     return PreparedEpilogue(cfg, [y for y in ys if y is not None], list(bns))

@@ -24,3 +24,4 @@ FOLD_ROW_SCALE = os.environ.get("MRG_FOLD_ROW_SCALE", "1") == "1"          # lab
 GROUPED_SEGMENTS = os.environ.get("MRG_GROUPED_SEGMENTS", "1") == "1"    # lab switch: 0 = one launch per direction segment
 DENSE_PAIR = os.environ.get("MRG_DENSE_PAIR", "1") == "1"       # lab switch: 0 = f_dense_comp and f_comp of a MixedOp as two autograd nodes
 GATED_RECOMPUTE = os.environ.get("MRG_GATED_RECOMPUTE", "1") == "1"     # lab switch: 0 = f_dense_comp's output is stored for the epilogue
+COMPGCN_TAIL = os.environ.get("MRG_COMPGCN_TAIL", "1") == "1"     # lab switch: 0 = CompGraphConv's BatchNorm -> tanh tail on torch kernels
