@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 14   /* 14: mrg_clip_sgd_step, mrg_optim_chunk (clip_grad_norm_ + SGD with momentum over every parameter tensor in three launches), mrg_gated_branch.act (tanh behind the BatchNorm: CompGraphConv's tail on the epilogue kernels); 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 14   /* 14: mrg_clip_sgd_step, mrg_optim_chunk (clip_grad_norm_ + SGD with momentum over every parameter tensor in three launches), mrg_gated_branch.act (tanh behind the BatchNorm: CompGraphConv's tail on the epilogue kernels), mrg_gemm_set_small (few-row products on two-tile column blocks); 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -429,6 +429,10 @@ int mrg_gemm_set_wide8(int on);
  * time instead of 16, so the two agree to rounding (both pinned <= 1.5 x the exact-f32 core's error against float64).  Measured:
  * -5 .. -12 % per launch at K = 400, equal at K = 200 (profiles/r5_rowgemm_q.txt).  Process-wide. */
 int mrg_gemm_set_q(int on);
+/* ABI 14.  1 (default): split-core products of at most 4 096 rows (a sampled step graph, a rank's node chunk) run on the wave-
+ * autonomous kernel with two-tile column blocks -- 3.5 x more waves with a 3.5 x shorter instruction chain each; same k-order per
+ * output element, bit-identical results.  0: one kernel for every row count. */
+int mrg_gemm_set_small(int on);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
  * (wgrad_x3_k, rounds 1-2).  Same operands and products in the same order: bit-identical gradients for any shape. */

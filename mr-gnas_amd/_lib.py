@@ -77,6 +77,7 @@ SIGNATURES = {
     "mrg_gemm_set_wide8": (_I, [_I]),
     "mrg_gemm_set_q": (_I, [_I]),
     "mrg_set_dynamic_rows": (_I, [_L, _P, _L, _P]),
+    "mrg_gemm_set_small": (_I, [_I]),
     "mrg_optim_chunk": (_I, []),
     "mrg_clip_sgd_step": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P]),
     "mrg_act_grad_transpose": (_I, [_P, _P, _P, _L, _L, _I, _P]),

@@ -115,7 +115,7 @@ extern "C" int mrg_dense_filter_fwd3(int kind, const float* s, const float* s_in
     a.grp.scale[i] = i < 2 ? scale_edge : scale_self;
     a.grp.use_rowscale[i] = (i < 2 && norm) ? 1 : 0;
   }
-  launch_bsplit3_any(kind == 0 ? EPI_GATE : EPI_SCALE, Bs, K, 1, D, K, outs, st);
+  launch_bsplit3_any(kind == 0 ? EPI_GATE : EPI_SCALE, M, Bs, K, 1, D, K, outs, st);
   MRG_LAUNCH_CHECK();
   if (kind == 0) return launch_rowgemm_x3_mode<EPI_GATE>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_SCALE>(a, outs[0], st);

@@ -33,27 +33,43 @@ inline bool x3q_shape(int epi, int N, int K) {
          && K > (gemm_q() == 2 ? 48 : X3Q_MIN_K);
 }
 
+// FEW ROWS (round 5: the sampled search step of graph_batch_size 300, a rank's node chunk).  A 128-row workgroup of rowgemm_x3s_k
+// walks all seven column tiles of its rows: 546 matrix instructions per wave one behind the other, ~20 us however few rows there
+// are, on an otherwise idle chip.  Below X3N_MAX_ROWS the product runs on the wave-autonomous kernel of gemm_x3.hpp with column
+// blocks of TWO tiles (grid.y = 4 for 200 columns): 3.5 x more waves, each with a 3.5 x shorter chain.  Same operands, same order of
+// the k-sum per output element: bit-identical with rowgemm_x3s_k (tests/test_ops_gpu.py::test_few_rows_row_gemm_is_bit_exact), so a
+// grouped launch and its per-range launches may fall on different sides of the bound.  Not for the shapes of rowgemm_x3q_k (another
+// summation order: those keep one kernel for every row count).  mrg_gemm_set_small(0) switches it off.
+constexpr int64_t X3N_MAX_ROWS = 4096;
+constexpr int X3N_NT = 2;
+inline int& gemm_small() { static int m = 1; return m; }
+inline bool x3n_shape(int epi, int64_t rows, int N, int K) {
+  return gemm_mode() == 0 && gemm_small() != 0 && rows > 0 && rows <= X3N_MAX_ROWS && gemm_pick_nt(N) > X3N_NT && N <= 224 && !x3q_shape(epi, N, K);
+}
+
 // bytes of ONE pre-split weight in whichever layout a launch of this shape may use
 inline size_t bsplit_bytes_any(int N, int K) {
   const size_t a = x3_bsplit_bytes(N, K, gemm_pick_nt(N));
   const size_t q = (N > 128 && N <= X3Q_NT * 16) ? x3q_bsplit_bytes(K) : 0;
-  return a > q ? a : q;
+  const size_t n = (gemm_pick_nt(N) > X3N_NT && N <= 224) ? x3_bsplit_bytes(N, K, X3N_NT) : 0;
+  const size_t m = a > q ? a : q;
+  return m > n ? m : n;
 }
 
-// the weight split of a launch with epilogue `epi`: B(n, k) = B[n * sn + k * sk]
-inline void launch_bsplit_any(int epi, const float* B, int64_t sn, int64_t sk, int N, int K, void* Bp, hipStream_t st) {
+// the weight split of a launch of `rows` rows with epilogue `epi`: B(n, k) = B[n * sn + k * sk]
+inline void launch_bsplit_any(int epi, int64_t rows, const float* B, int64_t sn, int64_t sk, int N, int K, void* Bp, hipStream_t st) {
   if (x3q_shape(epi, N, K)) {
     const float* Bs[1] = {B};
     void* outs[1] = {Bp};
     launch_bsplitq3(Bs, sn, sk, N, K, outs, 1, st);
   } else {
-    launch_bsplit(B, sn, sk, N, K, gemm_pick_nt(N), Bp, st);
+    launch_bsplit(B, sn, sk, N, K, x3n_shape(epi, rows, N, K) ? X3N_NT : gemm_pick_nt(N), Bp, st);
   }
 }
-inline void launch_bsplit3_any(int epi, const float* const* B, int64_t sn, int64_t sk, int N, int K, void* const* out, hipStream_t st,
+inline void launch_bsplit3_any(int epi, int64_t rows, const float* const* B, int64_t sn, int64_t sk, int N, int K, void* const* out, hipStream_t st,
                                const float* const* B2 = nullptr, int ksplit = 0) {
   if (x3q_shape(epi, N, K)) launch_bsplitq3(B, sn, sk, N, K, out, 3, st, B2, ksplit);
-  else launch_bsplit3(B, sn, sk, N, K, gemm_pick_nt(N), out, st, B2, ksplit);
+  else launch_bsplit3(B, sn, sk, N, K, x3n_shape(epi, rows, N, K) ? X3N_NT : gemm_pick_nt(N), out, st, B2, ksplit);
 }
 
 // the split-core row GEMM of the current mode for launches that prepared their own weight split (grouped launches, fused aggregators)
@@ -63,6 +79,10 @@ inline int launch_rowgemm_x3_mode(GemmArgs a, const void* Bp, hipStream_t st) {
   if (x3q_shape(EPI, a.N, a.K1 + a.K2)) {
     if (!x3q_eligible(a)) return MRG_E_SHAPE;              // the split was prepared in this kernel's layout: no other kernel can read it
     return launch_rowgemm_x3q<EPI>(a, Bp, st);
+  }
+  if (x3n_shape(EPI, a.rows, a.N, a.K1 + a.K2)) {
+    if (!x3_eligible(a)) return MRG_E_SHAPE;               // the split was prepared with two-tile column blocks
+    return launch_rowgemm_x3<EPI>(a, Bp, st, X3N_NT);
   }
   if (gemm_mode() != 2 && x3s_eligible(a)) {
     // eight column tiles (D = 256) as ONE block where the epilogue fits (gemm_x3s8.hpp): the activation operand is read once
@@ -88,7 +108,7 @@ inline int launch_gemm(GemmArgs a, int64_t b_sn, int64_t b_sk, void* ws, hipStre
   if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
   const int K = a.K1 + a.K2;
   if (ws && gemm_mode() != 1 && x3_eligible(a)) {
-    launch_bsplit_any(EPI, a.B, b_sn, b_sk, a.N, K, ws, st);
+    launch_bsplit_any(EPI, a.rows, a.B, b_sn, b_sk, a.N, K, ws, st);
     return launch_rowgemm_x3_mode<EPI>(a, ws, st);
   }
   if (b_sk != 1) {                                   // present B^T row-major to the f32 core

@@ -393,10 +393,10 @@ inline bool x3_eligible(const GemmArgs& a) {
 
 // Bp: the split of B prepared by launch_bsplit(..., nt = gemm_pick_nt(a.N), ...)
 template <int EPI>
-inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st) {
+inline int launch_rowgemm_x3(GemmArgs a, const void* Bp, hipStream_t st, int nt_force = 0) {
   if (a.rows <= 0) return MRG_OK;
   if (!a.A2 || a.K2 == 0) { a.A2 = a.A1; a.K2 = 0; }
-  const int nt = gemm_pick_nt(a.N);
+  const int nt = nt_force > 0 ? nt_force : gemm_pick_nt(a.N);    // nt_force: narrower column blocks for few rows (gemm_dispatch.hpp: x3n_shape)
   const int ntile = x3_tiles(a.N, nt);
   const int mt = a.rows > 128 * 512 ? 2 : 1;            // short operands: more, smaller workgroups
   const int gbm = 32 * mt * (X3_THREADS / 64);

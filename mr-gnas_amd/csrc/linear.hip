@@ -923,7 +923,7 @@ extern "C" int mrg_linear_relu_segmax_fwd(const float* X, const float* W, const 
     a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
     a.row_index = eid; a.row_seg = dst; a.seg_out = keys;
     if (!x3_eligible(a)) return MRG_E_SHAPE;
-    launch_bsplit_any(EPI_SEGMAX, W, K, 1, Nout, K, bsplit, st);
+    launch_bsplit_any(EPI_SEGMAX, E, W, K, 1, Nout, K, bsplit, st);
     const int rc = launch_rowgemm_x3_mode<EPI_SEGMAX>(a, bsplit, st);
     if (rc != MRG_OK) return rc;
   }
@@ -949,7 +949,7 @@ extern "C" int mrg_linear_relu_segsum_fwd(const float* X, const float* W, const 
   a.A1 = X; a.K1 = K; a.B = W; a.bias = bias; a.N = Nout; a.rows = E; a.act = MRG_ACT_RELU;
   a.row_index = eid; a.row_seg = dst; a.seg_part = part; a.relu_bits = relu_bits; a.bits_ld = (Nout + 31) / 32;
   if (!x3_eligible(a)) return MRG_E_SHAPE;
-  launch_bsplit_any(EPI_SEGSUM, W, K, 1, Nout, K, ws, st);
+  launch_bsplit_any(EPI_SEGSUM, E, W, K, 1, Nout, K, ws, st);
   return launch_rowgemm_x3_mode<EPI_SEGSUM>(a, ws, st);
 }
 
@@ -973,6 +973,12 @@ extern "C" int mrg_wgrad_set_variant(int variant) {
 extern "C" int mrg_gemm_set_wide8(int on) {
   if (on < 0 || on > 2) return MRG_E_ENUM;          // 2 (lab): seven-tile plain launches on the ring-of-two kernel as well
   gemm_wide8() = on;
+  return MRG_OK;
+}
+
+extern "C" int mrg_gemm_set_small(int on) {
+  if (on != 0 && on != 1) return MRG_E_ENUM;
+  gemm_small() = on;
   return MRG_OK;
 }
 
@@ -1059,7 +1065,7 @@ extern "C" int mrg_linear_bwd_input3(const float* gY, const float* const* W_host
     a.grp.lo[i] = lo[i]; a.grp.hi[i] = live ? hi[i] : lo[i];
     a.grp.scale[i] = 1.0f;
   }
-  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, Bs, 1, ldw, K, Nout, outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
+  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, M, Bs, 1, ldw, K, Nout, outs, st);         // B(n = k_in, k = n_out) = W[n_out * ldw + k_in]
   MRG_LAUNCH_CHECK();
   if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);
@@ -1102,7 +1108,7 @@ extern "C" int mrg_linear_bwd_input3_pair(const float* gY1, const float* gY2, co
     a.grp.scale[i] = 1.0f;
   }
   // B(n = k_in, k) = k < Nout ? W1[k * ldw + k_in] : W2[(k - Nout) * ldw + k_in]
-  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, Bs, 1, ldw, K, 2 * Nout, outs, st, Bs2, Nout);
+  launch_bsplit3_any(accumulate ? EPI_ACCUM : EPI_BIAS_ACT, M, Bs, 1, ldw, K, 2 * Nout, outs, st, Bs2, Nout);
   MRG_LAUNCH_CHECK();
   if (accumulate) return launch_rowgemm_x3_mode<EPI_ACCUM>(a, outs[0], st);
   return launch_rowgemm_x3_mode<EPI_BIAS_ACT>(a, outs[0], st);

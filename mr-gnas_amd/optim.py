@@ -13,6 +13,8 @@ from ._lib import call, ptr, stream_of
 
 
 class ClippedSGD:
+    CAPTURE_TABLES = 4          # step() calls that may be captured into HIP graphs over the optimiser's life (one pinned table each)
+
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, max_norm=0.0):
         self.params = [p for p in params]
         if not self.params:
@@ -50,6 +52,7 @@ class ClippedSGD:
         self._g_event = [None, None]
         self._turn = 0
         self._captured = []
+        self._spare = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory() for _ in range(self.CAPTURE_TABLES)]
         self._g_ptrs = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self._partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float64, device=dev)
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)                # [total gradient norm, clip coefficient] of the last step
@@ -70,7 +73,10 @@ class ClippedSGD:
         if torch.cuda.is_current_stream_capturing():
             # the captured copy node reads its host buffer again on every replay: a buffer of its own, never rewritten (the gradients
             # of a captured step live at fixed addresses of the graph's memory pool)
-            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            if not self._spare:                              # (pinning allocates: not allowed while a capture is open)
+                raise _lib.MrgnasError("ClippedSGD: more captures than spare pinned pointer tables (ClippedSGD.CAPTURE_TABLES)")
+            host = self._spare.pop()
+            host.numpy()[:] = ptrs
             self._captured.append(host)
             self._g_ptrs.copy_(host, non_blocking=True)
         else:

@@ -1137,3 +1137,84 @@ def test_clipped_sgd_equals_torch_clip_grad_norm_and_sgd(max_norm, wd):
     assert torch.equal(mine[2], ref[2])                      # never had a gradient: untouched, bit for bit
     with pytest.raises(Exception):
         ClippedSGD([torch.zeros(3)], 0.1)
+
+
+@pytest.mark.parametrize("D", [200, 100, 160])
+def test_few_rows_row_gemm_is_bit_exact(D):
+    """Products of at most 4 096 rows run on the wave-autonomous kernel with two-tile column blocks (gemm_dispatch.hpp: x3n_shape,
+    mrg_gemm_set_small): every operator that owns a row GEMM -- plain, fused a_max / a_mean (segmented epilogues, gathered rows),
+    the three-segment dense filters tied and untied, their input and weight gradients -- must give the SAME BITS as with the
+    switch off (one kernel for every row count)."""
+    lib = mr_gnas_amd._lib.load()
+    gen = torch.Generator().manual_seed(D)
+    N, E, R = 300, 1100, 5
+    src, dst = torch.randint(0, N, (E,), generator=gen), torch.randint(0, N, (E,), generator=gen)
+    dst[:200] = 7                                             # a hub
+    et = torch.randint(0, 2 * R, (E,), generator=gen)
+    g = G.RelGraph(N, src.numpy(), dst.numpy(), et.numpy(), (torch.rand(E, generator=gen) + 0.1).numpy().astype(np.float32), device=DEV)
+    a0, b0 = torch.randn(E + N, D, generator=gen), torch.randn(E + N, D, generator=gen)
+    gM, gN = torch.randn(E + N, D, generator=gen).to(DEV), torch.randn(N, D, generator=gen).to(DEV)
+    res = {}
+    try:
+        for small in (1, 0):
+            assert lib.mrg_gemm_set_small(small) == 0
+            torch.manual_seed(1)
+            outs = []
+            for kind, tied in (("f_dense_comp", True), ("f_dense_comp", False), ("f_comp", True), ("a_max", False), ("a_mean", False),
+                               ("f_dense_last", False)):
+                torch.manual_seed(hash(kind) % 1000)
+                op = O.MIXED_OPS[kind]({"feature_dim": D, "drop_aggr": 0.0}).to(DEV)
+                node = kind == "f_dense_last"
+                a = (a0[:N] if node else a0).clone().to(DEV).requires_grad_(True)
+                b = a if tied else (b0[:N] if node else b0).clone().to(DEV).requires_grad_(True)
+                out = op(g, a, b)
+                out.backward(gN if out.shape[0] == N else gM)
+                outs += [out.detach(), a.grad] + [p.grad.clone() for p in op.parameters() if p.grad is not None]
+            x = a0[:900].clone().to(DEV).requires_grad_(True)
+            W = torch.randn(D, D, generator=gen).to(DEV).requires_grad_(True) if small else W
+            y = K.linear(x, W, None, "relu")
+            y.backward(gM[:900])
+            outs += [y.detach(), x.grad, W.grad.clone()]
+            W.grad = None
+            res[small] = outs
+    finally:
+        lib.mrg_gemm_set_small(1)
+    assert len(res[1]) == len(res[0]) and len(res[1]) > 20
+    for i, (p, q) in enumerate(zip(res[1], res[0])):
+        assert torch.equal(p, q), f"tensor {i}: max diff {float((p - q).abs().max()):.3e}"
+
+
+def test_clipped_sgd_replays_from_a_hip_graph():
+    """backward + ClippedSGD.step() captured once and replayed: the gradient pointer table is copied from a pinned buffer of the
+    capture's own (no pinning while a capture is open), the gradients live at fixed addresses of the graph's pool."""
+    from mr_gnas_amd.optim import ClippedSGD
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    W = [torch.randn(64, 200, device=DEV, generator=gen).requires_grad_(True), torch.randn(5000, device=DEV, generator=gen).requires_grad_(True)]
+    ref = [w.detach().clone().requires_grad_(True) for w in W]
+    x = torch.randn(32, 200, device=DEV, generator=gen)
+    opt = ClippedSGD(W, 1e-2, momentum=0.9, max_norm=1.0)
+    topt = torch.optim.SGD(ref, 1e-2, momentum=0.9)
+
+    def step(ws, o, clip):
+        loss = (x @ ws[0].t()).square().mean() + ws[1].square().sum() * 1e-3
+        loss.backward()
+        if clip:
+            torch.nn.utils.clip_grad_norm_(ws, 1.0)
+        o.step()
+        o.zero_grad(set_to_none=True)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(W, opt, False)                                   # warm-up (eager)
+    torch.cuda.current_stream().wait_stream(side)
+    step(ref, topt, True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        step(W, opt, False)
+    for _ in range(3):
+        graph.replay()
+        step(ref, topt, True)
+    torch.cuda.synchronize()
+    for a, b in zip(W, ref):
+        close(a.detach(), b.detach().cpu(), "parameter after 1 eager + 3 replayed steps", rtol=5e-6, atol=1e-6, rms_rtol=5e-6)
