@@ -945,27 +945,40 @@ static const int32_t* dyn_rows_for(int64_t rows) {
   return nullptr;
 }
 // statistics: the flat kernels' bound (512 blocks measured best: profiles/r3_stream_grid.txt)
+// FEW ROWS (round 5: a sampled step graph, a rank's node chunk): a wave walks its rows one dependent memory round trip at a time, so
+// with `trips` rows per wave a launch over 900 rows is ~30 blocks of 8 trips = a 15 us latency chain on an idle chip.  Until there
+// is a block per CU, a block gets ONE row per wave: rows / (rows per trip) blocks, at most 256.
+static int64_t row_blocks(int64_t rows, int lpr, int trips) {
+  const int64_t per_trip = MRG_BLOCK / lpr;
+  int64_t b = (rows + per_trip * trips - 1) / (per_trip * trips);
+  if (b < 256) {
+    const int64_t b1 = (rows + per_trip - 1) / per_trip;
+    b = b1 < 256 ? b1 : 256;
+  }
+  return b < 1 ? 1 : b;
+}
 static int mix_grid(int64_t rows, int lpr) {
-  int g = stream_grid_for(rows, (MRG_BLOCK / lpr) * 8);
-  return g > 1024 ? 1024 : g;                      // partial buffers are sized for 1024 blocks
+  int64_t g = row_blocks(rows, lpr, 8);
+  if (g > stream_blocks()) g = stream_blocks();
+  return (int)(g > 1024 ? 1024 : g);               // partial buffers are sized for 1024 blocks
 }
 // backward reduction / combine: since the row addressing became scalar these kernels hold 4 / 8 workgroups per CU and gain from
 // more blocks than the 512 of the flat kernels (lab: 3.0 -> 2.4 ms and 2.53 -> 2.42 ms per step at 1024)
 static int mix_reduce_grid(int64_t rows, int lpr) {
   static const int cap = lab_env_int("MRG_MIX_REDUCE_BLOCKS", 1024);
-  int64_t b = (rows + (MRG_BLOCK / lpr) * 8 - 1) / ((MRG_BLOCK / lpr) * 8);
+  int64_t b = row_blocks(rows, lpr, 8);
   const int c = cap > 1024 ? 1024 : (cap < 1 ? 1 : cap);              // partial buffers are sized for 1024 blocks
   return (int)(b < 1 ? 1 : (b > c ? c : b));
 }
 static int mix_apply_grid(int64_t rows, int lpr) {
   static const int cap = lab_env_int("MRG_MIX_APPLY_BLOCKS", MRG_MAX_GRID);
-  int64_t b = (rows + (MRG_BLOCK / lpr) * 4 - 1) / ((MRG_BLOCK / lpr) * 4);
+  int64_t b = row_blocks(rows, lpr, 4);
   const int c = cap > 8192 ? 8192 : (cap < 1 ? 1 : cap);
   return (int)(b < 1 ? 1 : (b > c ? c : b));
 }
 static int mix_fwd_grid(int64_t rows, int lpr) {
   static const int cap = lab_env_int("MRG_MIX_FWD_BLOCKS", 1024);
-  int64_t b = (rows + (MRG_BLOCK / lpr) * 4 - 1) / ((MRG_BLOCK / lpr) * 4);
+  int64_t b = row_blocks(rows, lpr, 4);
   const int c = cap > MRG_MAX_GRID ? MRG_MAX_GRID : (cap < 1 ? 1 : cap);
   return (int)(b < 1 ? 1 : (b > c ? c : b));
 }
@@ -1292,8 +1305,7 @@ static int zero_src(ZeroSrc* z, const float* ent, const float* rel, const int32_
 // latency-bound per wave and want MORE blocks than the flat statistics kernels (512): up to 2048, which is what the
 // workspace (mrg_zero_workspace_bytes) is sized for.  Measured at FB15k-237, D = 200: statistics 307 -> see profiles/r3_cell_zero.txt.
 static int zero_grid(int64_t rows, int lpr) {
-  int64_t b = (rows + (MRG_BLOCK / lpr) * 8 - 1) / ((MRG_BLOCK / lpr) * 8);
-  if (b < 1) b = 1;
+  int64_t b = row_blocks(rows, lpr, 8);
   return (int)(b > 2048 ? 2048 : b);
 }
 
