@@ -313,7 +313,8 @@ typedef struct mrg_gated_branch {
   float *row_dq;           /* [rows] device, out */
   /* ABI 14: the activation behind the BatchNorm in mrg_mix_fwd / _bwd_reduce / _bwd_apply: 0 = ReLU (the MixedOp, reference
    * models/cell_lp.py:25-33), 1 = tanh (CompGraphConv's BatchNorm -> tanh tail, reference models/compgcn.py:100-111).  A descriptor
-   * with k < 0 and row_k < 0 carries only this field (s may then be NULL). */
+   * with k < 0 and row_k < 0 carries only this field (s may then be NULL); tanh needs exactly that (no recomputed candidate)
+   * and K <= 5, else MRG_E_SHAPE. */
   int32_t act;
 } mrg_gated_branch;
 int mrg_mix_colstats(const float *const *y_host, int K, int64_t rows, int D, double *sums, void *ws,

@@ -45,7 +45,8 @@ struct GatedPack { int k; const float* s; const float* c;
                    // and beyond it are capacity padding -- left out of every statistic, written as zeros by the passes that write
                    const int32_t* vrows;
                    // the activation behind the BatchNorm: 0 = ReLU (every MixedOp of the search space), 1 = tanh (CompGraphConv's tail,
-                   // reference models/compgcn.py:100-111).  Wave-uniform: a scalar branch around the inner statement.
+                   // reference models/compgcn.py:100-111).  A template parameter of the three kernels that apply it (a run-time branch
+                   // cost mix_bwd_apply_k 14 %); the tanh instances exist for un-gated launches of at most five candidates.
                    int act; };
 
 // rows that count: min(rows, *vrows) when the launch's row count is a registered capacity, else rows
@@ -279,7 +280,7 @@ __global__ void mix_reduce_finalize_fwd_k(const double* __restrict__ ws, int nb,
 // ---- forward combine
 // KB: the candidate slots the kernel is unrolled for (K <= KB): 5 covers every MixedOp of the search space (3, 4 or 5 candidates)
 // with 3/8 fewer registers than the general 8 -- one more wave per SIMD.
-template <int VEC, int LPR, int KMAX, bool GATED, int KB>
+template <int VEC, int LPR, int KMAX, bool GATED, int KB, int ACT = 0>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const float* __restrict__ coef, const float* __restrict__ w,
                                                        float* __restrict__ out, int64_t rows, int D,
                                                        const float* __restrict__ addend, GatedPack gp) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
               for (int j = 0; j < VEC; ++j) v[j] = v[j] * (isg ? gsv[j] : 1.0f) * cm;
             }
             Vec<VEC> sc = Vec<VEC>::load(lds + (k * 2 + 0) * D + c * VEC), sh = Vec<VEC>::load(lds + (k * 2 + 1) * D + c * VEC);
-            if (gp.act == 0) {
+            if constexpr (ACT == 0) {
 #pragma unroll
               for (int j = 0; j < VEC; ++j) {
                 float z = v[j] * sc[j] + sh[j];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_fwd_k(PtrPack ys, int K, const 
 
 // ---- backward reduce: per branch  red[k][0] = sum gr, [1] = sum gr*xhat, [2] = sum g*relu(z)  (gr = w g [z>0])
 // rows outermost: g is read once, every y_k once; per-branch column accumulators live in registers.
-template <int VEC, int LPR, int KMAX, int KB, bool GATED>
+template <int VEC, int LPR, int KMAX, int KB, bool GATED, int ACT = 0>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __restrict__ g, PtrPack ys, int K,
                                                               const float* __restrict__ coef, const float* __restrict__ w,
                                                               float* __restrict__ ws, int64_t rows, int D, GatedPack gp) {
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_reduce_k(const float* __res
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
               float rl, gr;
-              if (gp.act == 0) { rl = z > 0.f ? z : 0.f; gr = z > 0.f ? wk[k] * gv[j] : 0.f; }
+              if constexpr (ACT == 0) { rl = z > 0.f ? z : 0.f; gr = z > 0.f ? wk[k] * gv[j] : 0.f; }
               else { rl = tanhf(z); gr = wk[k] * gv[j] * (1.f - rl * rl); }
               a0[k][q][j] += gr;
               a1[k][q][j] += gr * xh;
@@ -482,7 +483,7 @@ __global__ void mix_finalize_bwd_k(const float* __restrict__ red, int K, double 
 // row, same order as gate_bwd_k) -> gp.rdq[r], the gradient w.r.t. f_r, from which mrg_gate_row_bwd derives the candidate's
 // parameter / s_in gradients; and with dz_r = q_r * h_r (h_r = t_r * gate * (1 - gate), saved by the forward) it ADDS the candidate's
 // whole gradient w.r.t. s, gy * f_r + dz_r * u[c], into the gated candidate's direct term gs_out (gradients w.r.t. the same rows s).
-template <int VEC, int LPR, int KMAX, bool GATED, int KB>
+template <int VEC, int LPR, int KMAX, bool GATED, int KB, int ACT = 0>
 __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __restrict__ g, PtrPack ys, MutPack gys, int K,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
                                                              const float* __restrict__ w, int64_t rows, int D, RowScalePack rsp,
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void mix_bwd_apply_k(const float* __rest
               float z = v[j] * c0[j] + c1[j];
               float xh = v[j] * c2[j] - c3[j];
               float gr;
-              if (gp.act == 0) gr = z > 0.f ? wk[k] * gv[j] : 0.f;
+              if constexpr (ACT == 0) gr = z > 0.f ? wk[k] * gv[j] : 0.f;
               else { const float th = tanhf(z); gr = wk[k] * gv[j] * (1.f - th * th); }
               ov[k][j] = (gr - c4[j] - xh * c5[j]) * c0[j] * live;
             }
@@ -995,6 +996,7 @@ static int gated_pack(const mrg_gated_branch* gb, const float* const* y_host, in
   gp->vrows = rows >= 0 ? dyn_rows_for(rows) : nullptr;
   if (gb && gb->act != 0 && gb->act != 1) return MRG_E_ENUM;
   gp->act = gb ? gb->act : 0;
+  if (gp->act == 1 && (K > 5 || gb->k >= 0 || gb->row_k >= 0)) return MRG_E_SHAPE;    // the tanh instances: un-gated, at most five candidates
   if (!gb || (gb->k < 0 && gb->row_k < 0)) return MRG_OK;
   if (gb->k >= K || gb->row_k >= K || (gb->k >= 0 && gb->k == gb->row_k)) return MRG_E_SHAPE;
   if (!gb->s) return MRG_E_NULLPTR;
@@ -1148,7 +1150,9 @@ extern "C" int mrg_mix_fwd(const float* const* y_host, int K, const float* coef,
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
     const dim3 grid_(mix_fwd_grid(rows, L));                                                               \
-    if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
+    if (gp.act == 1) {                                                                                    \
+      hipLaunchKernelGGL((mix_fwd_k<V, L, KM, false, 5, 1>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
+    } else if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
       if (K <= 5) hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
       else hipLaunchKernelGGL((mix_fwd_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, ys, K, coef, w, out, rows, D, addend, gp); \
     } else {                                                                                              \
@@ -1183,7 +1187,8 @@ extern "C" int mrg_mix_bwd_reduce(const float* g, const float* const* y_host, in
     grid = mix_reduce_grid(rows, L);                                                                             \
     size_t lds = ((size_t)K * 4 * D + (size_t)(MRG_BLOCK / L) * 3 * (L * KM * V)) * sizeof(float);        \
     if (lds > 64 * 1024) return MRG_E_SHAPE;                                                              \
-    if ((gp.k >= 0 || gp.rk >= 0) && K <= 5) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 5, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    if (gp.act == 1) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 5, false, 1>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
+    else if ((gp.k >= 0 || gp.rk >= 0) && K <= 5) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 5, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else if (gp.k >= 0 || gp.rk >= 0) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, true>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else if (K <= 4) hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, 4, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
     else hipLaunchKernelGGL((mix_bwd_reduce_k<V, L, KM, MRG_MIX_MAXK, false>), dim3(grid), dim3(MRG_BLOCK), lds, st, g, ys, K, coef, w, (float*)ws, rows, D, gp); \
@@ -1274,7 +1279,9 @@ extern "C" int mrg_mix_bwd_apply(const float* g, const float* const* y_host, flo
 #define CALL(V, L, KM)                                                                                    \
   do {                                                                                                    \
     const dim3 grid_(mix_apply_grid(rows, L));                                                             \
-    if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
+    if (gp.act == 1) {                                                                                    \
+      hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, false, 5, 1>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
+    } else if (gp.k >= 0 || gp.rk >= 0) {                                                                        \
       if (K <= 5) hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, 5>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
       else hipLaunchKernelGGL((mix_bwd_apply_k<V, L, KM, true, MRG_MIX_MAXK>), grid_, dim3(MRG_BLOCK), lds, st, g, ys, gys, K, coef, coef2, w, rows, D, rsp, gp); \
     } else {                                                                                              \
