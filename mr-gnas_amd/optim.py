@@ -56,7 +56,6 @@ class ClippedSGD:
         self._g_ptrs = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self._partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float64, device=dev)
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)                # [total gradient norm, clip coefficient] of the last step
-        self._held = None
 
     def step(self):
         """Clip (when max_norm > 0) and update.  Gradients are read where autograd left them; a parameter without a gradient, or
@@ -89,10 +88,12 @@ class ClippedSGD:
             self._g_np[k][:] = ptrs
             self._g_ptrs.copy_(self._g_host[k], non_blocking=True)
             self._g_event[k].record()
-        self._held = grads                                   # the gradient tensors stay alive until the launches that read them are enqueued
         call("mrg_clip_sgd_step", (ptr(self._p_ptrs), ptr(self._g_ptrs), ptr(self._b_ptrs), ptr(self._chunk_tensor), ptr(self._chunk_off),
                                    ptr(self._chunk_len), self.n_chunks, ptr(self._partial), ptr(self.norm_coef), self.max_norm, self.lr,
                                    self.momentum, self.weight_decay, stream_of(self._flat)))
+        # (the gradients -- and a converted copy of one -- are still referenced here: the launches that read them are enqueued, and the
+        #  caching allocator hands their memory out again in stream order)
+        torch.autograd.graph.increment_version(self.params)   # the kernels wrote the parameters behind autograd's back: say so
         return self.norm_coef
 
     def zero_grad(self, set_to_none=True):
