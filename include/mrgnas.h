@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRG_ABI_VERSION 14   /* 14: mrg_clip_sgd_step, mrg_optim_chunk (clip_grad_norm_ + SGD with momentum over every parameter tensor in three launches), mrg_gated_branch.act (tanh behind the BatchNorm: CompGraphConv's tail on the epilogue kernels), mrg_gemm_set_small (few-row products on two-tile column blocks); 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
+#define MRG_ABI_VERSION 14   /* 14: mrg_clip_sgd_step, mrg_optim_chunk (clip_grad_norm_ + SGD with momentum over every parameter tensor in three launches), mrg_gated_branch.act (tanh behind the BatchNorm: CompGraphConv's tail on the epilogue kernels), mrg_gemm_set_small (few-row products on two-tile column blocks), mrg_segmax_bwd_input (a_max's input gradient without a dense product); 13: mrg_set_dynamic_rows (device-side row counts: the sampled search step as one replayable HIP graph), mrg_seg_reduce_bwd_ordered (aggregator backward walked in destination order), mrg_gemm_set_q (the 16 x 16 x 32 row GEMM at three workgroups per CU for 129..224 output columns); 12: mrg_act_grad_transpose (the [B, N] scorer's output gradient, activation folded in, as [N, B] rows); 11: mrg_gemm_set_wide8 (eight-tile column block for D = 256); 10: mrg_gemm_set_epilogue(2) (transposed accumulators: a tested comparison point); 9: mrg_gated_branch (the MixedOp epilogue recomputes f_dense_comp's output from its gate and f_sparse_comp's from its row factor), mrg_gate_row_fwd / _bwd, mrg_sum_rows_gather, mrg_wgrad_set_variant, mrg_dense_filter_fwd3 out == NULL; 8: mrg_zero_* (cell-zero MixedOp recomputed from the tables), mrg_linear_bwd_input3_pair, mrg_sample_edge_neighborhood; 7: mrg_gemm_set_epilogue (row-order stores of the split-core row GEMM), mrg_set_stream_blocks, mrg_gemm_set_mode(2); 6: fused a_mean (run-sum epilogue, heads reducer, bit-mask backward), mrg_mix_stats_coef; 5: three-segment dense filter entry points; 4: mrg_linear_relu_segmax_fwd (fused a_max); 3: device graph / plan builders, samplers, [B, N] scorers, ranking; 2: GEMM workspaces, span_gcs ext_scal */
 
 #define MRG_OK            0
 #define MRG_E_NULLPTR    -1   /* a required pointer is NULL */
@@ -185,6 +185,16 @@ int mrg_seg_reduce_bwd(int mode, const float *gout, const int32_t *dst, const in
 int mrg_seg_reduce_bwd_ordered(int mode, const float *gout, const int32_t *dst, const int32_t *in_degree, const int32_t *arg,
                                float *gmsg, float *gself, const float *relu_src, const unsigned *relu_bits, const int32_t *order,
                                int64_t E, int64_t N, int D, void *stream);
+/* ABI 14.  a_max's backward without the dense input-gradient product (reference models/operations_lp.py:230-235): the gradient w.r.t.
+ * the messages has one non-zero per (node, column) -- the arg-max edge, where the maximum is positive -- so
+ *   gmsg[e][c] = (arg[dst[e]][c] == e && (mx == NULL || mx[dst[e]][c] > 0)) ? gout[dst[e]][c] : 0        [E, D]  (NULL: not written)
+ *   gx[e][k]   = sum_c gmsg[e][c] * W[c][k]                                                             [E, Kin]
+ * in ONE pass per edge row: the rows W[c, :] of the columns an edge won are added from a copy of W in LDS.  W [D, Kin] row-major must
+ * fit 160 KB (mrg_segmax_bwd_input_ok); D, Kin multiples of 4, at most 256.  order: NULL or the edge ids sorted by destination.
+ * Deterministic; exact f32 arithmetic. */
+int mrg_segmax_bwd_input_ok(int D, int Kin);
+int mrg_segmax_bwd_input(const float *gout, const float *mx, const int32_t *dst, const int32_t *arg, const float *W, float *gmsg,
+                         float *gx, const int32_t *order, int64_t E, int64_t N, int D, int Kin, void *stream);
 
 /* ---- a9: fused gather -> compose -> segmented sum ------------------------------
  * CompGraphConv.forward steps 1-3, reference models/compgcn.py:58-87:

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mrg_gemm_set_q": (_I, [_I]),
     "mrg_set_dynamic_rows": (_I, [_L, _P, _L, _P]),
     "mrg_gemm_set_small": (_I, [_I]),
+    "mrg_segmax_bwd_input_ok": (_I, [_I, _I]),
+    "mrg_segmax_bwd_input": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
     "mrg_optim_chunk": (_I, []),
     "mrg_clip_sgd_step": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P]),
     "mrg_act_grad_transpose": (_I, [_P, _P, _P, _L, _L, _I, _P]),

@@ -138,9 +138,118 @@ __global__ __launch_bounds__(MRG_BLOCK) void seg_bwd_k(const float* __restrict__
   }
 }
 
+// ---- a_max backward: the input gradient WITHOUT a dense product (round 5) ------------------------------------------------------------
+// a_max (reference models/operations_lp.py:230-235) is  h[v] = max over the in-edges e of v of ReLU(W x_e + b).  Its gradient w.r.t.
+// the messages, gmsg[e][c] = g[v][c] if e is the arg-max of (v, c) and the maximum is positive, has ONE non-zero per (node, column):
+// N * D of E * D entries (FB15k-237: 2.7 %).  The input gradient gx = gmsg W was a dense [E, D] x [D, K] product over that matrix
+// (0.33 ms per launch after a 0.19 ms seg_bwd_k wrote gmsg).  Here ONE pass per edge row forms gmsg[e] from the gathered g / arg /
+// max rows (written for the weight gradient, which stays dense) and adds the rows W[c, :] of the columns the edge won -- on average
+// N * D / E of them (5.3) -- from a copy of W in LDS (D * K * 4 bytes <= 160 KB: D = K = 200 fills the CU's LDS exactly; one
+// 1024-thread workgroup per CU).  Order of the sum per output element: the won columns c ascending within j = c % 4, j = 0..3 --
+// deterministic; exact f32 FMAs (the dense product ran on the split core at f32-equivalent accuracy).
+template <bool WLDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void segmax_bwd_gx_k(const float* __restrict__ gout, const float* __restrict__ mx,
+                                                         const int32_t* __restrict__ dst, const int32_t* __restrict__ arg,
+                                                         const float* __restrict__ W, float* __restrict__ gmsg, float* __restrict__ gx,
+                                                         const int32_t* __restrict__ order, int64_t E, int D, int Kin) {
+  extern __shared__ __align__(16) float wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int WAVES = THREADS / 64;
+  if constexpr (WLDS) {
+    const int n4 = D * Kin / 4;
+    for (int i = tid; i < n4; i += THREADS) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(W)[i];
+    __syncthreads();
+  }
+  const float* __restrict__ wsrc = WLDS ? wl : W;          // lab (MRG_SEGMAX_BWD_LDS=0): the rows of W from L2, four waves per block, no LDS
+  const int dv = D >> 2, kv = Kin >> 2;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  // A wave's rows are a chain edge id -> destination -> three gathered table rows -> stores: ~2 us of dependent latency per edge with
+  // only sixteen waves on the CU (the LDS is full).  Software pipeline: the table rows of edge i + 1 and the destination of edge
+  // i + 2 are in flight while edge i is processed (positions past the end are clamped to the last edge and never processed).
+  auto edge_at = [&](int64_t p) -> int { const int64_t q = p < E ? p : E - 1; return order ? order[q] : (int)q; };
+  const bool lv = lane < dv;
+  auto load_row = [&](int64_t v, float4& g4, int4& a4, float4& x4) {
+    g4 = make_float4(0.f, 0.f, 0.f, 0.f); a4 = make_int4(-1, -1, -1, -1); x4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (lv) {
+      g4 = *reinterpret_cast<const float4*>(gout + v * D + lane * 4);
+      a4 = *reinterpret_cast<const int4*>(arg + v * D + lane * 4);
+      if (mx) x4 = *reinterpret_cast<const float4*>(mx + v * D + lane * 4);
+    }
+  };
+  const int64_t first = (int64_t)blockIdx.x * WAVES + wave;
+  if (first >= E) return;                                   // (after the only barrier)
+  int r0 = __builtin_amdgcn_readfirstlane(edge_at(first));
+  int r1 = __builtin_amdgcn_readfirstlane(edge_at(first + stride));
+  int64_t v1 = __builtin_amdgcn_readfirstlane(dst[r1]);
+  float4 g4, x4; int4 a4;
+  load_row((int64_t)__builtin_amdgcn_readfirstlane(dst[r0]), g4, a4, x4);
+  for (int64_t pos = first; pos < E; pos += stride) {
+    const int r2 = __builtin_amdgcn_readfirstlane(edge_at(pos + 2 * stride));
+    const int v2 = dst[r2];                                 // in flight until the bottom of the trip
+    float4 gn, xn; int4 an;
+    load_row(v1, gn, an, xn);                               // edge i + 1's rows: in flight during edge i's work
+    const int r = r0;
+    float m[4];
+    m[0] = (a4.x == r && x4.x > 0.f) ? g4.x : 0.f;
+    m[1] = (a4.y == r && x4.y > 0.f) ? g4.y : 0.f;
+    m[2] = (a4.z == r && x4.z > 0.f) ? g4.z : 0.f;
+    m[3] = (a4.w == r && x4.w > 0.f) ? g4.w : 0.f;
+    if (lv && gmsg) *reinterpret_cast<float4*>(gmsg + (int64_t)r * D + lane * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned long long live = __ballot(m[j] != 0.f);
+      while (live) {                                        // wave-uniform: one trip per column this edge won
+        const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(live));
+        live &= live - 1;
+        const float val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[j]), src));
+        const int c = src * 4 + j;
+        if (lane < kv) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wsrc + c * Kin + lane * 4);
+          acc.x += val * w4.x; acc.y += val * w4.y; acc.z += val * w4.z; acc.w += val * w4.w;
+        }
+      }
+    }
+    if (lane < kv) *reinterpret_cast<float4*>(gx + (int64_t)r * Kin + lane * 4) = acc;
+    g4 = gn; a4 = an; x4 = xn;
+    r0 = r1; r1 = r2;
+    v1 = __builtin_amdgcn_readfirstlane(v2);
+  }
+}
+
 }  // namespace mrg
 
 using namespace mrg;
+
+// 1 when mrg_segmax_bwd_input takes the shape: W [D, Kin] fits the LDS of a CU, rows are whole float4s of at most one wave
+extern "C" int mrg_segmax_bwd_input_ok(int D, int Kin) {
+  return (D > 0 && Kin > 0 && D % 4 == 0 && Kin % 4 == 0 && D <= 256 && Kin <= 256 && (size_t)D * Kin * 4 <= 160 * 1024) ? 1 : 0;
+}
+
+// gmsg [E, D] (may be NULL) and gx [E, Kin] = gmsg W of a_max's backward in one pass (see segmax_bwd_gx_k).  gout / mx / arg: [N, D]
+// (mx NULL: no ReLU mask); W [D, Kin] row-major (nn.Linear.weight of the aggregator); order: NULL or the edge ids by destination.
+extern "C" int mrg_segmax_bwd_input(const float* gout, const float* mx, const int32_t* dst, const int32_t* arg, const float* W, float* gmsg,
+                                    float* gx, const int32_t* order, int64_t E, int64_t N, int D, int Kin, void* stream) {
+  if (E < 0 || N < 0 || E >= ((int64_t)1 << 31)) return MRG_E_SHAPE;
+  if (!mrg_segmax_bwd_input_ok(D, Kin)) return MRG_E_SHAPE;
+  if (E == 0) return MRG_OK;
+  if (!gout || !dst || !arg || !W || !gx) return MRG_E_NULLPTR;
+  if (!aligned16(gout) || !aligned16(arg) || !aligned16(W) || !aligned16(gx) || !aligned16(gmsg) || !aligned16(mx)) return MRG_E_SHAPE;
+  static const int use_lds = [] { const char* e = getenv("MRG_SEGMAX_BWD_LDS"); return e ? atoi(e) : 1; }();   // lab switch
+  if (use_lds) {
+    const size_t lds = (size_t)D * Kin * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&segmax_bwd_gx_k<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int64_t grid = (E + 15) / 16;
+    if (grid > 256) grid = 256;                            // one 1024-thread workgroup (the whole LDS) per CU
+    hipLaunchKernelGGL((segmax_bwd_gx_k<true, 1024>), dim3((unsigned)grid), dim3(1024), lds, (hipStream_t)stream, gout, mx, dst, arg, W, gmsg, gx, order, E, D, Kin);
+  } else {
+    int64_t grid = (E + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((segmax_bwd_gx_k<false, 256>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, gout, mx, dst, arg, W, gmsg, gx, order, E, D, Kin);
+  }
+  MRG_LAUNCH_CHECK();
+  return MRG_OK;
+}
 
 extern "C" int64_t mrg_seg_reduce_workspace_bytes(int64_t n_slots, int D) {
   if (n_slots < 0 || D <= 0) return 0;

@@ -46,6 +46,21 @@ def _seg_bwd(mode, g, graph, arg, gmsg, gself, relu_src=None, relu_bits=None):
                                         ptr(relu_src), ptr(relu_bits), ptr(order), E, N, D, stream_of(g)), nbytes=nb)
 
 
+
+def _amax_bwd_sparse(g, mx, arg, W, graph, gy, gx):
+    """a_max's backward for the fused forward: gy = the gradient w.r.t. the messages (one non-zero per (node, column): the arg-max
+    edge where the maximum is positive) AND gx[:E] = gy W in one pass per edge row, without the dense input-gradient product
+    (mrg_segmax_bwd_input).  Returns False when the shape is not taken (W beyond the LDS of a CU: D = 256)."""
+    E, N, D = graph.num_edges(), graph.number_of_nodes(), g.shape[1]
+    if not (SW.SPARSE_AMAX_BWD and g.is_cuda and _lib.load().mrg_segmax_bwd_input_ok(D, W.shape[1])):
+        return False
+    p = graph.plan()
+    big = 4 * D * N * 3 > ORDERED_BWD_MIN_BYTES            # the three gathered [N, D] tables beyond the caches: walk by destination
+    order = p["eid"] if (ORDERED_BWD and big) else None
+    call("mrg_segmax_bwd_input", (ptr(g), ptr(mx), ptr(graph.i32("dst")), ptr(arg), ptr(W), ptr(gy), ptr(gx), ptr(order), E, N, D, W.shape[1],
+                                  stream_of(g)), nbytes=4 * E * (D + W.shape[1]) + 4 * E + 12 * N * D)
+    return True
+
 class _SegReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, msg, self_rows, graph):
@@ -238,13 +253,16 @@ class _LinReluAgg(torch.autograd.Function):
         if ctx.fused == "mean":
             _seg_bwd(1, g, graph, None, gy, gx[E:], relu_bits=bits)
         elif ctx.fused:
-            _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)             # the winning message is ReLU-dead iff the maximum is 0
             gx[E:] = g
+            have_gx = _amax_bwd_sparse(g, mx, arg, W, graph, gy, gx)       # gy and gx[:E] in one pass, no dense product
+            if not have_gx:
+                _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)         # the winning message is ReLU-dead iff the maximum is 0
         else:
             _seg_bwd(mode, g, graph, arg, gy, gx[E:], relu_src=y)          # gy masked by ReLU; gx[E:] = g
         work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
-        wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
-        call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
+        if not (ctx.fused is True and have_gx):
+            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
+            call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
         gW = torch.empty_like(W)
         gb = torch.empty(D, dtype=torch.float32, device=x.device)
         ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", E, D, D), x)
@@ -335,12 +353,15 @@ class _LinReluPartial(torch.autograd.Function):
         if ctx.fused == "sum":
             _seg_bwd(0, g, graph, None, gy, None, relu_bits=bits)
         elif ctx.fused:
-            _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)          # the winning message is ReLU-dead iff the maximum is 0
+            have_gx = _amax_bwd_sparse(g, mx, arg, W, graph, gy, gx)    # gy and gx[:E] in one pass, no dense product
+            if not have_gx:
+                _seg_bwd(mode, g * (mx > 0), graph, arg, gy, None)      # the winning message is ReLU-dead iff the maximum is 0
         else:
             _seg_bwd(mode, g, graph, arg, gy, None, relu_src=y)        # gy masked by ReLU
         work = dict(nbytes=4 * E * 2 * D + 4 * D * D, flops=2 * E * D * D)
-        wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
-        call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
+        if not (ctx.fused is True and have_gx):
+            wt = _ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), x)
+            call("mrg_linear_bwd_input", (ptr(gy), ptr(W), ptr(gx), ptr(wt), E, D, D, D, 0, st), **work)
         gW = torch.empty_like(W)
         gb = torch.empty(D, dtype=torch.float32, device=x.device)
         ws = _ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", E, D, D), x)

@@ -25,3 +25,4 @@ GROUPED_SEGMENTS = os.environ.get("MRG_GROUPED_SEGMENTS", "1") == "1"    # lab s
 DENSE_PAIR = os.environ.get("MRG_DENSE_PAIR", "1") == "1"       # lab switch: 0 = f_dense_comp and f_comp of a MixedOp as two autograd nodes
 GATED_RECOMPUTE = os.environ.get("MRG_GATED_RECOMPUTE", "1") == "1"     # lab switch: 0 = f_dense_comp's output is stored for the epilogue
 COMPGCN_TAIL = os.environ.get("MRG_COMPGCN_TAIL", "1") == "1"     # lab switch: 0 = CompGraphConv's BatchNorm -> tanh tail on torch kernels
+SPARSE_AMAX_BWD = os.environ.get("MRG_SPARSE_AMAX_BWD", "1") == "1"   # lab switch: 0 = a_max's input gradient as seg_bwd_k + the dense row GEMM

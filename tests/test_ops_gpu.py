@@ -589,17 +589,38 @@ def test_fused_amax_is_bit_exact_with_the_two_launch_form(N, E, R, D, hub):
     min_rows = K.switches.FUSED_AMAX_MIN_ROWS
     try:
         K.switches.FUSED_AMAX_MIN_ROWS = 0
-        for fused in (True, False):
-            K.switches.FUSED_AMAX = fused
+        for fused in (True, False, "sparse"):
+            K.switches.FUSED_AMAX = bool(fused)
+            K.switches.SPARSE_AMAX_BWD = fused == "sparse"           # the bit comparison is between the two DENSE input-gradient products
             x, W, b = (t.clone().to(DEV).requires_grad_(True) for t in (x0, W0, b0))
             out = K.linear_relu_aggregate("max", x, W, b, g)
             out.backward(gout)
             res[fused] = (out.detach(), x.grad, W.grad, b.grad)
     finally:
-        K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS = True, min_rows
+        K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.SPARSE_AMAX_BWD = True, min_rows, True
     assert int(mr_gnas_amd._lib.load().mrg_linear_relu_segmax_workspace_bytes(N, D, D)) > 0
     for a, b_, what in zip(res[True], res[False], ("out", "gx", "gW", "gb")):
         assert torch.equal(a, b_), what
+    # the input gradient without a dense product (mrg_segmax_bwd_input: the rows of W of the columns an edge won, exact f32): the same
+    # message gradient bit for bit (so gW, gb too), gx within rounding of the split-core product -- and closer to float64 than it
+    assert mr_gnas_amd._lib.load().mrg_segmax_bwd_input_ok(D, D) == 1
+    for i, what in ((0, "out"), (2, "gW"), (3, "gb")):
+        assert torch.equal(res["sparse"][i], res[True][i]), what
+    assert torch.equal(res["sparse"][1][E:], res[True][1][E:])
+    close(res["sparse"][1], res[True][1].cpu(), "sparse a_max input gradient vs the dense product", rtol=2e-5, atol=2e-6, rms_rtol=2e-5)
+    gy64 = torch.zeros(E, D, dtype=torch.float64, device=DEV)
+    xg = x0.to(DEV)
+    m64 = torch.relu(xg[:E].double() @ W0.to(DEV).double().t() + b0.to(DEV).double())
+    dstd = dst.to(DEV)
+    top = torch.zeros(N, D, dtype=torch.float64, device=DEV).scatter_reduce(0, dstd.view(-1, 1).expand(E, D), m64, "amax", include_self=False)
+    win = (m64 == top[dstd]) & (m64 > 0)
+    first = torch.full((N, D), E, dtype=torch.long, device=DEV).scatter_reduce(0, dstd.view(-1, 1).expand(E, D),
+                                                                               torch.where(win, torch.arange(E, device=DEV).view(-1, 1).expand(E, D), E), "amin")
+    gy64 = torch.where(win & (first[dstd] == torch.arange(E, device=DEV).view(-1, 1)), gout.double()[dstd], 0.0)
+    gx64 = gy64 @ W0.to(DEV).double()
+    e_sparse = float((res["sparse"][1][:E].double() - gx64).abs().max())
+    e_dense = float((res[True][1][:E].double() - gx64).abs().max())
+    assert e_sparse <= max(2.0 * e_dense, 1e-6 * float(gx64.abs().max())), f"sparse {e_sparse:.3e} vs dense {e_dense:.3e} against float64"
     ref = OO.a_max(OGraph(N, src.numpy(), dst.numpy(), et.numpy(), np.ones(E, np.float32)), {"linear.weight": W0, "linear.bias": b0}, x0, None)
     close(res[True][0], ref, "fused a_max vs oracle")
 
