@@ -52,6 +52,10 @@ ENTRY_KERNELS.update({
     "mrg_linear_bwd_input3_pair": ["rowgemm_x3s_k<7, 3, true@max|rowgemm_x3s_k<7, 0, true@max"],
     "mrg_linear_relu_segmax_fwd": ["rowgemm_x3s_k<7, 4", "segmax_finalize_k"],
     "mrg_linear_relu_segsum_fwd": ["rowgemm_x3s_k<7, 5"],
+    # round 5: the 16 x 16 x 32 kernel takes the K = 400 products (rowgemm_x3q_k<EPI, DUAL>), a_max's input gradient has no GEMM
+    "mrg_dense_filter_fwd3": ["rowgemm_x3q_k<1, true>@max|rowgemm_x3q_k<2, true>@max|rowgemm_x3s_k<7, 1,@max|rowgemm_x3s_k<7, 2,@max"],
+    "mrg_linear_bwd_input3_pair": ["rowgemm_x3q_k<3, true>@max|rowgemm_x3q_k<0, true>@max|rowgemm_x3s_k<7, 3, true@max"],
+    "mrg_segmax_bwd_input": ["segmax_bwd_gx_k"],
     "mrg_zero_stats_coef": ["zero_colstats_k", "mix_reduce_finalize_fwd_k"],
     "mrg_zero_fwd": ["zero_fwd_k"],
     "mrg_zero_bwd_reduce": ["zero_bwd_reduce_k"],
