@@ -187,6 +187,64 @@ def test_sharded_fixed_network_matches_reference(tmp_path, world, case):
         assert float((got - v).abs().max()) <= 2e-3 * scale + 1e-7, k
 
 
+MIXED_CELL = [('pre_mult', 1, 0), ('f_identity', 2, 1), ('f_comp', 3, 1), ('f_zero', 3, 2), ('a_sum', 4, 2), ('a_mean', 5, 3),
+              ('f_identity', 6, 4), ('f_dense_last', 7, 5), ('f_zero', 7, 4)]
+
+
+def _kinds_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels as CK
+    from mr_gnas_amd import supernet as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        z = load_golden("fixednet_d64")
+        geno = [S.Genotype(alpha_cell=MIXED_CELL, concat_node=[4, 5, 6, 7], score_func='sf_DisMult')] * 2      # two cells: the all-gather between them
+        torch.manual_seed(3)
+        net = S.FixedNetwork("cpu", geno, z["N"], z["R"], z["D"], z["D0"], z["nbase"], registry=CK.registry())
+        net.train()
+        shard = MD.EdgeShard(z["N"], z["src"], z["dst"], z["etype"], z["norm"], z["R"], rank, world, "cpu")
+        sn = MD.ShardedFixedNet(net, shard, kernels=CK)
+        kinds = [sn._node_rows(m) for cell in net.cells[:1] for n in range(cell._nb) for i in range(n + 1) for m in cell._ops[n][i]]
+        pred = sn.forward(z["subj"], z["rel"])
+        loss = sn.loss(pred, z["label"])
+        loss.backward()
+        MD.all_reduce_gradients(sn.replicated_parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        preds, gembs = [None] * world, [None] * world
+        dist.all_gather_object(preds, pred.detach())
+        dist.all_gather_object(gembs, sn.emb_own.grad)
+        if rank == 0:
+            torch.save({"pred": torch.cat(preds, dim=1), "loss": total, "kinds": kinds, "gemb": torch.cat(gembs, dim=0),
+                        "g": {k: p.grad for k, p in net.named_parameters() if k != "embedding_h.weight"}}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fixed_network_other_genotypes_world2_equals_world1(tmp_path):
+    """A genotype with every row kind the README one lacks -- pre_mult (no BatchNorm), f_identity / f_zero in the first AND the last
+    stage (their row kind comes from their siblings or their input: ShardedFixedNet._node_rows), a_sum and a_mean exchanges, two ops
+    summed into one node, two cells (the all-gather between them): two ranks must reproduce one rank."""
+    res = {}
+    for world in (1, 2):
+        out = str(tmp_path / f"res{world}.pt")
+        port = 29500 + (os.getpid() % 2000) + 20 + world
+        mp.spawn(_kinds_worker, args=(world, port, out), nprocs=world, join=True)
+        res[world] = torch.load(out)
+    # zero node, node 2, node 3 (two ops): edge rows; nodes 4-7 (five ops): node rows
+    assert res[1]["kinds"] == [False, False, False, False, True, True, True, True, True]
+    torch.testing.assert_close(res[2]["pred"], res[1]["pred"], rtol=1e-4, atol=1e-6)          # float32, two cells, other summation orders
+    torch.testing.assert_close(res[2]["loss"], res[1]["loss"], rtol=1e-6, atol=1e-8)
+    assert float((res[2]["gemb"] - res[1]["gemb"]).abs().max()) <= 1e-4 * float(res[1]["gemb"].abs().max()) + 1e-9
+    for k, v in res[1]["g"].items():
+        got = res[2]["g"][k]
+        assert (got is None) == (v is None), k
+        if v is not None:
+            assert float((got - v).abs().max()) <= 1e-4 * max(float(v.abs().max()), 1e-8) + 1e-9, k
+
+
 def _bring_up_worker(rank, world, port, fault, out):
     """rccl.bring_up with a fault injected on ONE rank: every rank must leave it together with None (advisor r4)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
