@@ -242,7 +242,7 @@ def test_sharded_fixed_network_other_genotypes_world2_equals_world1(tmp_path):
         got = res[2]["g"][k]
         assert (got is None) == (v is None), k
         if v is not None:
-            assert float((got - v).abs().max()) <= 1e-4 * max(float(v.abs().max()), 1e-8) + 1e-9, k
+            assert float((got - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-6, k    # (+ 1e-6: gradients that are zero in exact arithmetic -- a scale in front of a BatchNorm -- are 1e-7 of noise on both sides)
 
 
 def _bring_up_worker(rank, world, port, fault, out):
