@@ -49,7 +49,6 @@ import torch.nn.functional as F
 
 from . import functional as K
 from . import operations_lp as OPS
-from .supernet import _tsum
 from .graph import RelGraph, cached_on
 
 import os

@@ -47,7 +47,6 @@ class _CellZeroMixed(torch.autograd.Function):
                 call("mrg_zero_stats_coef", (*src, ptr_array(gam), ptr_array(bet), rm, rv, rows, total, D, bn0.eps, mom, ptr(coef), ptr(ws), st),
                      nbytes=gathered)
             else:
-                import torch.distributed as dist
                 sums = torch.empty(K_, 2, D, dtype=torch.float64, device=dev)
                 call("mrg_zero_colstats", (*src, rows, D, ptr(sums), ptr(ws), st), nbytes=gathered)
                 _all_reduce_sum(sums, group)
@@ -90,7 +89,6 @@ class _CellZeroMixed(torch.autograd.Function):
         call("mrg_zero_bwd_reduce", (ptr(g), *src, ptr(coef), ptr(w), ptr(red), ptr(ws), rows, D, st), nbytes=4 * D * rows)
         red_local = red
         if group is not None and ctx.training:
-            import torch.distributed as dist
             red = red.clone()
             _all_reduce_sum(red, group)
         coef2 = torch.empty(K_, 2, D, dtype=torch.float32, device=dev)
