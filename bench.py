@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # the guide's measured float4 copy rate: what an H
 # eight entry-point names, so "the entry point with the largest time" (rounds 1-2) named the wrong kernel.  `roofline` is the
 # family with the largest summed time: its summed algorithmic work / its summed time.
 KERNEL_FAMILIES = {
-    "row_gemm [rowgemm_x3s_k rowgemm_x3s8_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
+    "row_gemm [rowgemm_x3s_k rowgemm_x3q_k rowgemm_x3s8_k rowgemm_x3_k]": ["mrg_linear_fwd", "mrg_linear_bwd_input", "mrg_linear_bwd_input3", "mrg_linear_bwd_input3_pair", "mrg_dense_filter_fwd",
                                  "mrg_dense_filter_fwd3", "mrg_linear_relu_segmax_fwd", "mrg_linear_relu_segsum_fwd"],
     "weight_gradient [wgrad_x3v_k]": ["mrg_linear_bwd_weight", "mrg_linear_bwd_weight3"],
     "mixedop_epilogue [mix_colstats_k mix_fwd_k mix_bwd_reduce_k mix_bwd_apply_k]": [
@@ -59,7 +59,8 @@ KERNEL_FAMILIES = {
     "scalar_gates [gate_row_fwd_k gate_row_bwd_k gate_fwd_k gate_bwd_k]": ["mrg_gate_collapse3", "mrg_gate_row_fwd", "mrg_gate_row_bwd", "mrg_gate_fwd", "mrg_gate_bwd",
                                                                            "mrg_gate_param_grad3"],
     "gradient_fan_in [sum_k sum_rows_gather_k]": ["mrg_sum_buffers", "mrg_sum_rows_gather"],
-    "segment_reducers [seg_chunk_k seg_bwd_k]": ["mrg_seg_reduce_fwd", "mrg_seg_reduce_bwd", "mrg_seg_reduce_bwd_bits", "mrg_seg_reduce_heads_fwd"],
+    "segment_reducers [seg_chunk_k seg_bwd_k segmax_bwd_gx_k]": ["mrg_seg_reduce_fwd", "mrg_seg_reduce_bwd", "mrg_seg_reduce_bwd_ordered", "mrg_seg_reduce_bwd_bits",
+                                                                  "mrg_seg_reduce_heads_fwd", "mrg_segmax_bwd_input"],
     "gathers [gather_compose_k distmult_k zero_colstats_k]": ["mrg_gather_compose_fwd", "mrg_distmult_score", "mrg_zero_stats_coef", "mrg_zero_colstats"],
     "cell_zero [zero_fwd_k zero_bwd_reduce_k zero_bwd_apply_k]": ["mrg_zero_fwd", "mrg_zero_bwd_reduce", "mrg_zero_bwd_apply"],
     "compose [compose_fwd_k]": ["mrg_compose_fwd", "mrg_compose_bwd", "mrg_dense_filter_dz", "mrg_dense_filter_dz3"],
