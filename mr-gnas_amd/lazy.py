@@ -47,6 +47,8 @@ Reference counterparts: models/cell_lp.py:12-33 (MixedOp), :89-152 (the stages' 
 """
 import os
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -141,6 +143,28 @@ class BatchNormView:
         self.num_batches_tracked = None
 
 
+# A training-mode BatchNorm call has a side effect -- the running statistics' momentum update -- and two calls on the SAME buffers do
+# not commute.  The reference uses every BatchNorm module once per forward, so the order of evaluation cannot show; for callers that
+# reuse one, a new Bn handle first evaluates the pending handle that would update the same buffers: the updates keep the call order.
+# (A BatchNorm whose output NOBODY ever reads is never evaluated and does not update its statistics: the one observable difference
+# from eager evaluation.)
+_PENDING_BN = {}
+
+
+def _bn_handle(x, view):
+    h = Lazy(Bn(x, view), x.shape, x)
+    rm = view.running_mean
+    if view.training and rm is not None:
+        key = id(rm)
+        prev = _PENDING_BN.get(key)
+        if prev is not None:
+            buf, old = prev[0](), prev[1]()
+            if buf is rm and old is not None and old._value is None:
+                old.materialize()
+        _PENDING_BN[key] = (weakref.ref(rm, lambda _r, key=key: _PENDING_BN.pop(key, None)), weakref.ref(h))
+    return h
+
+
 class Lazy(torch.Tensor):
     """A tensor that has not been computed (module docstring)."""
 
@@ -151,6 +175,7 @@ class Lazy(torch.Tensor):
 
     def __init__(self, node, shape, like):
         self.node = node
+        self._grad_mode = torch.is_grad_enabled()   # the mode the eager call would have run in: a consumer inside no_grad must not decide it
         self._value = None          # the real tensor once materialised
         self._fan = None            # functional.Fan over the real tensor: the readers of a state share one K-way gradient sum
         self._rows = None           # Gather handles: the functional.LazyRows form (one per handle: its readers share the materialised rows)
@@ -165,7 +190,11 @@ class Lazy(torch.Tensor):
 
     def materialize(self):
         if self._value is None:
-            self._value = _evaluate(self)
+            # evaluated in the autograd mode of the CALL that made the handle, whoever looks first: a `with torch.no_grad():` consumer
+            # would otherwise cache a value without a graph and every later reader would lose its gradient (found by
+            # tests/test_host_cpu.py::test_lazy_handles_random_programs_equal_eager)
+            with torch.set_grad_enabled(self._grad_mode):
+                self._value = _evaluate(self)
             self.node = None        # the description's operands are no longer needed: let them go
         return self._value
 
@@ -207,7 +236,7 @@ class Lazy(torch.Tensor):
                                      kwargs.get("training", args[5] if len(args) > 5 else False),
                                      kwargs.get("momentum", args[6] if len(args) > 6 else 0.1),
                                      kwargs.get("eps", args[7] if len(args) > 7 else 1e-5))
-                return Lazy(Bn(x, view), x.shape, x)
+                return _bn_handle(x, view)
             if (func is F.relu or name == "relu") and isinstance(x.node, Bn) and not kwargs.get("inplace", False) and len(args) == 1:
                 return Lazy(Act(x), x.shape, x)
             if name in ("add", "__add__", "__radd__") and len(args) == 2 and not kwargs:

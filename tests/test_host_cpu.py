@@ -336,3 +336,134 @@ def test_rccl_binding_loads_and_matches_the_header():
     assert rccl._DTYPE[torch.float32] == 7 and rccl._DTYPE[torch.float64] == 8 and rccl._DTYPE[torch.int32] == 2
     assert rccl._OP == {"sum": 0, "max": 2, "min": 3}
     assert lib.ncclGetErrorString(0).decode().lower().startswith("no error")
+
+
+def test_lazy_handles_random_programs_equal_eager():
+    """mr_gnas_amd/lazy.py is observational: whatever torch code touches an operator's lazy handle, the values (and the gradients)
+    are those of the eager evaluation.  Random programs over the handle vocabulary (operator call, BatchNorm, ReLU, dropout, scaling,
+    sums) mixed with calls OUTSIDE it (views, cat / stack, reductions, masked indexing, handle x handle products, in-place updates,
+    detach, no_grad, clone, comparison) run twice -- handles on (lazy.FORCE_CPU: CPU restatements of the operators behind this
+    package's forward / run protocol, every handle evaluated literally) and off -- and every observed tensor must be bit-equal."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels as CK
+    from mr_gnas_amd import lazy as LZ, operations_lp as OPS
+
+    def wrap(inner, node_rows):
+        class W(OPS._Operator):
+            def __init__(self):
+                super().__init__()
+                for k, m in inner.named_children():
+                    setattr(self, k, m)
+                object.__setattr__(self, "_inner", inner)
+
+            def out_shape(self, g, src_emb):
+                return (g.number_of_nodes() if node_rows else src_emb.shape[0], src_emb.shape[1])
+
+            def run(self, g, a, b, for_epilogue=False):
+                return inner(g, LZ.real(a), LZ.real(b))
+        return W()
+
+    rng = np.random.default_rng(11)
+    n, R, T, D = 30, 4, 120, 8
+    tri = np.stack([rng.integers(0, n, T), rng.integers(0, R, T), rng.integers(0, n, T)], 1)
+    g = G.build_search_graph(n, R, tri)
+    E = g.num_edges()
+    reg = CK.registry()
+    torch.manual_seed(0)
+    edge_ops = [wrap(reg[k]({"feature_dim": D}), False) for k in ("f_dense_comp", "f_sparse_comp", "f_comp", "f_identity")]
+    node_ops = [wrap(reg[k]({"feature_dim": D, "drop_aggr": 0.0}), True) for k in ("a_max", "a_sum", "a_mean")]
+    bns = [torch.nn.BatchNorm1d(D) for _ in range(3 + 14)]       # 0-2: reused by the MixedOp idiom (always on handles); 3 + step: once per program step
+    params = [p for m in edge_ops + node_ops + bns for p in m.parameters()]
+    state0 = [t.clone() for m in bns for t in m.state_dict().values()]
+    # (a BatchNorm module applied twice in one forward, once to a handle and once to a plain tensor, updates its running statistics in
+    #  evaluation order, not call order -- lazy.py's one documented difference; the reference uses every BatchNorm once per forward)
+
+    def program(seed, handles):
+        LZ.ENABLED, LZ.FORCE_CPU = handles, handles
+        for m, i in zip(bns, range(len(bns))):
+            m.load_state_dict(dict(zip(m.state_dict().keys(), state0[i * 5:(i + 1) * 5])))
+            m.train()
+        for p in params:
+            p.grad = None
+        r = np.random.default_rng(seed)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(E + n, D, generator=gen).requires_grad_(True)
+        y = torch.randn(E + n, D, generator=gen).requires_grad_(True)
+        w = torch.rand(6, generator=gen).requires_grad_(True)
+        edge, node, seen = [x], [], []                       # tensors / handles with E + n rows, with n rows; what the program looked at
+
+        def obs(t):
+            seen.append(torch.as_tensor(t).detach().clone() if isinstance(t, torch.Tensor) else torch.tensor(float(t)))
+
+        for step in range(14):
+            a = int(r.integers(0, 16))
+            pool = edge if (not node or r.random() < 0.6) else node
+            h = pool[int(r.integers(0, len(pool)))]
+            if a <= 2:                                        # an operator call on the latest states
+                op = edge_ops[int(r.integers(0, len(edge_ops)))]
+                edge.append(op(g, edge[-1], edge[0]))
+            elif a == 3:
+                node.append(node_ops[int(r.integers(0, len(node_ops)))](g, edge[-1], edge[0]))
+            elif a == 4:                                      # the MixedOp idiom: w * relu(bn(op(...))) summed
+                ops = [edge_ops[int(i)] for i in r.integers(0, len(edge_ops), 3)]
+                edge.append(sum(w[k] * torch.relu(bns[k](op(g, edge[-1], edge[0]))) for k, op in enumerate(ops)))
+            elif a == 5:
+                pool.append(torch.nn.functional.dropout(torch.relu(bns[3 + step](h)), 0.0, True))
+            elif a == 6:
+                pool.append(h + pool[0] if pool is edge else h + h)
+            elif a == 7:                                      # outside the vocabulary: views and reductions
+                obs(h.t().contiguous().sum(1))
+                obs(h.view(-1)[::7])
+            elif a == 8:
+                obs(torch.cat((h, h * 2.0), 1).mean(0))
+                obs(torch.stack((h, h)).amax(0))
+            elif a == 9:
+                m_ = h.detach() > 0.3
+                obs(h[m_])
+                obs((h > 0).sum())
+            elif a == 10:
+                pool.append(h * h)                            # handle x handle
+            elif a == 11:
+                with torch.no_grad():
+                    obs(h.clone().add_(1.0).mul_(0.5))
+                obs(h.detach().abs().max())
+            elif a == 12:
+                z = h.clone()
+                z[0] = 0.0                                     # in-place write into a copy
+                pool.append(z)
+            elif a == 13:
+                obs(h.shape[0] * 1.0)
+                obs(h.dim())
+                obs(h.new_zeros(3).sum() + h.sum())
+            elif a == 14:
+                pool.append(torch.where(h > 0, h, 0.1 * h))
+            else:
+                pool.append(0.5 * h - pool[0] if pool is edge else -h)
+        loss = sum(t.square().mean() for t in edge[1:]) + sum(t.abs().mean() for t in node)
+        if isinstance(loss, torch.Tensor) and loss.requires_grad:
+            loss.backward()
+        obs(loss)
+        grads = [None if p.grad is None else p.grad.clone() for p in [x, y, w] + params]
+        stats = [t.clone() for m in bns for t in m.state_dict().values()]
+        return seen, grads, stats, sum(isinstance(t, LZ.Lazy) for t in edge + node)
+
+    try:
+        handles_seen = 0
+        for seed in range(int(os.environ.get("MRG_LAZY_FUZZ", "60"))):
+            lazy_run = program(seed, True)
+            eager_run = program(seed, False)
+            handles_seen += lazy_run[3]
+            assert eager_run[3] == 0
+            assert len(lazy_run[0]) == len(eager_run[0])
+            for i, (a, b) in enumerate(zip(lazy_run[0], eager_run[0])):
+                assert a.shape == b.shape and torch.equal(a, b), f"seed {seed}: observation {i} differs by {float((a - b).abs().max()):.3e}"
+            for a, b in zip(lazy_run[2], eager_run[2]):
+                assert torch.equal(a, b), f"seed {seed}: BatchNorm running statistics differ"
+            for i, (a, b) in enumerate(zip(lazy_run[1], eager_run[1])):
+                assert (a is None) == (b is None), f"seed {seed}: gradient {i} present on one side only"
+                if a is not None:                              # (the order in which autograd sums a leaf's gradients may differ: rounding)
+                    assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6, f"seed {seed}: gradient {i}"
+        assert handles_seen > 100                               # the programs did run on handles
+    finally:
+        LZ.ENABLED, LZ.FORCE_CPU = True, False
