@@ -417,7 +417,7 @@ def test_lazy_fixed_genotype_chain_and_discarded_dropout():
 # ---------------------------------------------------------------------------
 # static step graphs (round 5): capacity padding + device-side row counts
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("D,sample", [(24, 300), (200, 300), (64, 2000)])
+@pytest.mark.parametrize("D,sample", [(24, 300), (200, 300), (64, 2000), (100, 37), (52, 5), (128, 1100), (200, 1400), (64, 1600)])
 def test_static_padded_step_equals_the_unpadded_step(D, sample):
     """sampler.static_step pads the draw's step graph to min(2 * sample, N) nodes and leaves the node count on the device;
     SearchNetwork.static_rows hands the counts to the MixedOp kernels (mrg_set_dynamic_rows).  The padded step must compute the
@@ -441,7 +441,7 @@ def test_static_padded_step_equals_the_unpadded_step(D, sample):
     st = SM.static_step(tri, sample, 0.5, R, 3, N_all)
     n = int(st["n_nodes"].item())
     cap = st["cap"]
-    assert cap == min(2 * sample, N_all) and 0 < n < cap and int(st["n_rows"].item()) == n + st["g"].num_edges()
+    assert cap == min(2 * sample, N_all) and 0 < n <= cap and int(st["n_rows"].item()) == n + st["g"].num_edges()
     assert int(st["samples"][:, [0, 2]].max()) < n                       # the scored triples only name the draw's nodes
 
     def run(g, node_id, src, rel, static):
@@ -465,7 +465,7 @@ def test_static_padded_step_equals_the_unpadded_step(D, sample):
     exact = run(g_exact, st["node_id"][:n], src_e, g_exact.edata["e_type"], None)
     padded = run(st["g"], st["node_id"], st["src"], st["rel"], (st["n_rows"], st["n_nodes"]))
     assert torch.equal(st["src"], src_e) and st["g"].num_edges() == g_exact.num_edges()      # same edges, same (rel, dst, src) order
-    assert tuple(padded[0].shape) == (cap, D) and float(padded[0][n:].abs().max()) == 0.0      # padding rows stay zero
+    assert tuple(padded[0].shape) == (cap, D) and (n == cap or float(padded[0][n:].abs().max()) == 0.0)      # padding rows stay zero
     # (equal to float32 rounding, not bit for bit: the padded launch has more rows, so its grids -- and with them the association of the
     #  per-block partial sums of the statistics -- differ)
     torch.testing.assert_close(padded[0][:n], exact[0], rtol=1e-4, atol=1e-5)
@@ -474,8 +474,13 @@ def test_static_padded_step_equals_the_unpadded_step(D, sample):
     assert sorted(padded[3]) == sorted(exact[3])
     gmax = max(float(v.abs().max()) for v in exact[3].values())
     for k, v in exact[3].items():
-        scale = max(float(v.abs().max()), 1e-3 * gmax)
-        assert float((padded[3][k] - v).abs().max()) <= 5e-4 * scale, (k, float((padded[3][k] - v).abs().max()), scale)
+        scale = max(float(v.abs().max()), 5e-3 * gmax)        # (a bias in front of a BatchNorm: a gradient that is zero in exact arithmetic)
+        d = (padded[3][k] - v).abs()
+        # (isolated entries may move more: statistics summed in another order can flip a ReLU decision whose pre-activation is ~0 --
+        #  as between any two float32 runs; tests/test_configs_gpu.py measures those flips -- conftest's clause: at most 0.5 % of a tensor's
+        #  entries (one entry of a [200] bias), each <= 2e-2)
+        assert float(d.max()) <= 5e-4 * scale or (float((d > 5e-4 * scale).double().mean()) <= 5e-3 and float(d.max()) <= 2e-2 * scale), \
+            (k, float(d.max()), scale)
     for a, b in zip(padded[4], exact[4]):
         assert float((a - b).abs().max()) <= 5e-4 * max(float(b.abs().max()), 1e-8)
     for k, v in exact[5].items():
