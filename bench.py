@@ -130,7 +130,7 @@ def parse():
                     help="with --resample: the new step graph of every step is padded to a host-known node capacity and its node count stays "
                          "on the device (sampler.static_step, mrg_set_dynamic_rows): no host read in the step, every shape fixed -- with "
                          "--hip-graph (which implies it) the WHOLE step, sampler included, is captured once and replayed with a new draw every time")
-    ap.add_argument("--comm", default=os.environ.get("MRG_COMM", "direct"), choices=["direct", "c10d"],
+    ap.add_argument("--comm", default=os.environ.get("MRG_COMM", "direct"), choices=["direct", "c10d", "gloo"],
                     help="N > 1: 'direct' = RCCL bound through ctypes (mr_gnas_amd/rccl.py: stream-ordered launches, the step is captured in a "
                          "HIP graph when every rank's capture succeeds; torch.distributed/gloo only bootstraps and times); 'c10d' = "
                          "torch.distributed's nccl backend for the data path (rounds 1-3)")
@@ -589,6 +589,11 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if args.comm == "gloo":
+        # LAB (not a measurement of any interconnect): N ranks that may SHARE this box's GPU(s), collectives over gloo on device
+        # tensors -- the driver's N > 1 launch line, rank / world parsing, barriers, the max over ranks and rank 0's JSON line run end
+        # to end on a one-GPU box:  python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --comm gloo
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     global _lib
@@ -644,6 +649,10 @@ def main():
             else:
                 comm = rccl.VirtualWorld(rehearse[0], rehearse[1], device)
                 barrier = lambda: None
+        elif args.comm == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            barrier = dist.barrier
+            comm = None                                            # the default (gloo) group carries the data path too
         else:
             if args.hip_graph:
                 # Capturing a step that contains c10d collectives worked in round 2 and aborted in round 3 on the same settings (the
@@ -805,7 +814,9 @@ def main():
                                    "f32 via 3-way bf16 split: 6 cross terms on v_mfma_f32_32x32x16_bf16, f32 accumulate "
                                    "(error vs float64 pinned <= 1.5x the exact-f32 core in tests)"),
                    "parallelism": ("single" if world == 1 and not sharded else
-                                   f"relation-block edge shards x{world} + RCCL ({'bound directly, stream-ordered' if direct else 'torch.distributed nccl backend'})"),
+                                   (f"LAB: relation-block edge shards x{world}, ranks SHARING devices, collectives over gloo on device tensors (--comm gloo): "
+                                    "the N > 1 code path end to end, not a measurement of any interconnect" if args.comm == "gloo" else
+                                    f"relation-block edge shards x{world} + RCCL ({'bound directly, stream-ordered' if direct else 'torch.distributed nccl backend'})")),
                    "launch": launch_mode,
                    "caller": ("cell_lp.MixedOp on the fused HIP epilogue (this package's cell_lp.py / supernet.py)" if args.caller == "fused" else
                               "the reference's literal formulation (models/cell_lp.py:25-33,95-152; models/model_search_lp.py:131-176) on this package's "
