@@ -1239,3 +1239,55 @@ def test_clipped_sgd_replays_from_a_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip(W, ref):
         close(a.detach(), b.detach().cpu(), "parameter after 1 eager + 3 replayed steps", rtol=5e-6, atol=1e-6, rms_rtol=5e-6)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_segmax_bwd_input_random_shapes(seed):
+    """mrg_segmax_bwd_input straight through the C ABI on random shapes (D and K multiples of 4 up to the LDS bound, K != D, tiny and
+    empty edge lists, hubs, isolated nodes, a maximum that is not positive, destination-ordered and edge-id walks, no ReLU mask):
+    gmsg bit-exact with its definition, gx against the float64 product of that gmsg with W."""
+    from mr_gnas_amd._lib import call, ptr, stream_of
+    lib = mr_gnas_amd._lib.load()
+    rng = np.random.default_rng(100 + seed)
+    D = int(rng.choice([4, 8, 52, 64, 100, 128, 200]))
+    Kin = int(rng.choice([4, 16, 64, 100, 200])) if D * 200 * 4 <= 160 * 1024 else int(rng.choice([4, 64]))
+    if D * Kin * 4 > 160 * 1024:
+        Kin = 4
+    N = int(rng.choice([1, 7, 300, 5000]))
+    E = int(rng.choice([0, 1, 15, 17, 1000, 60000]))
+    assert lib.mrg_segmax_bwd_input_ok(D, Kin) == 1
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    dst = torch.randint(0, N, (max(E, 1),), device=DEV, generator=gen, dtype=torch.int32)[:E]
+    if E > 20 and N > 3:
+        dst[: E // 3] = 2                                       # a hub
+    # a consistent arg table: for every (node, column) one of the node's in-edges (or -1 without in-edges)
+    arg = torch.full((N, D), -1, dtype=torch.int32, device=DEV)
+    if E:
+        pick = torch.rand(E, D, device=DEV, generator=gen)
+        best = torch.full((N, D), -1.0, device=DEV).scatter_reduce(0, dst.long().view(-1, 1).expand(E, D), pick, "amax", include_self=True)
+        win = pick == best[dst.long()]
+        eid = torch.arange(E, device=DEV, dtype=torch.int32).view(-1, 1).expand(E, D)
+        arg = torch.full((N, D), 2**31 - 1, dtype=torch.int32, device=DEV).scatter_reduce(0, dst.long().view(-1, 1).expand(E, D),
+                                                                                      torch.where(win, eid, 2**31 - 1), "amin")
+        arg = torch.where(arg == 2**31 - 1, -1, arg).contiguous()
+    gout = torch.randn(N, D, device=DEV, generator=gen)
+    mx = torch.randn(N, D, device=DEV, generator=gen) if seed % 3 else None          # a third of the cases: no ReLU mask
+    W = torch.randn(D, Kin, device=DEV, generator=gen)
+    order = torch.argsort(dst.long(), stable=True).int() if (E and seed % 2) else None
+    gmsg = torch.full((max(E, 1), D), float("nan"), device=DEV)[:E]
+    gx = torch.full((max(E, 1), Kin), float("nan"), device=DEV)[:E]
+    call("mrg_segmax_bwd_input", (ptr(gout), ptr(mx), ptr(dst), ptr(arg), ptr(W), ptr(gmsg), ptr(gx), ptr(order), E, N, D, Kin, stream_of(gout)))
+    torch.cuda.synchronize()
+    if E == 0:
+        return
+    eids = torch.arange(E, device=DEV, dtype=torch.int32).view(-1, 1)
+    keep = (arg[dst.long()] == eids) & ((mx[dst.long()] > 0) if mx is not None else True)
+    ref_msg = torch.where(keep, gout[dst.long()], 0.0)
+    assert torch.equal(gmsg, ref_msg)
+    ref_gx = (ref_msg.double() @ W.double())
+    err = float((gx.double() - ref_gx).abs().max())
+    assert err <= 2e-6 * max(float(ref_gx.abs().max()), 1.0) * max(1.0, (keep.sum(1).max().item()) ** 0.5), (err, D, Kin, N, E)
+    # gmsg == NULL: only gx
+    gx2 = torch.empty_like(gx)
+    call("mrg_segmax_bwd_input", (ptr(gout), ptr(mx), ptr(dst), ptr(arg), ptr(W), None, ptr(gx2), ptr(order), E, N, D, Kin, stream_of(gout)))
+    assert torch.equal(gx2, gx)
