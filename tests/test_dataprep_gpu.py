@@ -210,3 +210,43 @@ def test_score_functions_full_size_against_float64():
         for got, want, what in ((e.grad, e64.grad, "ent"), (s.grad, s64.grad, "sub"), (r.grad, r64.grad, "rel")):
             err = float((got.double() - want).abs().max())
             assert err <= 2e-4 * max(1.0, float(want.abs().max())), f"{nm} grad {what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("sample,negative", [(300, 10), (37, 1), (5000, 3)])
+def test_static_step_draws_what_the_host_driven_sampler_draws(sample, negative):
+    """sampler.static_step (no host read, capacity-padded shapes, node count on the device: the search step as one replayable HIP
+    graph) against generate_sampled_graph_and_labels (reference utils/utils_rgcn.py:79-118) on the SAME random stream: the same edge
+    pick, the same relabelling (node ids of the draw, padding entries 0 behind them), the same corrupted triples and labels, the same
+    graph split -- edge for edge."""
+    import torch
+    from mr_gnas_amd import sampler as SM
+    DEV = "cuda"
+    gen0 = torch.Generator().manual_seed(sample)
+    N_all, R, T = 4000, 9, 60000
+    tri = torch.stack((torch.randint(0, N_all, (T,), generator=gen0), torch.randint(0, R, (T,), generator=gen0),
+                       torch.randint(0, N_all, (T,), generator=gen0)), 1).to(DEV)
+    ga, gb = torch.Generator(device=DEV).manual_seed(77), torch.Generator(device=DEV).manual_seed(77)
+    st = SM.static_step(tri, sample, 0.5, R, negative, N_all, generator=ga)
+    g, uniq_v, src_o, rel, node_norm, samples, labels = SM.generate_sampled_graph_and_labels(tri, sample, 0.5, R, negative, N_all, generator=gb)
+    n = int(st["n_nodes"].item())
+    assert n == uniq_v.numel() and st["cap"] == min(2 * sample, N_all) and int(st["n_rows"].item()) == n + g.num_edges()
+    assert torch.equal(st["node_id"].view(-1)[:n], uniq_v.view(-1)) and int(st["node_id"].view(-1)[n:].abs().max() if n < st["cap"] else 0) == 0
+    # positives and labels are the same; the corrupted entities are drawn as floor(rand * n) against a DEVICE n (the host-driven
+    # sampler draws randint(n) against a host n: another stream, the same distribution) -- checked structurally
+    B = sample
+    assert torch.equal(st["samples"][:B], samples[:B]) and torch.equal(st["labels"], labels)
+    neg = st["samples"][B:].view(negative, B, 3) if negative else st["samples"][B:].view(0, B, 3)
+    pos = st["samples"][:B].unsqueeze(0).expand_as(neg)
+    assert int(st["samples"][:, [0, 2]].min()) >= 0 and int(st["samples"][:, [0, 2]].max()) < n
+    assert torch.equal(neg[..., 1], pos[..., 1])                                     # the relation is never corrupted
+    same_head, same_tail = neg[..., 0] == pos[..., 0], neg[..., 2] == pos[..., 2]
+    assert bool((same_head | same_tail).all())                                       # exactly one end is replaced (it may draw the same id)
+    if B * negative >= 3000:                                                         # uniform over [0, n): mean and head / tail balance
+        drawn = torch.where(same_tail, neg[..., 0], neg[..., 2]).double()
+        assert abs(float(drawn.mean()) - (n - 1) / 2) <= 0.05 * n and 0.4 <= float((~same_head).double().mean()) <= 0.6
+    assert st["g"].num_edges() == g.num_edges() and st["g"].number_of_nodes() == st["cap"]
+    for a, b in zip(st["g"].edges(form="all")[:2], g.edges(form="all")[:2]):
+        assert torch.equal(a, b)
+    assert torch.equal(st["src"], src_o) and torch.equal(st["rel"], rel)
+    # the edge norm of the padded graph on the draw's edges is the unpadded graph's (isolated padding nodes change no in-degree)
+    assert torch.equal(st["g"].edata["norm"], g.edata["norm"])
