@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lab: randomized comparison of the launch-count optimisations against their per-segment / two-launch forms.
 Random shapes (D multiple of 4 above 48, random edge counts and direction splits incl. empty segments); every output and
-gradient must be bit-identical (a_mean: equal within summation-order tolerance).  usage: python tools/fuzz_paths.py [cases] [seed]"""
+gradient must be bit-identical (a_mean: equal within summation-order tolerance; a_max's product-free input gradient: to rounding).  usage: python tools/fuzz_paths.py [cases] [seed]"""
 import os
 import sys
 
@@ -49,14 +49,22 @@ for c in range(cases):
         b0_ = torch.randn(E + N, D, generator=gen).to(DEV)
         gout = torch.randn(N if kind.startswith("a_") else E + N, D, generator=gen).to(DEV)
         res = {}
-        keep = (K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN)
+        keep = (K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN, K.switches.SPARSE_AMAX_BWD)
         try:
             K.switches.FUSED_AMAX_MIN_ROWS = 0
+            # the bit comparison is between forms that share the dense input-gradient product; a_max's product-free input gradient
+            # (round 5: mrg_segmax_bwd_input, exact f32 sums over the columns an edge won) is compared with it to rounding below
+            K.switches.SPARSE_AMAX_BWD = False
             for fast in (True, False):
                 K.switches.GROUPED_SEGMENTS = K.switches.FUSED_AMAX = K.switches.FUSED_AMEAN = fast
                 res[fast] = run(op, g, a0, b0_, gout, tied)
+            if kind == "a_max":
+                K.switches.GROUPED_SEGMENTS = K.switches.FUSED_AMAX = K.switches.FUSED_AMEAN = True
+                K.switches.SPARSE_AMAX_BWD = True
+                res["sparse"] = run(op, g, a0, b0_, gout, tied)
         finally:
-            K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN = keep
+            (K.switches.GROUPED_SEGMENTS, K.switches.FUSED_AMAX, K.switches.FUSED_AMAX_MIN_ROWS, K.switches.FUSED_AMEAN,
+             K.switches.SPARSE_AMAX_BWD) = keep
         def same(x, y):
             if x is None or y is None:
                 return x is None and y is None
@@ -64,6 +72,11 @@ for c in range(cases):
                 return bool(((x - y).abs() <= 2e-5 * max(1.0, float(y.abs().max())) + 1e-6).all())
             return torch.equal(x, y)
         ok = len(res[True]) == len(res[False]) and all(same(x, y) for x, y in zip(res[True], res[False]))
+        if ok and "sparse" in res:                         # same output, message gradient (hence weight / bias gradients) bit for bit; gx to rounding
+            sp, de = res["sparse"], res[True]
+            ok = len(sp) == len(de) and all(((x is None and y is None) or (x is not None and y is not None and torch.equal(x, y)))
+                                            for i, (x, y) in enumerate(zip(sp, de)) if i != 1)
+            ok = ok and bool(((sp[1] - de[1]).abs() <= 2e-5 * max(1.0, float(de[1].abs().max())) + 1e-6).all())
         if not ok:
             bad += 1
             print(f"MISMATCH case {c}: {kind} tied={tied} N={N} E={E} b0={b0} D={D}")
