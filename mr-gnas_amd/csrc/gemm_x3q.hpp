@@ -186,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue_q(const GemmArgs& a, f32x4v (&acc)
 #ifndef MRG_X3Q_WPS
 #define MRG_X3Q_WPS 3        // lab: waves per SIMD the kernel is compiled for (3: <= 168 registers)
 #endif
-// lab switches (timing only -- wrong results; tools/lab/q_parts.sh builds one library per value into tools/labso/):
+// lab switches (timing only -- wrong results; tools/lab/kernel_lab.sh libs NAME=-DMRG_X3Q_DBG=V:linear.hip,dense.hip builds one library per value into tools/labso/):
 // 1 no epilogue, 2 no A loads after the prologue, 4 no weight DMA after the prologue, 8 no barriers after the prologue,
 // 16 no fragment reads after the first tile, 32 no split arithmetic
 #ifndef MRG_X3Q_DBG
