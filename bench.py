@@ -618,9 +618,12 @@ def main():
     if args.hip_graph or direct:
         # a captured step runs on ONE stream: capturing the candidate / segment side streams of the full-size step
         # segfaults inside the HIP runtime (with and without RCCL in the capture)
-        os.environ["MRG_MIXED_STREAMS"] = "1"
+        # LAB: MRG_GRAPH_STREAMS=N keeps N candidate streams inside the capture (the captured graph then has parallel branches: the
+        # question for launch-bound sampled steps whose kernels each fill a fraction of the chip; MRG_FORK_MIN_ROWS=0 lets them fork)
+        gs = int(os.environ.get("MRG_GRAPH_STREAMS", "1"))
+        os.environ["MRG_MIXED_STREAMS"] = str(gs)
         os.environ["MRG_SEGMENT_STREAMS"] = "1"
-        CL.MIXED_STREAMS = 1
+        CL.MIXED_STREAMS = gs
         from mr_gnas_amd import functional as _KF
         _KF.switches.SEGMENT_STREAMS = 1
     if sharded:
