@@ -876,7 +876,7 @@ def main():
             r = raw_stats["mrg_fused_gcs"]
             flops = 2.0 * args.dim * args.dim * step.E * r["launches"] / max(1, r["launches"])
             sec = r["ms"] / 1e3 / r["launches"]
-            out["ccorr_kernel"] = {"kernel": "mrg_fused_gcs [gcs_corr_k]", "bound": "valu", "flop_per_launch": flops, "us_per_launch": round(sec * 1e6, 1),
+            out["ccorr_kernel"] = {"kernel": "mrg_fused_gcs [gcs_corr8_k]", "bound": "valu", "flop_per_launch": flops, "us_per_launch": round(sec * 1e6, 1),
                                    "achieved": round(flops / sec / 1e12, 2), "peak": VALU_F32_PEAK_TFS, "unit": "TFLOP/s",
                                    "frac": round(flops / sec / 1e12 / VALU_F32_PEAK_TFS, 4),
                                    "note": "circular correlation by its definition, 2 D^2 flop per edge (the reference's FFT form is O(D log D) but "

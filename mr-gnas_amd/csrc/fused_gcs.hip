@@ -217,9 +217,115 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
   }
 }
 
+// ---- circular correlation / convolution with EIGHT outputs per lane (round 5) ---------------------------------------------------------
+// gcs_corr_k above is bound by LDS issue: per four steps of i a lane reads two ds_read_b128 (the next four window values and the
+// broadcast x) for sixteen multiply-adds, and the four SIMDs of a CU share one LDS pipe -- 0.25 of the vector peak.  Here a lane owns
+// EIGHT consecutive outputs k0 .. k0+7: the register window is twelve values (w0 | w1 | wn), one step of four i still costs two
+// ds_read_b128 but feeds THIRTY-TWO multiply-adds.  A row needs D / 8 lanes, so a wave carries two chunks (LPR = 32).  Every output's
+// sum runs over i ascending as in gcs_corr_k; the two agree to rounding (3e-7: the compiler contracts the multiply-adds differently).
+// D % 8 == 0, D <= 256; MRG_CORR8=0 keeps the four-output kernel.
+template <int MODE, int OUT>
+__global__ __launch_bounds__(MRG_BLOCK) void gcs_corr8_k(const float* __restrict__ X, const int32_t* __restrict__ xi,
+                                                         const float* __restrict__ Y, const int32_t* __restrict__ yi,
+                                                         const float* __restrict__ scal, const int32_t* __restrict__ eid,
+                                                         const int32_t* __restrict__ chunk_node, const int32_t* __restrict__ chunk_start,
+                                                         const int32_t* __restrict__ chunk_end, const int32_t* __restrict__ chunk_slot,
+                                                         int64_t n_chunks, float* __restrict__ out, float* __restrict__ ws_val, int D) {
+  // OUT outputs per lane (8 or 16): LPR = 256 / OUT lanes per row cover up to 256 outputs; the last lane of a row may own outputs
+  // beyond D (computed from the zero padding behind z | z, never stored)
+  constexpr int LPR = 256 / OUT, RPB = MRG_BLOCK / LPR;
+  constexpr int XW = 256, ZW = 2 * 256 + 32;               // x | z z + the window's read-ahead / the overhang of a partial last lane
+  __shared__ __align__(16) float lds[RPB * (XW + ZW)];
+  const int sl = threadIdx.x % LPR, rw = threadIdx.x / LPR;
+  const int d4 = D >> 2, dl = (D + OUT - 1) / OUT;         // lanes of a row that own outputs
+  float* lx = lds + rw * (XW + ZW);
+  float* lz = lx + XW;
+  for (int64_t ch = (int64_t)blockIdx.x * RPB + rw; ch < n_chunks; ch += (int64_t)gridDim.x * RPB) {
+    const int v = chunk_node[ch];
+    if (v < 0) continue;                                    // padding beyond the plan's real chunks (the whole lane group skips together)
+    const int j0 = chunk_start[ch], j1 = chunk_end[ch];
+    const int slot = chunk_slot[ch];
+    float acc[OUT];
+#pragma unroll
+    for (int q = 0; q < OUT; ++q) acc[q] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+      const int e = eid[j];
+      const float s = scal != nullptr ? scal[e] : 1.0f;
+      const float* xr = X + (int64_t)xi[e] * D;
+      const float* yr = Y + (int64_t)yi[e] * D;
+      __threadfence_block();                                // earlier reads of lx / lz by this lane group are done
+      __builtin_amdgcn_wave_barrier();
+      for (int c = sl; c < d4; c += LPR) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + c * 4), b = *reinterpret_cast<const float4*>(yr + c * 4);
+        *reinterpret_cast<float4*>(lx + c * 4) = a;
+        if (MODE == MRG_GCS_CCORR) {
+          *reinterpret_cast<float4*>(lz + c * 4) = b;
+          *reinterpret_cast<float4*>(lz + D + c * 4) = b;
+        } else {                                            // z[m] = y[(D - m) % D] in both copies
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = (c * 4 + i) == 0 ? 0 : D - (c * 4 + i);
+            lz[m] = bb[i];
+            lz[D + m] = bb[i];
+          }
+        }
+      }
+      for (int c = sl; c < 8; c += LPR) *reinterpret_cast<float4*>(lz + 2 * D + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);   // behind z | z: finite
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      if (sl < dl) {
+        const float* zp = lz + sl * OUT;
+        float w[OUT + 4];
+#pragma unroll
+        for (int q = 0; q < OUT; q += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(zp + q);
+          w[q] = t.x; w[q + 1] = t.y; w[q + 2] = t.z; w[q + 3] = t.w;
+        }
+        float p[OUT];
+#pragma unroll
+        for (int q = 0; q < OUT; ++q) p[q] = 0.f;
+#pragma unroll 10
+        for (int i = 0; i < D; i += 4) {                    // (ten steps per trip: the window rotates through its registers without moves)
+          const float4 xv = *reinterpret_cast<const float4*>(lx + i);
+          const float4 wn = *reinterpret_cast<const float4*>(zp + i + OUT);
+          w[OUT] = wn.x; w[OUT + 1] = wn.y; w[OUT + 2] = wn.z; w[OUT + 3] = wn.w;
+          const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < OUT; ++q) p[q] += xs[t] * w[t + q];
+#pragma unroll
+          for (int q = 0; q < OUT; ++q) w[q] = w[q + 4];
+        }
+#pragma unroll
+        for (int q = 0; q < OUT; ++q) acc[q] += p[q] * s;
+      }
+    }
+    float* dst = slot < 0 ? out + (int64_t)v * D : ws_val + (int64_t)slot * D;
+    if (sl < dl) {
+#pragma unroll
+      for (int q = 0; q < OUT; q += 4) {
+        const int kp = sl * OUT + q;
+        if (kp < D) {                                       // D % 4 == 0: whole float4s
+          if (MODE == MRG_GCS_CCORR) {
+            *reinterpret_cast<float4*>(dst + kp) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+          } else {                                          // corr(x, z)[k'] = conv(x, y)[(D - k') % D]
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[(kp + u) == 0 ? 0 : D - (kp + u)] = acc[q + u];
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace mrg
 
 using namespace mrg;
+
+// lab switch: MRG_CORR8=0 keeps the four-outputs-per-lane kernel
+static int corr8_on() { static const int v = [] { const char* e = getenv("MRG_CORR8"); return e ? atoi(e) : 8; }(); return v; }
 
 extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const float* Y, const int32_t* yi,
                              const float* scal, const int32_t* eid, const int32_t* chunk_node, const int32_t* chunk_start,
@@ -238,6 +344,8 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
   RowGeom g = row_geom(D, aligned16(X) && aligned16(Y) && aligned16(out) && aligned16(ws));
   if (!g.ok) return MRG_E_SHAPE;
   (void)needs_y;
+  // eight or sixteen outputs per lane (gcs_corr8_k; MRG_CORR8 = 0 / 8 / 16)
+  const int corr8 = (corr8_on() && g.vec == 4 && D <= 256 && D >= 16) ? (corr8_on() == 16 ? 16 : (D % 8 == 0 ? 8 : 0)) : 0;
 #define LAUNCH(KERN, V, L, K, M)                                                                                       \
   hipLaunchKernelGGL((KERN<V, L, K, M>), dim3(grid), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, eid, chunk_node,       \
                      chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D)
@@ -249,8 +357,20 @@ extern "C" int mrg_fused_gcs(int mode, const float* X, const int32_t* xi, const 
       case MRG_GCS_MUL: LAUNCH(gcs_k, V, L, K, MRG_GCS_MUL); break;                                                    \
       case MRG_GCS_COPY: LAUNCH(gcs_k, V, L, K, MRG_GCS_COPY); break;                                                  \
       case MRG_GCS_NEGS: LAUNCH(gcs_k, V, L, K, MRG_GCS_NEGS); break;                                                  \
-      case MRG_GCS_CCORR: LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCORR); break;                                           \
-      default: LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCONV); break;                                                      \
+      case MRG_GCS_CCORR:                                                                                              \
+        if (corr8) { if (corr8 == 16) hipLaunchKernelGGL((gcs_corr8_k<MRG_GCS_CCORR, 16>), dim3(grid_for(n_chunks, MRG_BLOCK / 16)), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, \
+                                        eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D); \
+          else hipLaunchKernelGGL((gcs_corr8_k<MRG_GCS_CCORR, 8>), dim3(grid_for(n_chunks, MRG_BLOCK / 32)), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, \
+                                        eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D); }  \
+        else LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCORR);                                                               \
+        break;                                                                                                         \
+      default:                                                                                                         \
+        if (corr8) { if (corr8 == 16) hipLaunchKernelGGL((gcs_corr8_k<MRG_GCS_CCONV, 16>), dim3(grid_for(n_chunks, MRG_BLOCK / 16)), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, \
+                                        eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D); \
+          else hipLaunchKernelGGL((gcs_corr8_k<MRG_GCS_CCONV, 8>), dim3(grid_for(n_chunks, MRG_BLOCK / 32)), dim3(MRG_BLOCK), 0, st, X, xi, Y, yi, scal, \
+                                        eid, chunk_node, chunk_start, chunk_end, chunk_slot, n_chunks, out, ws_val, D); }  \
+        else LAUNCH(gcs_corr_k, V, L, K, MRG_GCS_CCONV);                                                               \
+        break;                                                                                                         \
     }                                                                                                                  \
     if (n_hubs > 0) {                                                                                                  \
       int gh = n_hubs < 4096 ? (int)n_hubs : 4096;                                                                        \
