@@ -167,7 +167,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void gcs_corr_k(const float* __restrict_
             const float* zp = ly + c * 4;
             float4 w = *reinterpret_cast<const float4*>(zp);
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-            for (int i = 0; i < D; i += 4) {
+#pragma unroll 10
+            for (int i = 0; i < D; i += 4) {                // (unrolled: the window rotates through registers without the four moves per step)
               const float4 xv = *reinterpret_cast<const float4*>(lx + i);
               const float4 wn = *reinterpret_cast<const float4*>(zp + i + 4);
               p0 += xv.x * w.x;  p1 += xv.x * w.y;  p2 += xv.x * w.z;  p3 += xv.x * w.w;
