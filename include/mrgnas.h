@@ -440,9 +440,9 @@ int mrg_gemm_set_wide8(int on);
  * time instead of 16, so the two agree to rounding (both pinned <= 1.5 x the exact-f32 core's error against float64).  Measured:
  * -5 .. -12 % per launch at K = 400, equal at K = 200 (profiles/r5_rowgemm_q.txt).  Process-wide. */
 int mrg_gemm_set_q(int on);
-/* ABI 14.  1 (default): split-core products of at most 4 096 rows (a sampled step graph, a rank's node chunk) run on the wave-
+/* ABI 14.  1 (default): split-core products of at most 16 384 rows (a sampled step graph, a rank's node chunk) run on the wave-
  * autonomous kernel with two-tile column blocks -- 3.5 x more waves with a 3.5 x shorter instruction chain each; same k-order per
- * output element, bit-identical results.  0: one kernel for every row count. */
+ * output element, bit-identical results.  0: one kernel for every row count.  on > 1 (lab): the row bound itself. */
 int mrg_gemm_set_small(int on);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it

@@ -35,16 +35,16 @@ inline bool x3q_shape(int epi, int N, int K) {
 
 // FEW ROWS (round 5: the sampled search step of graph_batch_size 300, a rank's node chunk).  A 128-row workgroup of rowgemm_x3s_k
 // walks all seven column tiles of its rows: 546 matrix instructions per wave one behind the other, ~20 us however few rows there
-// are, on an otherwise idle chip.  Below X3N_MAX_ROWS the product runs on the wave-autonomous kernel of gemm_x3.hpp with column
+// are, on an otherwise idle chip.  Up to X3N_MAX_ROWS rows the product runs on the wave-autonomous kernel of gemm_x3.hpp with column
 // blocks of TWO tiles (grid.y = 4 for 200 columns): 3.5 x more waves, each with a 3.5 x shorter chain.  Same operands, same order of
 // the k-sum per output element: bit-identical with rowgemm_x3s_k (tests/test_ops_gpu.py::test_few_rows_row_gemm_is_bit_exact), so a
 // grouped launch and its per-range launches may fall on different sides of the bound.  Not for the shapes of rowgemm_x3q_k (another
 // summation order: those keep one kernel for every row count).  mrg_gemm_set_small(0) switches it off.
-constexpr int64_t X3N_MAX_ROWS = 4096;
+constexpr int64_t X3N_MAX_ROWS = 16384;     // measured crossover (linear 200 x 200, one MI355X): 13 vs 24 us at 4 096 rows, 19 vs 27 at 16 384, 31 vs 30 at 32 768
 constexpr int X3N_NT = 2;
-inline int& gemm_small() { static int m = 1; return m; }
+inline int64_t& gemm_small() { static int64_t m = X3N_MAX_ROWS; return m; }     // the row bound; 0 = off (mrg_gemm_set_small)
 inline bool x3n_shape(int epi, int64_t rows, int N, int K) {
-  return gemm_mode() == 0 && gemm_small() != 0 && rows > 0 && rows <= X3N_MAX_ROWS && gemm_pick_nt(N) > X3N_NT && N <= 224 && !x3q_shape(epi, N, K);
+  return gemm_mode() == 0 && rows > 0 && rows <= gemm_small() && gemm_pick_nt(N) > X3N_NT && N <= 224 && !x3q_shape(epi, N, K);
 }
 
 // bytes of ONE pre-split weight in whichever layout a launch of this shape may use

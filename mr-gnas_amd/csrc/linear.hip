@@ -977,8 +977,8 @@ extern "C" int mrg_gemm_set_wide8(int on) {
 }
 
 extern "C" int mrg_gemm_set_small(int on) {
-  if (on != 0 && on != 1) return MRG_E_ENUM;
-  gemm_small() = on;
+  if (on < 0) return MRG_E_ENUM;
+  gemm_small() = on == 1 ? X3N_MAX_ROWS : (int64_t)on;      // 0 off, 1 the default bound, > 1 (lab) that many rows
   return MRG_OK;
 }
 
