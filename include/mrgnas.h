@@ -444,6 +444,10 @@ int mrg_gemm_set_q(int on);
  * autonomous kernel with two-tile column blocks -- 3.5 x more waves with a 3.5 x shorter instruction chain each; same k-order per
  * output element, bit-identical results.  0: one kernel for every row count.  on > 1 (lab): the row bound itself. */
 int mrg_gemm_set_small(int on);
+/* ABI 14 (lab).  mrg_linear_bwd_weight3 sizes the row blocks of its (up to three) ranges so that the ranges TOGETHER get about one
+ * workgroup per CU.  A caller that launches the ranges one by one with mrg_linear_bwd_weight and wants the SAME partial sums (bit
+ * for bit) announces the number of ranges (1..3) around those calls; 1 (default) = a launch is alone. */
+int mrg_wgrad_set_share(int n);
 /* The split-core weight gradient (mrg_linear_bwd_weight / _weight3): 1 (default) = every 32-column x 16-row operand fragment is
  * split into its bf16 planes ONCE per workgroup and shared through LDS (wgrad_x3v_k), 0 = by every wave that multiplies it
  * (wgrad_x3_k, rounds 1-2).  Same operands and products in the same order: bit-identical gradients for any shape. */

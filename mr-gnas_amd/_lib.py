@@ -78,6 +78,7 @@ SIGNATURES = {
     "mrg_gemm_set_q": (_I, [_I]),
     "mrg_set_dynamic_rows": (_I, [_L, _P, _L, _P]),
     "mrg_gemm_set_small": (_I, [_I]),
+    "mrg_wgrad_set_share": (_I, [_I]),
     "mrg_segmax_bwd_input_ok": (_I, [_I, _I]),
     "mrg_segmax_bwd_input": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
     "mrg_optim_chunk": (_I, []),

@@ -744,7 +744,13 @@ struct WgradPlan {
   bool ok;
 };
 
-static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
+// How many row ranges share one weight-gradient launch (the three direction segments of a dense filter: mrg_linear_bwd_weight3), so
+// that the ranges TOGETHER, not each of them, get about one workgroup per CU: with 15 000-row ranges (the 30 000-edge search step) three
+// ranges of 59 row blocks x 2 column blocks were 354 workgroups = 1.4 rounds of the chip, 46 us where one round of 23-tile blocks
+// takes 33.  A lab path that launches the ranges one by one says so with mrg_wgrad_set_share, to keep the same partial sums.
+static int g_wgrad_share = 1;
+
+static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false, int share = 0) {
   WgradPlan p{};
   p.TM = (Nout + 31) / 32;
   p.TN = (K + 1 + 31) / 32;
@@ -771,7 +777,12 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false) {
   // ... and about one workgroup per CU: 256 / (column blocks of the split-core kernel) row blocks (the figure depends on
   // the shape only, never on the kernel chosen: the workspace query and the launch must agree)
   const int ny = (p.TN + (p.TM <= 4 ? 16 : 8) - 1) / (p.TM <= 4 ? 16 : 8);
-  const int64_t gmax = 256 / ny > 32 ? 256 / ny : 32;
+  // (only where a range alone is far from filling the chip -- at most 64 row blocks of 16 tiles: measured -13 % at 15 000-row ranges,
+  //  but +20 % at 272 000-row ranges, where three rounds of 128 shorter workgroups per range beat one round of long ones)
+  const int sh = (share > 0 ? share : g_wgrad_share);
+  const bool shared = sh > 1 && (tiles + 15) / 16 <= 64;
+  const int64_t gshare = 256 / (ny * sh);
+  const int64_t gmax = !shared ? (256 / ny > 32 ? 256 / ny : 32) : (gshare > 16 ? gshare : 16);
   int64_t G = (tiles + 15) / 16 < gmax ? (tiles + 15) / 16 : gmax;
   // few rows (a sampled step graph, a rank's node chunk): a workgroup walks its 16-row tiles one barrier at a time (~2 us each), so
   // one or two workgroups of 16 tiles are a 30 us latency chain on an idle chip -- up to eight workgroups of >= 4 tiles instead
@@ -976,6 +987,12 @@ extern "C" int mrg_gemm_set_wide8(int on) {
   return MRG_OK;
 }
 
+extern "C" int mrg_wgrad_set_share(int n) {
+  if (n < 1 || n > 3) return MRG_E_ENUM;
+  g_wgrad_share = n;
+  return MRG_OK;
+}
+
 extern "C" int mrg_gemm_set_small(int on) {
   if (on < 0) return MRG_E_ENUM;
   gemm_small() = on == 1 ? X3N_MAX_ROWS : (int64_t)on;      // 0 off, 1 the default bound, > 1 (lab) that many rows
@@ -1146,9 +1163,12 @@ extern "C" int mrg_linear_bwd_weight3(const float* gY, const float* X1, const fl
   WgradPlan p0 = wgrad_plan(1, K, Nout, true);
   if (!p0.ok || p0.TM > 7) return MRG_E_SHAPE;
   a.TM = p0.TM; a.TN = p0.TN; a.TNB = p0.TNB;
+  int nlive = 0;
+  for (int i = 0; i < 3; ++i) nlive += (gW_host[i] != nullptr && hi[i] > lo[i]) ? 1 : 0;
+  if (nlive < 1) nlive = 1;
   for (int i = 0; i < 3; ++i) {
     const int64_t rows = hi[i] - lo[i];
-    WgradPlan p = wgrad_plan(rows, K, Nout, true);
+    WgradPlan p = wgrad_plan(rows, K, Nout, true, nlive);
     const bool live = gW_host[i] != nullptr;
     a.g_lo[i] = lo[i]; a.g_hi[i] = hi[i]; a.g_rpb[i] = p.rows_per_block; a.g_G[i] = live ? p.G : 0; a.g_ws_off[i] = off / (int64_t)sizeof(float);
     red.ws[i] = (const float*)((const char*)ws + off); red.gW[i] = gW_host[i]; red.gbias[i] = gb_host ? gb_host[i] : nullptr; red.G[i] = p.G;

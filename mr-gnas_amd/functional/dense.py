@@ -115,6 +115,10 @@ class _DenseFilter(torch.autograd.Function):
                              wt2=_ws(_ws_bytes("mrg_linear_bwd_input_workspace_bytes", D, D), s) if s_in is not None else None,
                              ws=_ws(_ws_bytes("mrg_linear_bwd_weight_workspace_bytes", rows, K_, D), s)))
         fork = Fork(s.device, len(work) if M >= SW.FORK_MIN_ROWS else 1)
+        # (lab path: one launch per direction segment.  The grouped launch sizes its row blocks for the ranges together: say so, to get
+        #  the same partial sums bit for bit -- mrg_wgrad_set_share)
+        live_ranges = sum(1 for w in work if w["rows"] > 0)
+        lib.mrg_wgrad_set_share(max(1, min(3, live_ranges)))
         for j, w in enumerate(work):
             W, rows, sl = w["W"], w["rows"], w["sl"]
             with fork.on(j):
@@ -135,6 +139,7 @@ class _DenseFilter(torch.autograd.Function):
                                                ptr(w["gb"]), ptr(w["ws"]), rows, D, D if s_in is not None else 0, D, st),
                      nbytes=4 * rows * (D + K_), flops=2 * rows * K_ * D)
         fork.join()
+        lib.mrg_wgrad_set_share(1)
         return (None, None, gs, gs_in, None, None, None, None, None, *grads)
 
 
