@@ -749,6 +749,7 @@ struct WgradPlan {
 // ranges of 59 row blocks x 2 column blocks were 354 workgroups = 1.4 rounds of the chip, 46 us where one round of 23-tile blocks
 // takes 33.  A lab path that launches the ranges one by one says so with mrg_wgrad_set_share, to keep the same partial sums.
 static int g_wgrad_share = 1;
+static int wgrad_share_max_blocks() { static const int v = [] { const char* e = getenv("MRG_WGRAD_SHARE_MAX"); return e ? atoi(e) : 400; }(); return v; }   // lab; measured: 15 000-row ranges -13 %, 87 000-row ranges (WN18RR) -10 %, 272 000-row ranges (1 063 blocks) +20 %
 
 static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false, int share = 0) {
   WgradPlan p{};
@@ -777,10 +778,10 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false, int
   // ... and about one workgroup per CU: 256 / (column blocks of the split-core kernel) row blocks (the figure depends on
   // the shape only, never on the kernel chosen: the workspace query and the launch must agree)
   const int ny = (p.TN + (p.TM <= 4 ? 16 : 8) - 1) / (p.TM <= 4 ? 16 : 8);
-  // (only where a range alone is far from filling the chip -- at most 64 row blocks of 16 tiles: measured -13 % at 15 000-row ranges,
-  //  but +20 % at 272 000-row ranges, where three rounds of 128 shorter workgroups per range beat one round of long ones)
+  // (only up to 400 row blocks of 16 tiles per range: measured -13 % at 15 000-row ranges,
+  //  -10 % at 87 000-row ranges, but +20 % at 272 000-row ranges, where three rounds of 128 shorter workgroups per range beat one round of long ones)
   const int sh = (share > 0 ? share : g_wgrad_share);
-  const bool shared = sh > 1 && (tiles + 15) / 16 <= 64;
+  const bool shared = sh > 1 && (tiles + 15) / 16 <= wgrad_share_max_blocks();
   const int64_t gshare = 256 / (ny * sh);
   const int64_t gmax = !shared ? (256 / ny > 32 ? 256 / ny : 32) : (gshare > 16 ? gshare : 16);
   int64_t G = (tiles + 15) / 16 < gmax ? (tiles + 15) / 16 : gmax;
