@@ -783,7 +783,8 @@ static WgradPlan wgrad_plan(int64_t rows, int K, int Nout, bool dma = false, int
   const int sh = (share > 0 ? share : g_wgrad_share);
   const bool shared = sh > 1 && (tiles + 15) / 16 <= wgrad_share_max_blocks();
   const int64_t gshare = 256 / (ny * sh);
-  const int64_t gmax = !shared ? (256 / ny > 32 ? 256 / ny : 32) : (gshare > 16 ? gshare : 16);
+  static const int gmul = [] { const char* e = getenv("MRG_WGRAD_GMUL"); return e ? atoi(e) : 1; }();      // lab: rounds of workgroups per range
+  const int64_t gmax = !shared ? ((256 / ny > 32 ? 256 / ny : 32) * gmul) : (gshare > 16 ? gshare : 16);
   int64_t G = (tiles + 15) / 16 < gmax ? (tiles + 15) / 16 : gmax;
   // few rows (a sampled step graph, a rank's node chunk): a workgroup walks its 16-row tiles one barrier at a time (~2 us each), so
   // one or two workgroups of 16 tiles are a 30 us latency chain on an idle chip -- up to eight workgroups of >= 4 tiles instead
