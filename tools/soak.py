@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 args = bench.parse()
+from mr_gnas_amd import cell_lp as _CL  # noqa: E402
+_CL.CALLER = args.caller                              # --caller reference: the reference's literal formulation on lazy handles
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 step = bench.Step(args, dev, bench.build_step_inputs(args.workload, args.negative, args.seed))
